@@ -1,0 +1,102 @@
+/*
+ * simplerecon_hip.h -- C ABI of libsimplerecon_hip.so (MI355X / gfx950).
+ *
+ * The upstream reference (nianticlabs/simplerecon) has NO native code and NO FFI:
+ * its "plugin point" for this path is a Python class contract plus an attribute
+ * swap (`model.cost_volume = model.cost_volume.to_fast()`, reference test.py:196-198).
+ * This header is therefore the boundary a maintainer binds from Python (ctypes stub
+ * in INTEGRATION.md); each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 unless stated; tensors are dense in the
+ *    stated layout; the caller owns and allocates every buffer (no allocation, no
+ *    ownership transfer, no global mutable state, no host synchronisation inside);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *  - return value: 0 = ok, SR_ERR_* for argument errors, 1000 + hipError_t for a
+ *    failed launch.  Nothing throws across the ABI.  Re-entrant; safe from several
+ *    host threads on different streams as long as workspaces are not shared.
+ *  - 4x4 matrices are row-major, 16 floats.
+ */
+#ifndef SIMPLERECON_HIP_H_
+#define SIMPLERECON_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_OK 0
+#define SR_ERR_INVALID_ARGUMENT 1
+#define SR_ERR_UNSUPPORTED 2
+#define SR_ERR_WORKSPACE_TOO_SMALL 3
+#define SR_ERR_HIP_BASE 1000
+
+/* ABI version; bumped on any signature change. */
+int sr_abi_version(void);
+
+/* Name of the GPU architecture this library was compiled for ("gfx950"). */
+const char* sr_target_arch(void);
+
+/* ------------------------------------------------------------------ cost volume --
+ *
+ * Depth planes are addressed  planes[b*ps_b + j*ps_d + y*ps_y + x*ps_x]  (strides in
+ * elements): (D,1,0,0) for the [B,D] values of generate_depth_planes (reference
+ * modules/cost_volume.py:100-136), (D*h*w, h*w, w, 1) for a caller-supplied
+ * depth_planes_bdhw (cost_volume.py:247, 297-299).
+ *
+ * The volume is written at  out_cv[b*cv_sb + j*cv_sd + (y*w + x)*cv_sp]:
+ * (D*h*w, h*w, 1) = the reference's b,d,h,w layout, (D*h*w, 1, D) = channels-last.
+ */
+
+/* Scratch bytes needed by sr_dot_volume_fwd / sr_mlp_volume_fwd for these sizes. */
+size_t sr_volume_workspace_bytes(int B, int K, int C, int h, int w);
+
+/* Stage 1 of either sweep: per-(b,k) geometry records (P = K_src @ T_src_cur, reference
+ * utils/geometry_utils.py:78; source camera centres and the DVMVS pose measures of
+ * geometry_utils.py:178-191 when T_cur_src != NULL) and the channels-last repack of `src`
+ * ([B,K,C,h,w] -> [B*K, h*w, C]) into `workspace`.  T_cur_src = cur_cam_T_src_cam ("src_poses"),
+ * [B,K,16], may be NULL for the dot model. */
+int sr_volume_prepare(const float* src, const float* K_src, const float* T_src_cur,
+                      const float* T_cur_src, int B, int K, int C, int h, int w, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* Stage 2 of the dot model: the sweep kernel alone, on a workspace filled by
+ * sr_volume_prepare for the same sizes (lets a caller time / profile / re-run it alone). */
+int sr_dot_volume_sweep(const float* cur, const float* invK_cur, const float* planes, int64_t ps_b,
+                        int64_t ps_d, int64_t ps_y, int64_t ps_x, int B, int K, int C, int h, int w,
+                        int D, float* out_cv, int64_t cv_sb, int64_t cv_sd, int64_t cv_sp,
+                        float* out_lowest, uint8_t* out_mask, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* Fused plane sweep of the dot-product model (= sr_volume_prepare + sr_dot_volume_sweep): replaces
+ *   CostVolumeManager.build_cost_volume + forward      (cost_volume.py:237-380)
+ *   = BackprojectDepth (utils/geometry_utils.py:51-59) + Project3D (:72-89)
+ *   + F.grid_sample(bilinear, zeros, align_corners=False) (cost_volume.py:201-212)
+ *   + sum_c(warped * cur) * (z' > 0), summed over views  (cost_volume.py:322-329)
+ *   + argmax / gather of the depth planes               (cost_volume.py:338-342, 374-378)
+ * in one launch per batch, never materialising the warped features.
+ *
+ *  cur        [B,C,h,w]      reference-frame matching features
+ *  src        [B,K,C,h,w]    source-frame matching features
+ *  K_src      [B,K,16]       source intrinsics at matching resolution (K_s1_b44)
+ *  T_src_cur  [B,K,16]       src_cam_T_cur_cam  ("src_extrinsics")
+ *  invK_cur   [B,16]         inverse reference intrinsics ("cur_invK")
+ *  out_cv     see above;  out_lowest [B,h,w] (may be NULL);
+ *  out_mask   [B,h,w] uint8 (may be NULL): any_k(z'>0) & any_k(2<u<w-2 & 2<v<h-2) at the
+ *             LAST plane -- the rule of cost_volume.py:625-637 (the dot model itself
+ *             returns None, cost_volume.py:286, 335).
+ *  C must be a multiple of 4 and <= 32.
+ */
+int sr_dot_volume_fwd(const float* cur, const float* src, const float* K_src,
+                      const float* T_src_cur, const float* invK_cur, const float* planes,
+                      int64_t ps_b, int64_t ps_d, int64_t ps_y, int64_t ps_x, int B, int K, int C,
+                      int h, int w, int D, float* out_cv, int64_t cv_sb, int64_t cv_sd,
+                      int64_t cv_sp, float* out_lowest, uint8_t* out_mask, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMPLERECON_HIP_H_ */

@@ -1,0 +1,91 @@
+"""ctypes binding of libsimplerecon_hip.so (the C ABI of include/simplerecon_hip.h).
+
+There is NO fallback: if the library is missing, was built for another architecture, or
+the tensors are not fp32 device tensors, the call fails loudly."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsimplerecon_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_f = C.c_float
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/simplerecon_hip.h
+SIGNATURES = {
+    "sr_abi_version": (_i, []),
+    "sr_target_arch": (C.c_char_p, []),
+    "sr_volume_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sr_volume_prepare": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "sr_dot_volume_sweep": (_i, [_p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i,
+                                 _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
+    "sr_dot_volume_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i,
+                               _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `python -m simplerecon_amd.build` "
+                "(hipcc --offload-arch=gfx950).  simplerecon_amd has no CPU/torch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if l.sr_abi_version() != ABI_VERSION:
+            raise HipLibraryError(f"ABI mismatch: library {l.sr_abi_version()} vs binding {ABI_VERSION}")
+        _lib = l
+    return _lib
+
+
+_ERRORS = {1: "invalid argument", 2: "unsupported configuration", 3: "workspace too small"}
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERRORS.get(rc, f"hipError {rc - 1000}" if rc >= 1000 else f"error {rc}")
+        raise HipLibraryError(f"{what} failed: {msg}")
+
+
+def require_device_f32(name, t, allow_none=False):
+    if t is None:
+        if allow_none:
+            return
+        raise ValueError(f"{name} is None")
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise HipLibraryError(f"{name} lives on {t.device}: the HIP path needs device tensors (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (the reference runs inference in fp32), got {t.dtype}")
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def refuse_autograd(*tensors):
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            "simplerecon_amd implements the inference hot path only; run under torch.inference_mode() / "
+            "no_grad() (the backward pass is listed as a 'next' component, SURVEY.md §8f)")

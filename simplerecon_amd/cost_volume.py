@@ -1,0 +1,262 @@
+"""Plane-sweep cost volumes -- drop-in for reference modules/cost_volume.py, backed by HIP.
+
+Same class names, constructor arguments, `forward` keyword arguments, return tuples and
+parameter/buffer names as the reference (cost_volume.py:13-380 `CostVolumeManager`,
+:383-746 `FeatureVolumeManager`, :749-1164 `FastFeatureVolumeManager`), so that
+
+    model.cost_volume = simplerecon_amd.cost_volume.to_hip(model.cost_volume)
+
+works exactly like the reference's own `to_fast()` seam (reference test.py:196-198) and a
+reference checkpoint loads with strict=True.  The arithmetic runs in hand-written gfx950
+kernels reached through the C ABI of include/simplerecon_hip.h; there is no torch/CPU
+fallback (inputs must be fp32 device tensors, inference only).
+"""
+import ctypes as C
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from .geometry import BackprojectDepth, Project3D
+from .networks import MLP
+
+
+class CostVolumeManager(nn.Module):
+    """Dot-product plane-sweep volume (reference cost_volume.py:13-380)."""
+
+    def __init__(self, matching_height, matching_width, num_depth_bins=64, matching_dim_size=None,
+                 num_source_views=None):
+        super().__init__()
+        self.num_depth_bins = num_depth_bins
+        self.matching_height = matching_height
+        self.matching_width = matching_width
+        # memory format of the returned volume: contiguous (= the reference's b,d,h,w) or
+        # channels_last (what the HIP CVEncoder consumes without a transpose)
+        self.volume_memory_format = torch.contiguous_format
+        self._workspace = None
+        self.initialise_for_projection()
+
+    # -- state with the reference's names (cost_volume.py:58-74) ---------------------------
+    def initialise_for_projection(self):
+        ramp = torch.linspace(0, 1, self.num_depth_bins).view(1, self.num_depth_bins, 1, 1)
+        self.register_buffer("linear_ramp_1d11", ramp)
+        self.backprojector = BackprojectDepth(height=self.matching_height, width=self.matching_width)
+        self.projector = Project3D()
+
+    # -- public helpers of the reference ----------------------------------------------------
+    def get_mask(self, pix_coords_bk2hw):
+        """Bounds mask of sampling locations (reference cost_volume.py:77-97)."""
+        x, y = pix_coords_bk2hw[:, :, 0], pix_coords_bk2hw[:, :, 1]
+        return (x > 2) & (x < self.matching_width - 2) & (y > 2) & (y < self.matching_height - 2)
+
+    def generate_depth_planes(self, batch_size: int, min_depth: Tensor, max_depth: Tensor) -> Tensor:
+        """Log-spaced planes as an expanded (stride-0) b,d,h,w view (reference cost_volume.py:100-136)."""
+        ramp = self.linear_ramp_1d11.expand(batch_size, self.num_depth_bins, 1, 1)
+        planes_bd11 = torch.exp(torch.log(min_depth) + torch.log(max_depth / min_depth) * ramp)
+        if planes_bd11.stride(0) == 0:  # keep per-batch values addressable with plain strides
+            planes_bd11 = planes_bd11.contiguous()
+        return planes_bd11.expand(batch_size, self.num_depth_bins, self.matching_height, self.matching_width)
+
+    def indices_to_disparity(self, indices, depth_planes_bdhw):
+        """planes[argmax] lookup (reference cost_volume.py:338-342)."""
+        return torch.gather(depth_planes_bdhw, dim=1, index=indices.unsqueeze(1)).squeeze(1)
+
+    # -- HIP plumbing -------------------------------------------------------------------------
+    def _check_inputs(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK):
+        for name, t in (("cur_feats", cur_feats), ("src_feats", src_feats), ("src_extrinsics", src_extrinsics),
+                        ("src_Ks", src_Ks), ("cur_invK", cur_invK)):
+            _lib.require_device_f32(name, t)
+        _lib.refuse_autograd(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
+        if src_feats.dim() != 5 or cur_feats.dim() != 4:
+            raise ValueError("expected cur_feats [b,c,h,w] and src_feats [b,k,c,h,w]")
+        b, k, c, h, w = src_feats.shape
+        if (h, w) != (self.matching_height, self.matching_width):
+            raise ValueError(f"feature maps are {h}x{w}, manager was built for "
+                             f"{self.matching_height}x{self.matching_width}")
+        if tuple(cur_feats.shape) != (b, c, h, w):
+            raise ValueError(f"cur_feats {tuple(cur_feats.shape)} does not match src_feats {tuple(src_feats.shape)}")
+        for name, t, shp in (("src_extrinsics", src_extrinsics, (b, k, 4, 4)), ("src_Ks", src_Ks, (b, k, 4, 4)),
+                             ("cur_invK", cur_invK, (b, 4, 4))):
+            if tuple(t.shape) != shp:
+                raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {shp}")
+        return b, k, c, h, w
+
+    def _planes(self, batch_size, min_depth, max_depth, depth_planes_bdhw):
+        if depth_planes_bdhw is None:
+            depth_planes_bdhw = self.generate_depth_planes(batch_size, min_depth, max_depth)
+        _lib.require_device_f32("depth_planes_bdhw", depth_planes_bdhw)
+        exp = (batch_size, self.num_depth_bins, self.matching_height, self.matching_width)
+        if tuple(depth_planes_bdhw.shape) != exp:
+            raise ValueError(f"depth_planes_bdhw has shape {tuple(depth_planes_bdhw.shape)}, expected {exp}")
+        return depth_planes_bdhw
+
+    def _get_workspace(self, nbytes, device):
+        ws = self._workspace
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._workspace = ws
+        return ws
+
+    def _alloc_outputs(self, b, h, w, device, return_mask):
+        d = self.num_depth_bins
+        vol = torch.empty((b, d, h, w), dtype=torch.float32, device=device,
+                          memory_format=self.volume_memory_format)
+        lowest = torch.empty((b, h, w), dtype=torch.float32, device=device)
+        mask = torch.empty((b, h, w), dtype=torch.uint8, device=device) if return_mask else None
+        return vol, lowest, mask
+
+    @staticmethod
+    def _volume_strides(vol):
+        sb, sd, sy, sx = vol.stride()
+        if sy != vol.shape[3] * sx:
+            raise ValueError("cost volume rows must be dense")
+        return sb, sd, sx
+
+    def _sweep(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+               depth_planes_bdhw, return_mask):
+        b, k, c, h, w = self._check_inputs(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
+        planes = self._planes(b, min_depth, max_depth, depth_planes_bdhw)
+        dev = src_feats.device
+        lib = _lib.lib()
+        vol, lowest, _ = self._alloc_outputs(b, h, w, dev, False)
+        if b == 0:
+            return vol, lowest, planes, None
+        cur, src = cur_feats.contiguous(), src_feats.contiguous()
+        Ks, T, invK = src_Ks.contiguous(), src_extrinsics.contiguous(), cur_invK.contiguous()
+        nws = lib.sr_volume_workspace_bytes(b, k, c, h, w)
+        ws = self._get_workspace(nws, dev)
+        sb, sd, sp = self._volume_strides(vol)
+        with torch.cuda.device(dev):
+            rc = lib.sr_dot_volume_fwd(
+                _lib.ptr(cur), _lib.ptr(src), _lib.ptr(Ks), _lib.ptr(T), _lib.ptr(invK), _lib.ptr(planes),
+                *planes.stride(), b, k, c, h, w, self.num_depth_bins, _lib.ptr(vol), sb, sd, sp,
+                _lib.ptr(lowest), C.c_void_p(0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "sr_dot_volume_fwd")
+        # the dot model ignores return_mask and returns None (reference cost_volume.py:286, 335)
+        return vol, lowest, planes, None
+
+    # -- the reference's entry points -------------------------------------------------------
+    def build_cost_volume(self, cur_feats: Tensor, src_feats: Tensor, src_extrinsics: Tensor, src_poses: Tensor,
+                          src_Ks: Tensor, cur_invK: Tensor, min_depth: Tensor, max_depth: Tensor,
+                          depth_planes_bdhw: Tensor = None, return_mask: bool = False):
+        """Returns (volume_bdhw, depth_planes_bdhw, overall_mask_bhw | None) like reference
+        cost_volume.py:237-335 / 451-736."""
+        vol, _, planes, mask = self._sweep(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK,
+                                           min_depth, max_depth, depth_planes_bdhw, return_mask)
+        return vol, planes, mask
+
+    def forward(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+                depth_planes_bdhw=None, return_mask=False):
+        """Returns (cost_volume, lowest_cost, depth_planes_bdhw, overall_mask_bhw) like reference
+        cost_volume.py:345-380; the argmax/gather is fused into the sweep kernel."""
+        return self._sweep(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth,
+                           max_depth, depth_planes_bdhw, return_mask)
+
+
+def mlp_input_channels(matching_dim_size, num_source_views):
+    """mlp_channels[0] of the reference (cost_volume.py:420-435): visual + depth + ray + angle +
+    mask + dot + pose-penalty channels = C(1+K) + 10K + 4  (202 for C=16, K=7)."""
+    k, c = num_source_views, matching_dim_size
+    return c * (1 + k) + (1 + k) + 3 * (1 + k) + k + k + k + 3 * k
+
+
+class FeatureVolumeManager(CostVolumeManager):
+    """Metadata-MLP feature volume (reference cost_volume.py:383-746).
+
+    `mlp_channels` is taken BY VALUE (the reference mutates a shared default list,
+    cost_volume.py:402, 429 -- harmless there, not replicated)."""
+
+    def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=(202, 128, 128, 1),
+                 matching_dim_size=16, num_source_views=7):
+        super().__init__(matching_height, matching_width, num_depth_bins)
+        chans = list(mlp_channels)
+        chans[0] = mlp_input_channels(matching_dim_size, num_source_views)
+        self.matching_dim_size = matching_dim_size
+        self.num_source_views = num_source_views
+        self.mlp_channels = chans
+        self.mlp = MLP(channel_list=chans, disable_final_activation=True)
+        self._packed = None
+
+    def _mlp_params(self):
+        lin = [m for m in self.mlp.net if isinstance(m, nn.Linear)]
+        if len(lin) != 3 or lin[2].out_features != 1 or lin[0].out_features != lin[1].in_features \
+                or lin[1].out_features != lin[1].in_features:
+            raise _lib.HipLibraryError(f"HIP matching MLP supports [Cin, H, H, 1] channel lists, got {self.mlp_channels}")
+        return lin
+
+    def _sweep(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+               depth_planes_bdhw, return_mask):
+        b, k, c, h, w = self._check_inputs(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
+        _lib.require_device_f32("src_poses", src_poses)
+        if tuple(src_poses.shape) != (b, k, 4, 4):
+            raise ValueError(f"src_poses has shape {tuple(src_poses.shape)}, expected {(b, k, 4, 4)}")
+        lin = self._mlp_params()
+        if lin[0].in_features != mlp_input_channels(c, k):
+            raise ValueError(f"MLP expects {lin[0].in_features} input channels but {k} views x {c} channels "
+                             f"give {mlp_input_channels(c, k)}")
+        planes = self._planes(b, min_depth, max_depth, depth_planes_bdhw)
+        dev = src_feats.device
+        lib = _lib.lib()
+        vol, lowest, mask = self._alloc_outputs(b, h, w, dev, return_mask)
+        if b == 0:
+            return vol, lowest, planes, (mask.bool() if return_mask else None)
+        cur, src = cur_feats.contiguous(), src_feats.contiguous()
+        Ks, T, Tp, invK = (src_Ks.contiguous(), src_extrinsics.contiguous(), src_poses.contiguous(),
+                           cur_invK.contiguous())
+        params = [t.detach().contiguous() for t in (lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
+                                                    lin[2].weight, lin[2].bias)]
+        for i, t in enumerate(params):
+            _lib.require_device_f32(f"mlp parameter {i}", t)
+        hidden = lin[0].out_features
+        nws = lib.sr_mlp_volume_workspace_bytes(b, k, c, h, w, hidden)
+        ws = self._get_workspace(nws, dev)
+        sb, sd, sp = self._volume_strides(vol)
+        with torch.cuda.device(dev):
+            rc = lib.sr_mlp_volume_fwd(
+                _lib.ptr(cur), _lib.ptr(src), _lib.ptr(Ks), _lib.ptr(T), _lib.ptr(Tp), _lib.ptr(invK),
+                _lib.ptr(planes), *planes.stride(), *[_lib.ptr(t) for t in params], hidden,
+                C.c_float(0.01),  # nn.LeakyReLU default slope (reference networks.py:139)
+                b, k, c, h, w, self.num_depth_bins, _lib.ptr(vol), sb, sd, sp, _lib.ptr(lowest),
+                _lib.ptr(mask), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "sr_mlp_volume_fwd")
+        return vol, lowest, planes, (mask.bool() if return_mask else None)
+
+    def to_fast(self) -> "FastFeatureVolumeManager":
+        """Same seam as the reference (cost_volume.py:739-746): shares the MLP."""
+        manager = FastFeatureVolumeManager(self.matching_height, self.matching_width,
+                                           num_depth_bins=self.num_depth_bins, mlp_channels=self.mlp_channels,
+                                           matching_dim_size=self.matching_dim_size,
+                                           num_source_views=self.num_source_views)
+        manager.mlp = self.mlp
+        manager.volume_memory_format = self.volume_memory_format
+        return manager
+
+
+class FastFeatureVolumeManager(FeatureVolumeManager):
+    """The reference's batched variant (cost_volume.py:749-1164) trades O(B*D*N*202) memory for
+    fewer launches.  The fused HIP sweep already is one launch with O(1) intermediates, so this
+    class is the same kernel under the reference's second name."""
+
+
+def to_hip(manager):
+    """Builds the HIP-backed twin of a REFERENCE manager instance (or of one of ours), sharing
+    its MLP and buffers -- the attribute-swap seam of reference test.py:196-198:
+
+        model.cost_volume = simplerecon_amd.cost_volume.to_hip(model.cost_volume)
+    """
+    h, w, d = manager.matching_height, manager.matching_width, manager.num_depth_bins
+    if hasattr(manager, "mlp"):
+        lin = [m for m in manager.mlp.net if isinstance(m, nn.Linear)]
+        cin = lin[0].in_features
+        chans = [cin] + [m.out_features for m in lin]
+        # C(1+K) + 10K + 4 = cin; recover (C, K) from the attributes when present, else assume C = 16
+        c = getattr(manager, "matching_dim_size", 16)
+        k = (cin - c - 4) // (c + 10)
+        new = FeatureVolumeManager(h, w, num_depth_bins=d, mlp_channels=chans, matching_dim_size=c,
+                                   num_source_views=k)
+        new.mlp.load_state_dict(manager.mlp.state_dict())
+    else:
+        new = CostVolumeManager(h, w, num_depth_bins=d)
+    new.linear_ramp_1d11.copy_(manager.linear_ramp_1d11)
+    dev = manager.linear_ramp_1d11.device
+    return new.to(dev)

@@ -1,0 +1,95 @@
+// sr_common.h -- shared device/host helpers for libsimplerecon_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "simplerecon_hip.h"
+
+// Per-(batch, view) geometry record written by sr_geom_kernel into the workspace:
+//   [0,12)  rows 0..2 of P = K_src @ T_src_cur      (reference utils/geometry_utils.py:78-80)
+//   [12,15) t = T_cur_src[:3,3]  (source camera centre in the reference frame; cost_volume.py:654-669)
+//   [15]    pose_dist  [16] R_measure  [17] t_measure  (geometry_utils.py:178-191)
+#define SR_GEOM_STRIDE 20
+
+#define SR_WAVE 64
+
+static inline int sr_hip_rc(hipError_t e) { return e == hipSuccess ? SR_OK : SR_ERR_HIP_BASE + (int)e; }
+
+static inline size_t sr_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct SrPlanes {
+  const float* ptr;
+  int64_t sb, sd, sy, sx;
+};
+
+struct SrVolumeOut {
+  float* cv;
+  int64_t sb, sd, sp;
+  float* lowest;   // [B,h,w] or null
+  uint8_t* mask;   // [B,h,w] or null
+};
+
+// ----------------------------------------------------------------------------------------
+// Geometry shared by the dot-product and the MLP sweep.  Written op-by-op in the reference's
+// order with FP contraction OFF so that pixel coordinates, z', masks and bilinear weights are
+// bit-identical to the fp32 CPU oracle (discontinuous decisions cannot flip).
+// ----------------------------------------------------------------------------------------
+struct SrSample {
+  float zp;            // z' = q_z + 1e-8                    (geometry_utils.py:84)
+  float pix_x, pix_y;  // q_x * s, q_y * s                   (geometry_utils.py:85-87)
+  float w_nw, w_ne, w_sw, w_se;  // bilinear weights, already zeroed for out-of-image taps
+  int o_nw, o_ne, o_sw, o_se;    // texel indices (y*w + x), clamped in-image
+};
+
+__device__ __forceinline__ void sr_project_sample(const float* __restrict__ g /*geom record*/,
+                                                  float X0, float X1, float X2, int h, int w,
+                                                  float inv_w, float inv_h, SrSample& s) {
+#pragma clang fp contract(off)
+  const float eps = 1e-8f;
+  const float q0 = g[0] * X0 + g[1] * X1 + g[2] * X2 + g[3];
+  const float q1 = g[4] * X0 + g[5] * X1 + g[6] * X2 + g[7];
+  const float q2 = g[8] * X0 + g[9] * X1 + g[10] * X2 + g[11];
+  s.zp = q2 + eps;
+  const float sc = (fabsf(q2) > eps) ? 1.0f / s.zp : 1.0f;
+  s.pix_x = q0 * sc;
+  s.pix_y = q1 * sc;
+  // uv = 2*pix*(1/w,1/h) - 1 (cost_volume.py:199); grid_sample unnormalise, align_corners=False
+  const float u = 2.0f * s.pix_x * inv_w - 1.0f;
+  const float v = 2.0f * s.pix_y * inv_h - 1.0f;
+  const float ix = ((u + 1.0f) * (float)w - 1.0f) / 2.0f;
+  const float iy = ((v + 1.0f) * (float)h - 1.0f) / 2.0f;
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
+  const float wm = (float)(w - 1), hm = (float)(h - 1);
+  const bool vx0 = (fx0 >= 0.0f) && (fx0 <= wm), vx1 = (fx1 >= 0.0f) && (fx1 <= wm);
+  const bool vy0 = (fy0 >= 0.0f) && (fy0 <= hm), vy1 = (fy1 >= 0.0f) && (fy1 <= hm);
+  const float ax1 = fx1 - ix, ax0 = ix - fx0, ay1 = fy1 - iy, ay0 = iy - fy0;
+  s.w_nw = (vx0 && vy0) ? ax1 * ay1 : 0.0f;
+  s.w_ne = (vx1 && vy0) ? ax0 * ay1 : 0.0f;
+  s.w_sw = (vx0 && vy1) ? ax1 * ay0 : 0.0f;
+  s.w_se = (vx1 && vy1) ? ax0 * ay0 : 0.0f;
+  // clamp (NaN-safe: fmaxf(NaN, 0) = 0) so every tap address is in-image; weight 0 kills it
+  const int x0 = (int)fminf(fmaxf(fx0, 0.0f), wm), x1 = (int)fminf(fmaxf(fx1, 0.0f), wm);
+  const int y0 = (int)fminf(fmaxf(fy0, 0.0f), hm), y1 = (int)fminf(fmaxf(fy1, 0.0f), hm);
+  s.o_nw = y0 * w + x0;
+  s.o_ne = y0 * w + x1;
+  s.o_sw = y1 * w + x0;
+  s.o_se = y1 * w + x1;
+}
+
+// bounds test of get_mask (cost_volume.py:77-97)
+__device__ __forceinline__ bool sr_in_bounds(const SrSample& s, int h, int w) {
+  return (s.pix_x > 2.0f) && (s.pix_x < (float)(w - 2)) && (s.pix_y > 2.0f) && (s.pix_y < (float)(h - 2));
+}
+
+// workspace carving: [geom records | channels-last source features]
+static inline float* sr_ws_geom(void* workspace) { return (float*)sr_align_up((size_t)workspace, 256); }
+static inline float* sr_ws_src_nhwc(void* workspace, int B, int K) {
+  return (float*)((char*)sr_ws_geom(workspace) + sr_align_up((size_t)B * K * SR_GEOM_STRIDE * sizeof(float), 256));
+}
+
+// internal launchers shared between translation units
+int sr_launch_geom(const float* K_src, const float* T_src_cur, const float* T_cur_src, float* geom,
+                   int n, hipStream_t stream);
+int sr_launch_pack_nhwc(const float* src_nchw, float* dst_nhwc, int images, int C, int npix,
+                        hipStream_t stream);

@@ -1,0 +1,291 @@
+// sr_dot_volume.hip -- fused plane sweep of the dot-product cost volume for gfx950.
+//
+// Replaces CostVolumeManager.build_cost_volume/forward of the reference
+// (modules/cost_volume.py:237-380): per depth plane ~12 ATen launches and a
+// [B,K,C,h,w] warped-feature tensor written+read per plane.  Here: one launch per batch;
+// a wavefront owns 64 consecutive pixels; the source features live channels-last in HBM
+// ([B*K, h*w, C], one bilinear tap = one contiguous 4*C-byte read, neighbouring lanes hit
+// neighbouring texels); the reference feature vector stays in VGPRs over all planes; the
+// over-views reduction and the running argmax stay in registers; planes are split over the
+// waves of a workgroup (more bytes in flight for the L1/TA-bound gather) and merged in LDS.
+#include "sr_common.h"
+
+// ------------------------------------------------------------------------ prologue ----
+
+// One thread per (b,k).  P = K @ T (rows 0..2), source-camera centre and the DVMVS pose
+// measures (geometry_utils.py:178-191).  Op-by-op, contraction off (see sr_common.h).
+__global__ void sr_geom_kernel(const float* __restrict__ K_src, const float* __restrict__ T_src_cur,
+                               const float* __restrict__ T_cur_src, float* __restrict__ geom, int n) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* Km = K_src + 16 * (size_t)i;
+  const float* T = T_src_cur + 16 * (size_t)i;
+  float* g = geom + SR_GEOM_STRIDE * (size_t)i;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      float s = 0.0f;
+      for (int k = 0; k < 4; ++k) s += Km[r * 4 + k] * T[k * 4 + c];
+      g[r * 4 + c] = s;
+    }
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, dist = 0.f, rm = 0.f, tm = 0.f;
+  if (T_cur_src) {
+    const float* Tc = T_cur_src + 16 * (size_t)i;
+    t0 = Tc[3]; t1 = Tc[7]; t2 = Tc[11];
+    const float tr = (Tc[0] + Tc[5]) + Tc[10];
+    rm = sqrtf(2.0f * (1.0f - fminf(3.0f, tr) / 3.0f));
+    tm = sqrtf((t0 * t0 + t1 * t1) + t2 * t2);
+    dist = sqrtf(tm * tm + rm * rm);
+  }
+  g[12] = t0; g[13] = t1; g[14] = t2; g[15] = dist; g[16] = rm; g[17] = tm; g[18] = 0.f; g[19] = 0.f;
+}
+
+int sr_launch_geom(const float* K_src, const float* T_src_cur, const float* T_cur_src, float* geom,
+                   int n, hipStream_t stream) {
+  if (n == 0) return SR_OK;
+  hipLaunchKernelGGL(sr_geom_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, K_src, T_src_cur, T_cur_src,
+                     geom, n);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// [images, C, npix] -> [images, npix, C] through an LDS tile (coalesced on both sides).
+template <int C>
+__global__ __launch_bounds__(256) void sr_pack_nhwc_kernel(const float* __restrict__ src,
+                                                           float* __restrict__ dst, int npix) {
+  __shared__ float tile[64][C + 1];
+  const int img = blockIdx.y;
+  const int p0 = blockIdx.x * 64;
+  const float* s = src + (size_t)img * C * npix;
+  float* d = dst + (size_t)img * npix * C;
+  for (int e = threadIdx.x; e < 64 * C; e += 256) {
+    const int c = e >> 6, p = e & 63;
+    tile[p][c] = (p0 + p < npix) ? s[(size_t)c * npix + p0 + p] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * C; e += 256) {
+    const int p = e / C, c = e - p * C;
+    if (p0 + p < npix) d[(size_t)(p0 + p) * C + c] = tile[p][c];
+  }
+}
+
+int sr_launch_pack_nhwc(const float* src_nchw, float* dst_nhwc, int images, int C, int npix,
+                        hipStream_t stream) {
+  if (images == 0 || npix == 0) return SR_OK;
+  dim3 grid((npix + 63) / 64, images), block(256);
+  switch (C) {
+    case 4: hipLaunchKernelGGL(sr_pack_nhwc_kernel<4>, grid, block, 0, stream, src_nchw, dst_nhwc, npix); break;
+    case 8: hipLaunchKernelGGL(sr_pack_nhwc_kernel<8>, grid, block, 0, stream, src_nchw, dst_nhwc, npix); break;
+    case 12: hipLaunchKernelGGL(sr_pack_nhwc_kernel<12>, grid, block, 0, stream, src_nchw, dst_nhwc, npix); break;
+    case 16: hipLaunchKernelGGL(sr_pack_nhwc_kernel<16>, grid, block, 0, stream, src_nchw, dst_nhwc, npix); break;
+    case 24: hipLaunchKernelGGL(sr_pack_nhwc_kernel<24>, grid, block, 0, stream, src_nchw, dst_nhwc, npix); break;
+    case 32: hipLaunchKernelGGL(sr_pack_nhwc_kernel<32>, grid, block, 0, stream, src_nchw, dst_nhwc, npix); break;
+    default: return SR_ERR_UNSUPPORTED;
+  }
+  return sr_hip_rc(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------ the sweep ---
+
+struct SrDotParams {
+  const float* cur;       // [B,C,h,w]
+  const float* src_nhwc;  // [B*K, h*w, C]
+  const float* invK;      // [B,16]
+  const float* geom;      // [B*K, SR_GEOM_STRIDE]
+  SrPlanes planes;
+  SrVolumeOut out;
+  int B, K, h, w, D;
+  float inv_w, inv_h;
+};
+
+// dot of one C-channel texel with the reference feature vector (C/4 x 16-byte loads)
+template <int C>
+__device__ __forceinline__ float sr_tap_dot(const float* __restrict__ img, int texel, const float (&cur)[C]) {
+  const float4* t = reinterpret_cast<const float4*>(img + (size_t)texel * C);
+  float acc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < C / 4; ++i) {
+    const float4 v = t[i];
+    acc = fmaf(v.x, cur[4 * i + 0], acc);
+    acc = fmaf(v.y, cur[4 * i + 1], acc);
+    acc = fmaf(v.z, cur[4 * i + 2], acc);
+    acc = fmaf(v.w, cur[4 * i + 3], acc);
+  }
+  return acc;
+}
+
+template <int C>
+__global__ __launch_bounds__(1024) void sr_dot_volume_kernel(SrDotParams p) {
+  extern __shared__ float smem[];  // [S][64] best cost, [S][64] best depth, [S][64] valid flag
+  const int lane = threadIdx.x & 63;
+  const int grp = threadIdx.x >> 6;
+  const int S = blockDim.x >> 6;
+  const int b = blockIdx.y;
+  const int N = p.h * p.w;
+  const int pix = blockIdx.x * 64 + lane;
+  const bool active = pix < N;
+  const int pc = active ? pix : N - 1;
+  const int y = pc / p.w, x = pc - y * p.w;
+
+  const int per = (p.D + S - 1) / S;
+  const int j0 = grp * per;
+  const int j1 = min(p.D, j0 + per);
+
+  float cur[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) cur[c] = p.cur[((size_t)b * C + c) * N + pc];
+
+  float r0, r1, r2;
+  {
+#pragma clang fp contract(off)
+    const float* iK = p.invK + 16 * (size_t)b;
+    const float px = (float)x + 0.5f, py = (float)y + 0.5f;  // geometry_utils.py:34-44
+    r0 = iK[0] * px + iK[1] * py + iK[2];
+    r1 = iK[4] * px + iK[5] * py + iK[6];
+    r2 = iK[8] * px + iK[9] * py + iK[10];
+  }
+
+  const float* geom_b = p.geom + (size_t)b * p.K * SR_GEOM_STRIDE;
+  const float* src_b = p.src_nhwc + (size_t)b * p.K * N * C;
+  const float* planes = p.planes.ptr + b * p.planes.sb + y * p.planes.sy + x * p.planes.sx;
+  float* out = p.out.cv + b * p.out.sb + (int64_t)pc * p.out.sp;
+
+  float best = 0.0f, best_d = 0.0f;
+  bool have = false;
+  for (int j = j0; j < j1; ++j) {
+    const float d = planes[j * p.planes.sd];
+    float X0, X1, X2;
+    {
+#pragma clang fp contract(off)
+      X0 = d * r0; X1 = d * r1; X2 = d * r2;  // geometry_utils.py:56-57
+    }
+    float cost = 0.0f;
+    bool any_depth = false, any_bounds = false;
+#pragma unroll 1
+    for (int k = 0; k < p.K; ++k) {
+      SrSample s;
+      sr_project_sample(geom_b + k * SR_GEOM_STRIDE, X0, X1, X2, p.h, p.w, p.inv_w, p.inv_h, s);
+      const float* img = src_b + (size_t)k * N * C;
+      const float d_nw = sr_tap_dot<C>(img, s.o_nw, cur);
+      const float d_ne = sr_tap_dot<C>(img, s.o_ne, cur);
+      const float d_sw = sr_tap_dot<C>(img, s.o_sw, cur);
+      const float d_se = sr_tap_dot<C>(img, s.o_se, cur);
+      // sum_c (sum_taps w_t * tap_c) * cur_c  ==  sum_taps w_t * (tap . cur)   (cost_volume.py:322-326)
+      const float dot = fmaf(s.w_se, d_se, fmaf(s.w_sw, d_sw, fmaf(s.w_ne, d_ne, s.w_nw * d_nw)));
+      const bool front = s.zp > 0.0f;  // cost_volume.py:231-232
+      cost += front ? dot : 0.0f;      // cost_volume.py:329
+      any_depth |= front;
+      any_bounds |= sr_in_bounds(s, p.h, p.w);
+    }
+    if (active) out[j * p.out.sd] = cost;
+    if (!have || cost > best) { best = cost; best_d = d; have = true; }  // first max wins
+    if (j == p.D - 1 && p.out.mask && active)
+      p.out.mask[(size_t)b * N + pix] = (uint8_t)(any_depth && any_bounds);
+  }
+
+  if (p.out.lowest) {
+    if (S == 1) {
+      if (active) p.out.lowest[(size_t)b * N + pix] = best_d;
+    } else {
+      float* s_best = smem;
+      float* s_d = smem + S * 64;
+      float* s_have = smem + 2 * S * 64;
+      s_best[grp * 64 + lane] = best;
+      s_d[grp * 64 + lane] = best_d;
+      s_have[grp * 64 + lane] = have ? 1.0f : 0.0f;
+      __syncthreads();
+      if (grp == 0 && active) {
+        float bb = best, bd = best_d;  // group 0 always owns plane 0
+        for (int g = 1; g < S; ++g)
+          if (s_have[g * 64 + lane] != 0.0f && s_best[g * 64 + lane] > bb) {
+            bb = s_best[g * 64 + lane];
+            bd = s_d[g * 64 + lane];
+          }
+        p.out.lowest[(size_t)b * N + pix] = bd;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------ C ABI -------
+
+extern "C" int sr_abi_version(void) { return 1; }
+extern "C" const char* sr_target_arch(void) { return "gfx950"; }
+
+extern "C" size_t sr_volume_workspace_bytes(int B, int K, int C, int h, int w) {
+  if (B < 0 || K < 0 || C < 0 || h < 0 || w < 0) return 0;
+  const size_t geom = sr_align_up((size_t)B * K * SR_GEOM_STRIDE * sizeof(float), 256);
+  const size_t nhwc = sr_align_up((size_t)B * K * h * w * C * sizeof(float), 256);
+  return geom + nhwc + 256;
+}
+
+static int sr_pick_plane_split(int B, int N, int D) {
+  // Enough waves to cover 256 CUs several times over; never more groups than planes.
+  const long tiles = (long)B * ((N + 63) / 64);
+  int S = 1;
+  while (S < 16 && tiles * S < 256L * 16 && S * 2 <= D) S *= 2;
+  return S;
+}
+
+// geometry records + channels-last source features -> workspace (shared by both sweeps)
+extern "C" int sr_volume_prepare(const float* src, const float* K_src, const float* T_src_cur,
+                                 const float* T_cur_src, int B, int K, int C, int h, int w, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+  if (B < 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!src || !K_src || !T_src_cur || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if (C % 4 != 0 || C > 32) return SR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sr_volume_workspace_bytes(B, K, C, h, w)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = sr_launch_geom(K_src, T_src_cur, T_cur_src, sr_ws_geom(workspace), B * K, stream);
+  if (rc) return rc;
+  return sr_launch_pack_nhwc(src, sr_ws_src_nhwc(workspace, B, K), B * K, C, h * w, stream);
+}
+
+extern "C" int sr_dot_volume_sweep(const float* cur, const float* invK_cur, const float* planes, int64_t ps_b,
+                                   int64_t ps_d, int64_t ps_y, int64_t ps_x, int B, int K, int C, int h, int w,
+                                   int D, float* out_cv, int64_t cv_sb, int64_t cv_sd, int64_t cv_sp,
+                                   float* out_lowest, uint8_t* out_mask, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
+  if (B < 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!cur || !invK_cur || !planes || !out_cv || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if (C % 4 != 0 || C > 32) return SR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sr_volume_workspace_bytes(B, K, C, h, w)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = h * w;
+
+  SrDotParams p;
+  p.cur = cur; p.src_nhwc = sr_ws_src_nhwc(workspace, B, K); p.invK = invK_cur; p.geom = sr_ws_geom(workspace);
+  p.planes = {planes, ps_b, ps_d, ps_y, ps_x};
+  p.out = {out_cv, cv_sb, cv_sd, cv_sp, out_lowest, out_mask};
+  p.B = B; p.K = K; p.h = h; p.w = w; p.D = D;
+  p.inv_w = (float)(1.0 / (double)w);
+  p.inv_h = (float)(1.0 / (double)h);
+
+  const int S = sr_pick_plane_split(B, N, D);
+  dim3 grid((N + 63) / 64, B), block(64 * S);
+  const size_t lds = (size_t)3 * S * 64 * sizeof(float);
+  switch (C) {
+    case 4: hipLaunchKernelGGL(sr_dot_volume_kernel<4>, grid, block, lds, stream, p); break;
+    case 8: hipLaunchKernelGGL(sr_dot_volume_kernel<8>, grid, block, lds, stream, p); break;
+    case 12: hipLaunchKernelGGL(sr_dot_volume_kernel<12>, grid, block, lds, stream, p); break;
+    case 16: hipLaunchKernelGGL(sr_dot_volume_kernel<16>, grid, block, lds, stream, p); break;
+    case 24: hipLaunchKernelGGL(sr_dot_volume_kernel<24>, grid, block, lds, stream, p); break;
+    case 32: hipLaunchKernelGGL(sr_dot_volume_kernel<32>, grid, block, lds, stream, p); break;
+    default: return SR_ERR_UNSUPPORTED;
+  }
+  return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" int sr_dot_volume_fwd(const float* cur, const float* src, const float* K_src,
+                                 const float* T_src_cur, const float* invK_cur, const float* planes,
+                                 int64_t ps_b, int64_t ps_d, int64_t ps_y, int64_t ps_x, int B, int K, int C,
+                                 int h, int w, int D, float* out_cv, int64_t cv_sb, int64_t cv_sd,
+                                 int64_t cv_sp, float* out_lowest, uint8_t* out_mask, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+  if (!cur || !src) return B == 0 ? SR_OK : SR_ERR_INVALID_ARGUMENT;
+  int rc = sr_volume_prepare(src, K_src, T_src_cur, nullptr, B, K, C, h, w, workspace, workspace_bytes, stream_);
+  if (rc) return rc;
+  return sr_dot_volume_sweep(cur, invK_cur, planes, ps_b, ps_d, ps_y, ps_x, B, K, C, h, w, D, out_cv, cv_sb,
+                             cv_sd, cv_sp, out_lowest, out_mask, workspace, workspace_bytes, stream_);
+}

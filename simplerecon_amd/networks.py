@@ -1,0 +1,140 @@
+"""2-D networks of the hot path -- API/state-dict compatible with reference modules/networks.py:
+`MLP` (:129-147), `CVEncoder` (:99-127), `DepthDecoderPP` (:20-96).
+
+Activations flow between our layers as channels_last (NHWC-in-memory) torch tensors -- logically
+still b,c,h,w, so callers see the reference's shapes -- and every BasicBlock writes straight into
+its slice of the next concat buffer (no torch.cat copies)."""
+import numpy as np
+import torch
+from torch import nn
+
+from .layers import BasicBlock
+
+
+def double_basic_block(num_ch_in, num_ch_out, num_repeats=2):
+    """Sequential(0: BasicBlock, conv_0: BasicBlock, ...) -- same child names as reference networks.py:13-17."""
+    layers = nn.Sequential(BasicBlock(num_ch_in, num_ch_out))
+    for i in range(num_repeats - 1):
+        layers.add_module(f"conv_{i}", BasicBlock(num_ch_out, num_ch_out))
+    return layers
+
+
+class MLP(nn.Module):
+    """Linear / LeakyReLU(0.01) stack (reference networks.py:129-147).  Inside the feature volume the
+    three layers are fused into the HIP sweep kernel (cost_volume.FeatureVolumeManager reads
+    `net.{0,2,4}.{weight,bias}`); calling the module directly applies the layers as written."""
+
+    def __init__(self, channel_list, disable_final_activation=False):
+        super().__init__()
+        layer_list = []
+        for i in range(len(channel_list) - 1):
+            layer_list.append(nn.Linear(channel_list[i], channel_list[i + 1]))
+            layer_list.append(nn.LeakyReLU(inplace=True))
+        if disable_final_activation:
+            layer_list = layer_list[:-1]
+        self.net = nn.Sequential(*layer_list)
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class CVEncoder(nn.Module):
+    """Cost-volume + image-prior multi-scale encoder (reference networks.py:99-127)."""
+
+    def __init__(self, num_ch_cv, num_ch_enc, num_ch_outs):
+        super().__init__()
+        self.convs = nn.ModuleDict()
+        self.num_ch_enc = []
+        self.num_blocks = len(num_ch_outs)
+        self._img_ch = list(num_ch_enc)
+        for i in range(self.num_blocks):
+            num_ch_in = num_ch_cv if i == 0 else num_ch_outs[i - 1]
+            num_ch_out = num_ch_outs[i]
+            self.convs[f"ds_conv_{i}"] = BasicBlock(num_ch_in, num_ch_out, stride=1 if i == 0 else 2)
+            self.convs[f"conv_{i}"] = nn.Sequential(
+                BasicBlock(num_ch_enc[i] + num_ch_out, num_ch_out, stride=1),
+                BasicBlock(num_ch_out, num_ch_out, stride=1),
+            )
+            self.num_ch_enc.append(num_ch_out)
+
+    def forward(self, x, img_feats):
+        from . import ops
+        outputs = []
+        for i in range(self.num_blocks):
+            ds = self.convs[f"ds_conv_{i}"]
+            c_out = ds.conv2.out_channels
+            feat = img_feats[i]
+            ho, wo = ops.conv_out_hw(x.shape[2], x.shape[3], ds.stride)
+            # concat buffer [x | img_feats[i]] (reference networks.py:124): ds_conv writes its slice in place
+            buf = ops.empty_nhwc(x.shape[0], c_out + feat.shape[1], ho, wo, x.device)
+            ds(x, out=buf[:, :c_out])
+            ops.copy_into(buf[:, c_out:], feat)
+            x = self.convs[f"conv_{i}"][1](self.convs[f"conv_{i}"][0](buf))
+            outputs.append(x)
+        return outputs
+
+
+class DepthDecoderPP(nn.Module):
+    """UNet++ depth decoder (reference networks.py:20-96).  Output heads that the reference evaluates
+    and then overwrites (`output_i` is recomputed at every node j, the last one wins, networks.py:92)
+    are evaluated once, at the node whose value survives."""
+
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+        super().__init__()
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.upsample_mode = "nearest"
+        self.scales = scales
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([64, 64, 128, 256])
+        self.convs = nn.ModuleDict()
+        for j in range(1, 5):
+            max_i = 4 - j
+            for i in range(max_i, -1, -1):
+                num_ch_out = int(self.num_ch_dec[i])
+                total = 0
+                num_ch_in = int(self.num_ch_enc[i + 1] if j == 1 else self.num_ch_dec[i + 1])
+                self.convs[f"diag_conv_{i + 1}{j - 1}"] = BasicBlock(num_ch_in, num_ch_out)
+                total += num_ch_out
+                num_ch_in = int(self.num_ch_enc[i] if j == 1 else self.num_ch_dec[i])
+                self.convs[f"right_conv_{i}{j - 1}"] = BasicBlock(num_ch_in, num_ch_out)
+                total += num_ch_out
+                if i + j != 4:
+                    num_ch_in = int(self.num_ch_dec[i + 1])
+                    self.convs[f"up_conv_{i + 1}{j}"] = BasicBlock(num_ch_in, num_ch_out)
+                    total += num_ch_out
+                self.convs[f"in_conv_{i}{j}"] = double_basic_block(total, num_ch_out)
+                self.convs[f"output_{i}"] = nn.Sequential(
+                    BasicBlock(num_ch_out, num_ch_out) if i != 0 else nn.Identity(),
+                    nn.Conv2d(num_ch_out, self.num_output_channels, 1),
+                )
+
+    def forward(self, input_features):
+        from . import ops
+        prev_outputs = list(input_features)
+        outputs = []
+        depth_outputs = {}
+        for j in range(1, 5):
+            max_i = 4 - j
+            for i in range(max_i, -1, -1):
+                right = self.convs[f"right_conv_{i}{j - 1}"]
+                diag = self.convs[f"diag_conv_{i + 1}{j - 1}"]
+                c = right.conv2.out_channels
+                x_i = prev_outputs[i]
+                n_parts = 3 if i + j != 4 else 2
+                buf = ops.empty_nhwc(x_i.shape[0], c * n_parts, x_i.shape[2], x_i.shape[3], x_i.device)
+                right(x_i, out=buf[:, :c])
+                ops.upsample2x(diag(prev_outputs[i + 1]), out=buf[:, c:2 * c])
+                if i + j != 4:
+                    up = self.convs[f"up_conv_{i + 1}{j}"]
+                    ops.upsample2x(up(outputs[-1]), out=buf[:, 2 * c:3 * c])
+                in_conv = self.convs[f"in_conv_{i}{j}"]
+                output = in_conv[1](in_conv[0](buf))
+                outputs.append(output)
+                if i + j == 4:  # last node of scale i: the head value the reference keeps
+                    head = self.convs[f"output_{i}"]
+                    hx = output if isinstance(head[0], nn.Identity) else head[0](output)
+                    depth_outputs[f"log_depth_pred_s{i}_b1hw"] = ops.conv2d(hx, head[1])
+            prev_outputs = outputs[::-1]
+        # same key order as the reference's dict (s3, s2, s1, s0 first inserted at j = 1)
+        return {k: depth_outputs[k] for k in sorted(depth_outputs, reverse=True)}

@@ -1,0 +1,97 @@
+"""Generates tests/golden/*.npz by running the UPSTREAM reference modules on CPU.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference has no tests or golden vectors of its own, so the
+outputs of its unmodified modules -- imported through oracle/refshim.py -- on
+seeded synthetic inputs ARE the golden vectors.  Inputs and weights are not
+stored: they are regenerated bit-identically from (seed, shape) with
+simplerecon_amd.synthetic (numpy RNG), see tests/golden_cases.py.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import refshim  # noqa: E402
+import golden_cases as gc  # noqa: E402
+from simplerecon_amd import synthetic  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    torch.set_num_threads(8)
+    cv, nets, layers, geo, gen = refshim.import_reference()
+
+    # ---- cost volumes ------------------------------------------------------
+    for name, case in gc.VOLUME_CASES.items():
+        inp = gc.volume_inputs(case)
+        h, w, D, K, C = case["h"], case["w"], case["D"], case["K"], case["C"]
+        if case["model"] == "dot":
+            mgr = cv.CostVolumeManager(h, w, num_depth_bins=D)
+        else:
+            mgr = cv.FeatureVolumeManager(h, w, num_depth_bins=D, mlp_channels=[202, 128, 128, 1],
+                                          matching_dim_size=C, num_source_views=K)
+            synthetic.seeded_fill_(mgr.mlp, seed=case["seed"])
+        captured = {}
+        if case["model"] == "hero":
+            # capture the MLP input at the LAST plane (channel-order pin, cost_volume.py:709-723)
+            def hook(mod, args):
+                captured["x"] = args[0].detach().clone()
+            hh = mgr.mlp.register_forward_pre_hook(hook)
+        with torch.inference_mode():
+            vol, lowest, planes, mask = mgr(return_mask=True, **inp)
+        out = dict(cost_volume=vol.numpy(), lowest_cost=lowest.numpy(),
+                   planes_bd=planes[:, :, 0, 0].contiguous().numpy() if "depth_planes_bdhw" not in inp else
+                   np.zeros((0,), np.float32))
+        if mask is not None:
+            out["overall_mask"] = mask.numpy()
+        if case["model"] == "hero":
+            hh.remove()
+            out["mlp_input_last_plane"] = captured["x"].numpy()  # [B,h,w,Cin]
+            fast = mgr.to_fast()
+            with torch.inference_mode():
+                vol_f, lowest_f, _, mask_f = fast(return_mask=True, **inp)
+            out["cost_volume_fast"] = vol_f.numpy()
+        np.savez_compressed(os.path.join(OUT, f"volume_{name}.npz"), **out)
+        print(name, vol.shape, float(vol.abs().max()))
+
+    # ---- conv stack --------------------------------------------------------
+    for name, case in gc.BLOCK_CASES.items():
+        blk = layers.BasicBlock(case["cin"], case["cout"], stride=case["stride"])
+        synthetic.seeded_fill_(blk, seed=case["seed"])
+        x = gc.block_input(case)
+        with torch.inference_mode():
+            y = blk(x)
+        np.savez_compressed(os.path.join(OUT, f"block_{name}.npz"), out=y.numpy())
+        print(name, y.shape)
+
+    x = gc.upsample_input()
+    np.savez_compressed(os.path.join(OUT, "upsample.npz"), out=gen.upsample(x).numpy())
+
+    for name, case in gc.NET_CASES.items():
+        enc = nets.CVEncoder(num_ch_cv=case["D"], num_ch_enc=case["enc_ch"][1:], num_ch_outs=case["cv_outs"])
+        dec = nets.DepthDecoderPP(case["enc_ch"][:1] + case["cv_outs"])
+        synthetic.seeded_fill_(enc, seed=case["seed"])
+        synthetic.seeded_fill_(dec, seed=case["seed"] + 1)
+        vol, feats = gc.net_inputs(case)
+        with torch.inference_mode():
+            cvf = enc(vol, feats[1:])
+            outs = dec(feats[:1] + cvf)
+        save = {f"cv_feat_{i}": t.numpy() for i, t in enumerate(cvf)}
+        save.update({k: v.numpy() for k, v in outs.items()})
+        np.savez_compressed(os.path.join(OUT, f"net_{name}.npz"), **save)
+        print(name, {k: tuple(v.shape) for k, v in outs.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""Seeded test-case definitions shared by tests/golden/make_golden.py (which runs the
+upstream reference on them) and by the parity tests (which run the oracle and the
+HIP path on the same bytes).  Inputs are regenerated from (seed, shape); only the
+reference's OUTPUTS are stored under tests/golden/."""
+import os
+
+import numpy as np
+import torch
+
+from simplerecon_amd import synthetic
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+VOLUME_CASES = {
+    # BASELINE.json configs[0]: dot model, B=1, 2 source views, 32 planes, 320x256 -> 64x80
+    "dot_cfg1": dict(model="dot", B=1, K=2, C=16, D=32, h=64, w=80, seed=2),
+    "dot_small": dict(model="dot", B=2, K=3, C=16, D=8, h=24, w=32, seed=1),
+    "dot_edge": dict(model="dot", B=1, K=4, C=16, D=6, h=20, w=28, seed=5, edge=True),
+    "dot_planes": dict(model="dot", B=2, K=2, C=16, D=5, h=16, w=24, seed=6, pixel_planes=True),
+    "hero_small": dict(model="hero", B=2, K=3, C=16, D=8, h=24, w=32, seed=3),
+    # K=7, C=16 -> the 202-channel MLP of hero_model.yaml
+    "hero_k7": dict(model="hero", B=1, K=7, C=16, D=4, h=24, w=32, seed=4),
+    "hero_edge": dict(model="hero", B=1, K=4, C=16, D=6, h=20, w=28, seed=7, edge=True),
+    "hero_planes": dict(model="hero", B=1, K=2, C=16, D=5, h=16, w=24, seed=8, pixel_planes=True),
+}
+
+
+def _edge_poses(B, K):
+    """Poses that hit the reference's special cases: identity (R_measure = 0, samples on
+    texel centres), a camera looking backwards (z' < 0 -> mask 0), a large rotation
+    (mostly out-of-bounds samples), a pure forward translation."""
+    def rot_y(t):
+        c, s = np.cos(t), np.sin(t)
+        R = np.eye(4)
+        R[0, 0], R[0, 2], R[2, 0], R[2, 2] = c, s, -s, c
+        return R
+    Ts = [np.eye(4), rot_y(np.pi), rot_y(0.6), np.eye(4)]
+    Ts[1][:3, 3] = [0.05, 0.0, 0.1]
+    Ts[2][:3, 3] = [0.3, 0.1, 0.0]
+    Ts[3][:3, 3] = [0.0, 0.0, 0.2]
+    src_poses = np.stack([np.stack(Ts[:K])] * B).astype(np.float64)
+    return src_poses.astype(np.float32), np.linalg.inv(src_poses).astype(np.float32)
+
+
+def volume_inputs(case, device="cpu"):
+    inp = synthetic.cost_volume_inputs(case["B"], case["K"], case["C"], case["h"], case["w"],
+                                       seed=case["seed"], device="cpu")
+    if case.get("edge"):
+        p, e = _edge_poses(case["B"], case["K"])
+        inp["src_poses"], inp["src_extrinsics"] = torch.from_numpy(p), torch.from_numpy(e)
+    if case.get("pixel_planes"):
+        rng = np.random.default_rng(900 + case["seed"])
+        B, D, h, w = case["B"], case["D"], case["h"], case["w"]
+        base = np.exp(np.log(0.25) + np.log(5.0 / 0.25) * np.linspace(0, 1, D)).reshape(1, D, 1, 1)
+        planes = base * (1.0 + 0.1 * rng.uniform(-1, 1, size=(B, 1, h, w)))
+        inp["depth_planes_bdhw"] = torch.from_numpy(planes.astype(np.float32))
+    return {k: v.to(device) for k, v in inp.items()}
+
+
+def load_golden(prefix, name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"{prefix}_{name}.npz")))
+
+
+# ------------------------------------------------------------------ conv stack
+
+BLOCK_CASES = {
+    "same": dict(cin=16, cout=16, stride=1, B=2, h=12, w=20, seed=11),          # identity skip
+    "widen": dict(cin=24, cout=16, stride=1, B=1, h=10, w=14, seed=12),         # conv1x1 skip (layers.py:62)
+    "down": dict(cin=16, cout=32, stride=2, B=2, h=12, w=20, seed=13),          # conv3x3-s2 skip
+    "down_odd": dict(cin=8, cout=8, stride=2, B=1, h=15, w=21, seed=14),        # odd sizes, stride 2
+    "wide_in": dict(cin=192, cout=64, stride=1, B=1, h=8, w=12, seed=15),       # decoder in_conv shape
+}
+
+
+def block_input(case, device="cpu"):
+    rng = np.random.default_rng(case["seed"])
+    x = rng.standard_normal((case["B"], case["cin"], case["h"], case["w"]), dtype=np.float32)
+    return torch.from_numpy(x).to(device)
+
+
+def upsample_input(device="cpu"):
+    rng = np.random.default_rng(21)
+    return torch.from_numpy(rng.standard_normal((2, 5, 7, 9), dtype=np.float32)).to(device)
+
+
+NET_CASES = {
+    # real channel widths of hero_model.yaml (depth_model.py:123-135), tiny spatial size:
+    # matching res 16x24 -> pyramid 32x48, 16x24, 8x12, 4x6, 2x3
+    "full_width": dict(D=64, enc_ch=[24, 48, 64, 160, 256], cv_outs=[64, 128, 256, 384], B=1, h=16, w=24, seed=31),
+    # batch 2, non-square, fewer planes
+    "narrow": dict(D=8, enc_ch=[6, 10, 12, 20, 28], cv_outs=[64, 128, 256, 384], B=2, h=8, w=16, seed=33),
+}
+
+
+def net_inputs(case, device="cpu"):
+    rng = np.random.default_rng(case["seed"])
+    vol = torch.from_numpy(rng.standard_normal((case["B"], case["D"], case["h"], case["w"]), dtype=np.float32))
+    feats = synthetic.image_prior_pyramid(case["B"], case["h"], case["w"], chans=case["enc_ch"], seed=case["seed"])
+    return vol.to(device), [f.to(device) for f in feats]

@@ -1,0 +1,59 @@
+"""Parity metrics.  The bar (BASELINE.json north_star): 1e-4 relative, fp32.
+
+`rel_err` is max|a-b| / max|b| (error relative to the tensor's dynamic range), the
+metric the reference's own "<10^-4" repeatability statement (reference test.py:16-20)
+is about.  Discrete outputs (masks, argmax planes) are compared exactly, with a
+tiny allowance for ties that fp32 reassociation can flip (SURVEY.md §7 hard parts)."""
+import numpy as np
+
+TOL = 1e-4
+
+
+def to_np(x):
+    try:
+        import torch
+        if isinstance(x, torch.Tensor):
+            return x.detach().cpu().numpy()
+    except ImportError:
+        pass
+    return np.asarray(x)
+
+
+def rel_err(a, b):
+    a, b = to_np(a).astype(np.float64), to_np(b).astype(np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    denom = max(np.abs(b).max(), 1e-30)
+    return float(np.abs(a - b).max() / denom)
+
+
+def assert_close(a, b, tol=TOL, what=""):
+    e = rel_err(a, b)
+    assert np.isfinite(to_np(a)).all(), f"{what}: non-finite values"
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+    return e
+
+
+def mismatch_fraction(a, b):
+    a, b = to_np(a), to_np(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a != b).mean())
+
+
+def assert_lowest_cost(lowest, cost_volume, planes_bd, ref_lowest, what=""):
+    """lowest_cost = planes[argmax_d cost] (reference cost_volume.py:374-378).  Must be
+    self-consistent with OUR volume exactly; vs the reference, argmax may flip only where
+    the two top costs tie to within the parity tolerance."""
+    lowest, cv, ref_lowest = to_np(lowest), to_np(cost_volume), to_np(ref_lowest)
+    planes = to_np(planes_bd)
+    idx = cv.argmax(1)
+    if planes.ndim == 2:
+        own = np.take_along_axis(planes[:, :, None, None] * np.ones_like(cv), idx[:, None], 1)[:, 0]
+    else:
+        own = np.take_along_axis(planes, idx[:, None], 1)[:, 0]
+    assert np.array_equal(lowest, own.astype(lowest.dtype)), f"{what}: lowest_cost != planes[argmax(own volume)]"
+    bad = lowest.astype(np.float32) != ref_lowest.astype(np.float32)
+    if bad.any():
+        srt = np.sort(cv, axis=1)
+        gap = (srt[:, -1] - srt[:, -2]) / max(np.abs(cv).max(), 1e-30)
+        assert (gap[bad] <= 2 * TOL).all(), f"{what}: argmax differs from reference beyond a tie ({bad.sum()} px)"
+    return float(bad.mean())
