@@ -96,6 +96,45 @@ int sr_dot_volume_fwd(const float* cur, const float* src, const float* K_src,
                       int64_t cv_sp, float* out_lowest, uint8_t* out_mask, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------ metadata-MLP volume --
+ *
+ * Fused plane sweep of the hero model: replaces FeatureVolumeManager.build_cost_volume + forward
+ * and FastFeatureVolumeManager (cost_volume.py:451-736, 967-1164, 345-380): per (b, d, y, x) the
+ * C(1+K)+10K+4-channel vector of cost_volume.py:709-723 (warped source features, reference
+ * features, masks, source depths, plane depth, dot products, ray angles, rays, pose measures) is
+ * built in registers and pushed through MLP = Linear, LeakyReLU, Linear, LeakyReLU, Linear
+ * (modules/networks.py:129-147, built at cost_volume.py:438) on fp32 MFMA.
+ *
+ *  T_cur_src  [B,K,16]  cur_cam_T_src_cam ("src_poses")
+ *  W1 [hidden, Cin], b1 [hidden], W2 [hidden, hidden], b2 [hidden], W3 [1, hidden], b3 [1]
+ *             = mlp.net.{0,2,4}.{weight,bias};  hidden must be 128, C must be 16.
+ *  leaky_slope: 0.01 (nn.LeakyReLU default, networks.py:139); must lie in (0,1).
+ *  out_mask as for the dot model (this model does return it, cost_volume.py:625-637).
+ */
+size_t sr_mlp_volume_workspace_bytes(int B, int K, int C, int h, int w, int hidden);
+
+/* Packs the MLP parameters into the k-step order of the sweep kernel (into `workspace`). */
+int sr_mlp_pack_weights(const float* W1, const float* b1, const float* W2, const float* b2,
+                        const float* W3, const float* b3, int hidden, int B, int K, int C, int h, int w,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* The sweep kernel alone, on a workspace filled by sr_volume_prepare (with T_cur_src) and
+ * sr_mlp_pack_weights for the same sizes. */
+int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, const float* planes, int64_t ps_b,
+                        int64_t ps_d, int64_t ps_y, int64_t ps_x, float leaky_slope, int B, int K,
+                        int C, int h, int w, int D, float* out_cv, int64_t cv_sb, int64_t cv_sd,
+                        int64_t cv_sp, float* out_lowest, uint8_t* out_mask, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* = sr_volume_prepare + sr_mlp_pack_weights + sr_mlp_volume_sweep. */
+int sr_mlp_volume_fwd(const float* cur, const float* src, const float* K_src, const float* T_src_cur,
+                      const float* T_cur_src, const float* invK_cur, const float* planes, int64_t ps_b,
+                      int64_t ps_d, int64_t ps_y, int64_t ps_x, const float* W1, const float* b1,
+                      const float* W2, const float* b2, const float* W3, const float* b3, int hidden,
+                      float leaky_slope, int B, int K, int C, int h, int w, int D, float* out_cv,
+                      int64_t cv_sb, int64_t cv_sd, int64_t cv_sp, float* out_lowest, uint8_t* out_mask,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,6 +227,7 @@ class FeatureVolumeManager(CostVolumeManager):
                                            num_depth_bins=self.num_depth_bins, mlp_channels=self.mlp_channels,
                                            matching_dim_size=self.matching_dim_size,
                                            num_source_views=self.num_source_views)
+        manager.to(self.linear_ramp_1d11.device)
         manager.mlp = self.mlp
         manager.volume_memory_format = self.volume_memory_format
         return manager

@@ -1,0 +1,440 @@
+// sr_mlp_volume.hip -- fused plane sweep of the metadata-MLP feature volume for gfx950.
+//
+// Replaces FeatureVolumeManager.build_cost_volume / FastFeatureVolumeManager of the reference
+// (modules/cost_volume.py:451-736, 967-1164): per depth plane ~40 ATen launches, a 202-channel
+// concat tensor and two [B*N,128] hidden tensors (or, in the "fast" variant, 7.9 GB of them at
+// batch 8).  Here a wavefront owns 64 points (64 pixels of one depth plane):
+//   * VALU part: homography, 4-tap bilinear gather of the channels-last source features,
+//     dot / mask / depth / rays / ray angle -- each lane builds the MLP input vector of ITS point
+//     in registers, never in memory;
+//   * MFMA part (fp32 in, fp32 accumulate, v_mfma_f32_32x32x2_f32): H1^T = W1 . X^T and
+//     H2^T = W2 . H1^T as two 32-point column groups.  One v_permlane32_swap per k-step turns two
+//     per-lane feature registers into the B operands of both groups; the layer-1 accumulators ARE
+//     the layer-2 B operands (the k order of W2 is permuted to the MFMA C layout on the host side),
+//     so activations never touch LDS or HBM.  Layer 3 (128 -> 1) is a per-lane dot + one swap.
+//   * W1 (packed in k-step order) lives in LDS for the whole persistent block; W2 streams from
+//     L2 with a register prefetch (both do not fit the 160 KB LDS in fp32).
+#include "sr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SR_HID 128          // hidden width of the matching MLP (reference cost_volume.py:402)
+#define SR_VIEW_SLOTS 26    // per-view k-slots: 16 warped + mask, z', dot, angle, ray(3), pose(3)
+#define SR_TAIL_SLOTS 22    // d, cur(16), cur_ray(3), one (bias), zero pad
+
+static inline int sr_mlp_steps1(int K) { return (SR_VIEW_SLOTS * K + SR_TAIL_SLOTS) / 2; }
+#define SR_MLP_STEPS2 65    // 64 hidden pairs + one bias step
+
+// packed parameter block (floats): [W1p: steps1*256][W2p: 65*256][w3tab: 128][b3: 1][pad]
+static inline size_t sr_mlp_packed_floats(int K) { return (size_t)(sr_mlp_steps1(K) + SR_MLP_STEPS2) * 256 + 128 + 4; }
+
+// ------------------------------------------------------------------ weight packing ----
+// W?p[t][lane][mt] = W[row = 32*mt + (lane&31)][column of k-slot (t, half = lane>>5)]
+__global__ void sr_mlp_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+                                   const float* __restrict__ W2, const float* __restrict__ b2,
+                                   const float* __restrict__ W3, const float* __restrict__ b3,
+                                   float* __restrict__ packed, int K, int C) {
+  const int steps1 = (SR_VIEW_SLOTS * K + SR_TAIL_SLOTS) / 2;
+  const int Cin = C * (K + 1) + 10 * K + 4;
+  // reference channel offsets (cost_volume.py:709-723)
+  const int o_cur = K * C, o_mask = o_cur + C, o_z = o_mask + K, o_d = o_z + K, o_dot = o_d + 1;
+  const int o_ang = o_dot + K, o_cray = o_ang + K, o_sray = o_cray + 3, o_pd = o_sray + 3 * K;
+  const int o_rm = o_pd + K, o_tm = o_rm + K;
+  const int total = (steps1 + SR_MLP_STEPS2) * 256 + 128 + 1;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    float v = 0.0f;
+    if (e < steps1 * 256) {
+      const int t = e >> 8, lane = (e >> 2) & 63, mt = e & 3;
+      const int row = 32 * mt + (lane & 31);
+      const int slot = 2 * t + (lane >> 5);
+      int col = -1;  // -1: zero, -2: bias
+      if (slot < SR_VIEW_SLOTS * K) {
+        const int k = slot / SR_VIEW_SLOTS, s = slot - k * SR_VIEW_SLOTS;
+        if (s < 16) col = k * C + s;
+        else if (s == 16) col = o_mask + k;
+        else if (s == 17) col = o_z + k;
+        else if (s == 18) col = o_dot + k;
+        else if (s == 19) col = o_ang + k;
+        else if (s < 23) col = o_sray + 3 * k + (s - 20);
+        else if (s == 23) col = o_pd + k;
+        else if (s == 24) col = o_rm + k;
+        else col = o_tm + k;
+      } else {
+        const int s = slot - SR_VIEW_SLOTS * K;
+        if (s == 0) col = o_d;
+        else if (s <= 16) col = o_cur + (s - 1);
+        else if (s <= 19) col = o_cray + (s - 17);
+        else if (s == 20) col = -2;
+      }
+      v = (col >= 0) ? W1[(size_t)row * Cin + col] : (col == -2 ? b1[row] : 0.0f);
+    } else if (e < (steps1 + SR_MLP_STEPS2) * 256) {
+      const int e2 = e - steps1 * 256;
+      const int t = e2 >> 8, lane = (e2 >> 2) & 63, mt = e2 & 3;
+      const int row = 32 * mt + (lane & 31);
+      if (t < 64) {
+        // k-step t = (m, r): hidden feature held by this half in accumulator register r of tile m
+        const int m = t >> 4, r = t & 15;
+        const int f = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        v = W2[(size_t)row * SR_HID + f];
+      } else {
+        v = (lane < 32) ? b2[row] : 0.0f;  // bias step: B operand is 1 in half 0
+      }
+    } else if (e < (steps1 + SR_MLP_STEPS2) * 256 + 128) {
+      // w3tab[half][mt][r] = W3[feature of accumulator register r of tile mt in that half]
+      const int i = e - (steps1 + SR_MLP_STEPS2) * 256;
+      const int half = i >> 6, mt = (i >> 4) & 3, r = i & 15;
+      v = W3[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half];
+    } else {
+      v = b3[0];
+    }
+    packed[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------ the sweep ---------
+
+struct SrMlpParams {
+  const float* cur;       // [B,16,h,w]
+  const float* src_nhwc;  // [B*K, h*w, 16]
+  const float* invK;      // [B,16]
+  const float* geom;      // [B*K, SR_GEOM_STRIDE]
+  const float* packed;    // sr_mlp_pack_kernel output
+  SrPlanes planes;
+  SrVolumeOut out;
+  int B, K, h, w, D;
+  int tiles;              // ceil(h*w / 64)
+  float inv_w, inv_h, slope;
+};
+
+__device__ __forceinline__ void sr_swap_halves(float fa, float fb, float& bP, float& bQ) {
+  // vdst lanes 32-63 <-> src lanes 0-31: bP = [fa(0..31) | fb(0..31)], bQ = [fa(32..63) | fb(32..63)]
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(fa), __float_as_uint(fb), false, false);
+  bP = __uint_as_float(r[0]);
+  bQ = __uint_as_float(r[1]);
+}
+
+#define SR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void sr_l1_step(f32x16 (&acc)[2][4], const float4 wA, float fa, float fb) {
+  float bP, bQ;
+  sr_swap_halves(fa, fb, bP, bQ);
+  acc[0][0] = SR_MFMA(wA.x, bP, acc[0][0]);
+  acc[1][0] = SR_MFMA(wA.x, bQ, acc[1][0]);
+  acc[0][1] = SR_MFMA(wA.y, bP, acc[0][1]);
+  acc[1][1] = SR_MFMA(wA.y, bQ, acc[1][1]);
+  acc[0][2] = SR_MFMA(wA.z, bP, acc[0][2]);
+  acc[1][2] = SR_MFMA(wA.z, bQ, acc[1][2]);
+  acc[0][3] = SR_MFMA(wA.w, bP, acc[0][3]);
+  acc[1][3] = SR_MFMA(wA.w, bQ, acc[1][3]);
+}
+
+template <bool W1_LDS>
+__global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int C = 16;
+  const int lane = threadIdx.x & 63;
+  const int steps1 = (SR_VIEW_SLOTS * p.K + SR_TAIL_SLOTS) / 2;
+  const float4* gW1 = reinterpret_cast<const float4*>(p.packed);
+  const float4* gW2 = gW1 + (size_t)steps1 * 64;
+  const float* gW3 = p.packed + (size_t)(steps1 + SR_MLP_STEPS2) * 256;
+
+  if (W1_LDS) {
+    float4* l4 = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < steps1 * 64; i += blockDim.x) l4[i] = gW1[i];
+    __syncthreads();
+  }
+  const float4* W1p = W1_LDS ? reinterpret_cast<const float4*>(lds) : gW1;
+
+  const int N = p.h * p.w;
+  const long nitems = (long)p.B * p.tiles * p.D;
+  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const int half = lane >> 5;
+
+  for (long item = wave0; item < nitems; item += nwaves) {
+    const int j = (int)(item % p.D);
+    const long tb = item / p.D;
+    const int tile = (int)(tb % p.tiles);
+    const int b = (int)(tb / p.tiles);
+    const int pix = tile * 64 + lane;
+    const bool active = pix < N;
+    const int pc = active ? pix : N - 1;
+    const int y = pc / p.w, x = pc - y * p.w;
+
+    float cur[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) cur[c] = p.cur[((size_t)b * C + c) * N + pc];
+
+    float X0, X1, X2;
+    const float d = p.planes.ptr[b * p.planes.sb + j * p.planes.sd + y * p.planes.sy + x * p.planes.sx];
+    {
+#pragma clang fp contract(off)
+      const float* iK = p.invK + 16 * (size_t)b;
+      const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+      const float r0 = iK[0] * px + iK[1] * py + iK[2];
+      const float r1 = iK[4] * px + iK[5] * py + iK[6];
+      const float r2 = iK[8] * px + iK[9] * py + iK[10];
+      X0 = d * r0; X1 = d * r1; X2 = d * r2;
+    }
+    // current-frame ray: F.normalize(X) (cost_volume.py:641-651), eps 1e-12
+    float cr0, cr1, cr2, n1;
+    {
+#pragma clang fp contract(off)
+      const float cn = sqrtf((X0 * X0 + X1 * X1) + X2 * X2);
+      const float cden = fmaxf(cn, 1e-12f);
+      cr0 = X0 / cden; cr1 = X1 / cden; cr2 = X2 / cden;
+      n1 = fmaxf(sqrtf((cr0 * cr0 + cr1 * cr1) + cr2 * cr2), 1e-5f);
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][m][r] = 0.0f;
+
+    const float* geom_b = p.geom + (size_t)b * p.K * SR_GEOM_STRIDE;
+    const float* src_b = p.src_nhwc + (size_t)b * p.K * N * C;
+    bool any_depth = false, any_bounds = false;
+
+#pragma unroll 1
+    for (int k = 0; k < p.K; ++k) {
+      const float* g = geom_b + k * SR_GEOM_STRIDE;
+      SrSample s;
+      sr_project_sample(g, X0, X1, X2, p.h, p.w, p.inv_w, p.inv_h, s);
+      const float* img = src_b + (size_t)k * N * C;
+      const float4* t_nw = reinterpret_cast<const float4*>(img + (size_t)s.o_nw * C);
+      const float4* t_ne = reinterpret_cast<const float4*>(img + (size_t)s.o_ne * C);
+      const float4* t_sw = reinterpret_cast<const float4*>(img + (size_t)s.o_sw * C);
+      const float4* t_se = reinterpret_cast<const float4*>(img + (size_t)s.o_se * C);
+      float f[SR_VIEW_SLOTS];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 a = t_nw[i], bq = t_ne[i], c4 = t_sw[i], d4 = t_se[i];
+        f[4 * i + 0] = fmaf(s.w_se, d4.x, fmaf(s.w_sw, c4.x, fmaf(s.w_ne, bq.x, s.w_nw * a.x)));
+        f[4 * i + 1] = fmaf(s.w_se, d4.y, fmaf(s.w_sw, c4.y, fmaf(s.w_ne, bq.y, s.w_nw * a.y)));
+        f[4 * i + 2] = fmaf(s.w_se, d4.z, fmaf(s.w_sw, c4.z, fmaf(s.w_ne, bq.z, s.w_nw * a.z)));
+        f[4 * i + 3] = fmaf(s.w_se, d4.w, fmaf(s.w_sw, c4.w, fmaf(s.w_ne, bq.w, s.w_nw * a.w)));
+      }
+      float dot = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) dot = fmaf(f[c], cur[c], dot);
+      const bool front = s.zp > 0.0f;
+      any_depth |= front;
+      any_bounds |= sr_in_bounds(s, p.h, p.w);
+      f[16] = front ? 1.0f : 0.0f;  // mask        (cost_volume.py:611-612)
+      f[17] = s.zp;                 // z'_k        (cost_volume.py:603-609)
+      f[18] = front ? dot : 0.0f;   // dot * mask  (cost_volume.py:691-695)
+      {
+#pragma clang fp contract(off)
+        // source ray: normalize(X - t_k) (cost_volume.py:654-669, geometry_utils.py:169-173)
+        const float v0 = X0 - g[12], v1 = X1 - g[13], v2 = X2 - g[14];
+        const float sn = sqrtf((v0 * v0 + v1 * v1) + v2 * v2);
+        const float sden = fmaxf(sn, 1e-12f);
+        const float s0 = v0 / sden, s1 = v1 / sden, s2 = v2 / sden;
+        // F.cosine_similarity(cur_ray, src_ray, eps=1e-5) (cost_volume.py:683-688)
+        const float n2 = fmaxf(sqrtf((s0 * s0 + s1 * s1) + s2 * s2), 1e-5f);
+        f[19] = ((cr0 / n1) * (s0 / n2) + (cr1 / n1) * (s1 / n2)) + (cr2 / n1) * (s2 / n2);
+        f[20] = s0; f[21] = s1; f[22] = s2;
+      }
+      f[23] = g[15]; f[24] = g[16]; f[25] = g[17];  // pose_dist, R_measure, t_measure
+      const float4* wk = W1p + (size_t)(13 * k) * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < SR_VIEW_SLOTS / 2; ++t) sr_l1_step(acc, wk[t * 64], f[2 * t], f[2 * t + 1]);
+    }
+    {
+      // tail slots: d, cur[0..15], cur_ray[0..2], 1 (bias), 0
+      const float4* wk = W1p + (size_t)(13 * p.K) * 64 + lane;
+      sr_l1_step(acc, wk[0 * 64], d, cur[0]);
+#pragma unroll
+      for (int t = 1; t < 8; ++t) sr_l1_step(acc, wk[t * 64], cur[2 * t - 1], cur[2 * t]);
+      sr_l1_step(acc, wk[8 * 64], cur[15], cr0);
+      sr_l1_step(acc, wk[9 * 64], cr1, cr2);
+      sr_l1_step(acc, wk[10 * 64], 1.0f, 0.0f);
+    }
+
+    // LeakyReLU(slope) on the hidden layer (networks.py:139): max(v, slope*v) for 0 < slope < 1
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][m][r] = fmaxf(acc[g][m][r], p.slope * acc[g][m][r]);
+
+    // layer 2: the layer-1 accumulators are the B operands; W2 streams from L2
+    f32x16 acc2[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[g][m][r] = 0.0f;
+    const float4* w2 = gW2 + lane;
+    float4 wn0 = w2[0], wn1 = w2[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+      const float4 wA = wn0;
+      wn0 = wn1;
+      wn1 = w2[(size_t)min(t + 2, 64) * 64];
+      const float bP = acc[0][t >> 4][t & 15], bQ = acc[1][t >> 4][t & 15];
+      acc2[0][0] = SR_MFMA(wA.x, bP, acc2[0][0]);
+      acc2[1][0] = SR_MFMA(wA.x, bQ, acc2[1][0]);
+      acc2[0][1] = SR_MFMA(wA.y, bP, acc2[0][1]);
+      acc2[1][1] = SR_MFMA(wA.y, bQ, acc2[1][1]);
+      acc2[0][2] = SR_MFMA(wA.z, bP, acc2[0][2]);
+      acc2[1][2] = SR_MFMA(wA.z, bQ, acc2[1][2]);
+      acc2[0][3] = SR_MFMA(wA.w, bP, acc2[0][3]);
+      acc2[1][3] = SR_MFMA(wA.w, bQ, acc2[1][3]);
+    }
+    {
+      const float4 wA = wn0;  // bias step (t = 64)
+      const float one = half ? 0.0f : 1.0f;
+      acc2[0][0] = SR_MFMA(wA.x, one, acc2[0][0]);
+      acc2[1][0] = SR_MFMA(wA.x, one, acc2[1][0]);
+      acc2[0][1] = SR_MFMA(wA.y, one, acc2[0][1]);
+      acc2[1][1] = SR_MFMA(wA.y, one, acc2[1][1]);
+      acc2[0][2] = SR_MFMA(wA.z, one, acc2[0][2]);
+      acc2[1][2] = SR_MFMA(wA.z, one, acc2[1][2]);
+      acc2[0][3] = SR_MFMA(wA.w, one, acc2[0][3]);
+      acc2[1][3] = SR_MFMA(wA.w, one, acc2[1][3]);
+    }
+
+    // layer 3 (128 -> 1, no activation: disable_final_activation=True, cost_volume.py:438)
+    const float4* w3 = reinterpret_cast<const float4*>(gW3 + half * 64);
+    float oP = 0.0f, oQ = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 wv = w3[m * 4 + q];
+        const float wr[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float hp = acc2[0][m][4 * q + i], hq = acc2[1][m][4 * q + i];
+          oP = fmaf(wr[i], fmaxf(hp, p.slope * hp), oP);
+          oQ = fmaf(wr[i], fmaxf(hq, p.slope * hq), oQ);
+        }
+      }
+    oP += __shfl_xor(oP, 32);
+    oQ += __shfl_xor(oQ, 32);
+    const float cost = (half ? oQ : oP) + gW3[128];
+
+    if (active) {
+      p.out.cv[b * p.out.sb + j * p.out.sd + (int64_t)pix * p.out.sp] = cost;
+      if (j == p.D - 1 && p.out.mask) p.out.mask[(size_t)b * N + pix] = (uint8_t)(any_depth && any_bounds);
+    }
+  }
+}
+
+// lowest_cost = planes[argmax_d volume] (cost_volume.py:338-342, 374-378); first maximum wins
+__global__ void sr_argmax_planes_kernel(const float* __restrict__ cv, int64_t sb, int64_t sd, int64_t sp,
+                                        SrPlanes planes, int h, int w, int D, float* __restrict__ lowest) {
+  const int N = h * w;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= N) return;
+  const int y = pix / w, x = pix - y * w;
+  const float* c = cv + b * sb + (int64_t)pix * sp;
+  float best = c[0];
+  int bj = 0;
+  for (int j = 1; j < D; ++j) {
+    const float v = c[j * sd];
+    if (v > best) { best = v; bj = j; }
+  }
+  lowest[(size_t)b * N + pix] = planes.ptr[b * planes.sb + bj * planes.sd + y * planes.sy + x * planes.sx];
+}
+
+// ------------------------------------------------------------------ C ABI -------------
+
+extern "C" size_t sr_mlp_volume_workspace_bytes(int B, int K, int C, int h, int w, int hidden) {
+  (void)hidden;
+  if (B < 0 || K < 0) return 0;
+  return sr_volume_workspace_bytes(B, K, C, h, w) + sr_align_up(sr_mlp_packed_floats(K) * sizeof(float), 256) + 256;
+}
+
+static float* sr_ws_packed(void* workspace, int B, int K, int C, int h, int w) {
+  return (float*)sr_align_up((size_t)workspace + sr_volume_workspace_bytes(B, K, C, h, w), 256);
+}
+
+extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, const float* planes, int64_t ps_b,
+                                   int64_t ps_d, int64_t ps_y, int64_t ps_x, float leaky_slope, int B, int K,
+                                   int C, int h, int w, int D, float* out_cv, int64_t cv_sb, int64_t cv_sd,
+                                   int64_t cv_sp, float* out_lowest, uint8_t* out_mask, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
+  if (B < 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!cur || !invK_cur || !planes || !out_cv || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if (C != 16) return SR_ERR_UNSUPPORTED;
+  if (!(leaky_slope > 0.0f && leaky_slope < 1.0f)) return SR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sr_mlp_volume_workspace_bytes(B, K, C, h, w, SR_HID)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = h * w;
+
+  SrMlpParams p;
+  p.cur = cur; p.src_nhwc = sr_ws_src_nhwc(workspace, B, K); p.invK = invK_cur; p.geom = sr_ws_geom(workspace);
+  p.packed = sr_ws_packed(workspace, B, K, C, h, w);
+  p.planes = {planes, ps_b, ps_d, ps_y, ps_x};
+  p.out = {out_cv, cv_sb, cv_sd, cv_sp, out_lowest, out_mask};
+  p.B = B; p.K = K; p.h = h; p.w = w; p.D = D;
+  p.tiles = (N + 63) / 64;
+  p.inv_w = (float)(1.0 / (double)w);
+  p.inv_h = (float)(1.0 / (double)h);
+  p.slope = leaky_slope;
+
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const long nitems = (long)B * p.tiles * D;
+  const int blocks = (int)((nitems + 3) / 4 < cus ? (nitems + 3) / 4 : cus);
+  const size_t w1_bytes = (size_t)sr_mlp_steps1(K) * 1024;
+  if (w1_bytes <= 160 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)sr_mlp_volume_kernel<true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)w1_bytes);
+    if (e != hipSuccess) return sr_hip_rc(e);
+    hipLaunchKernelGGL(sr_mlp_volume_kernel<true>, dim3(blocks), dim3(256), w1_bytes, stream, p);
+  } else {
+    hipLaunchKernelGGL(sr_mlp_volume_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
+  }
+  int rc = sr_hip_rc(hipGetLastError());
+  if (rc) return rc;
+  if (out_lowest) {
+    hipLaunchKernelGGL(sr_argmax_planes_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, out_cv, cv_sb,
+                       cv_sd, cv_sp, p.planes, h, w, D, out_lowest);
+    rc = sr_hip_rc(hipGetLastError());
+  }
+  return rc;
+}
+
+extern "C" int sr_mlp_pack_weights(const float* W1, const float* b1, const float* W2, const float* b2,
+                                   const float* W3, const float* b3, int hidden, int B, int K, int C, int h, int w,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !workspace || K <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (hidden != SR_HID || C != 16) return SR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sr_mlp_volume_workspace_bytes(B, K, C, h, w, hidden)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  hipLaunchKernelGGL(sr_mlp_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream_, W1, b1, W2, b2, W3, b3,
+                     sr_ws_packed(workspace, B, K, C, h, w), K, C);
+  return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" int sr_mlp_volume_fwd(const float* cur, const float* src, const float* K_src, const float* T_src_cur,
+                                 const float* T_cur_src, const float* invK_cur, const float* planes, int64_t ps_b,
+                                 int64_t ps_d, int64_t ps_y, int64_t ps_x, const float* W1, const float* b1,
+                                 const float* W2, const float* b2, const float* W3, const float* b3, int hidden,
+                                 float leaky_slope, int B, int K, int C, int h, int w, int D, float* out_cv,
+                                 int64_t cv_sb, int64_t cv_sd, int64_t cv_sp, float* out_lowest, uint8_t* out_mask,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
+  if (B < 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!T_cur_src) return SR_ERR_INVALID_ARGUMENT;
+  if (hidden != SR_HID || C != 16) return SR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sr_mlp_volume_workspace_bytes(B, K, C, h, w, hidden)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  int rc = sr_volume_prepare(src, K_src, T_src_cur, T_cur_src, B, K, C, h, w, workspace, workspace_bytes, stream_);
+  if (rc) return rc;
+  rc = sr_mlp_pack_weights(W1, b1, W2, b2, W3, b3, hidden, B, K, C, h, w, workspace, workspace_bytes, stream_);
+  if (rc) return rc;
+  return sr_mlp_volume_sweep(cur, invK_cur, planes, ps_b, ps_d, ps_y, ps_x, leaky_slope, B, K, C, h, w, D, out_cv,
+                             cv_sb, cv_sd, cv_sp, out_lowest, out_mask, workspace, workspace_bytes, stream_);
+}
