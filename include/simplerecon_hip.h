@@ -135,6 +135,38 @@ int sr_mlp_volume_fwd(const float* cur, const float* src, const float* K_src, co
                       int64_t cv_sb, int64_t cv_sd, int64_t cv_sp, float* out_lowest, uint8_t* out_mask,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------- 2-D conv stack -------
+ *
+ * Channels-last activations: element (b, y, x, c) of a tensor lives at
+ *   ptr[b*batch_stride + (y*W + x)*pix_stride + c]      (strides in elements),
+ * so a channel slice of a wider concat buffer is addressed by offsetting `ptr` and keeping
+ * the buffer's pix_stride -- producers write straight into the consumer's torch.cat layout
+ * (reference modules/networks.py:83-89, 124).
+ */
+
+/* Floats needed for the packed form of a [Cout, Cin, k, k] Conv2d weight (k = 1 or 3). */
+size_t sr_conv_packed_weight_floats(int Cout, int Cin, int ksize);
+
+/* Packs an nn.Conv2d weight ([Cout,Cin,k,k], contiguous) into MFMA B-fragment order. */
+int sr_conv_pack_weights(const float* weight, int Cout, int Cin, int ksize, float* packed, void* stream);
+
+/* out = act( conv2d(in, W, stride, padding = k/2) + bias [+ residual] ), act = LeakyReLU(slope)
+ * when leaky_slope >= 0, identity otherwise.  One launch replaces nn.Conv2d + bias + the
+ * residual add + nn.LeakyReLU of BasicBlock.forward (reference modules/layers.py:68-85) and
+ * conv3x3 / conv1x1 (layers.py:7-22).  ksize in {1,3}, stride in {1,2}; fp32 MFMA
+ * (exact fp32 products and accumulation).  `residual` has the output's geometry. */
+int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                       const float* packed_weight, const float* bias, const float* residual,
+                       int64_t res_batch_stride, int res_pix_stride, float* out,
+                       int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                       int Cout, int ksize, int stride, float leaky_slope, void* stream);
+
+/* F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) -- `upsample` of the
+ * reference (utils/generic_utils.py:96-105) -- on channels-last data, [B,H,W,C] -> [B,2H,2W,C]. */
+int sr_upsample2x_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out,
+                           int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

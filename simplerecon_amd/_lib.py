@@ -35,6 +35,10 @@ SIGNATURES = {
                                  _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
     "sr_mlp_volume_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i,
                                _f, _i, _i, _i, _i, _i, _i, _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
+    "sr_conv_packed_weight_floats": (_sz, [_i, _i, _i]),
+    "sr_conv_pack_weights": (_i, [_p, _i, _i, _i, _p, _p]),
+    "sr_conv2d_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "sr_upsample2x_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
 }
 
 

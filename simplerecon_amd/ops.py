@@ -1,0 +1,150 @@
+"""Host-side plumbing for the HIP conv stack: channels-last tensor views, packed-weight cache,
+and thin wrappers that hand raw pointers/strides to the C ABI (include/simplerecon_hip.h).
+
+A "channels-last view" is a logically [B,C,H,W] torch tensor whose memory is [B,H,W,Ctot] with
+this tensor occupying channels [c0, c0+C) of each pixel -- either a dense channels_last tensor or
+a channel slice `buf[:, c0:c1]` of one.  Kernels take (pointer, batch stride, pixel stride)."""
+import ctypes as C
+import weakref
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_PACKED = weakref.WeakKeyDictionary()  # nn.Conv2d -> (weight version, data_ptr, packed tensor)
+
+
+def empty_nhwc(b, c, h, w, device):
+    return torch.empty((b, c, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+
+
+def conv_out_hw(h, w, stride, ksize=3):
+    pad = ksize // 2
+    return (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+
+
+def _is_nhwc_view(t):
+    if t.dim() != 4:
+        return False
+    b, c, h, w = t.shape
+    sb, sc, sh, sw = t.stride()
+    if c == 1:
+        sc = 1
+    return sc == 1 and sw >= c and sh == w * sw and (b == 1 or sb >= h * sh)
+
+
+def as_nhwc(t, name="tensor"):
+    """Returns `t` if it already is a channels-last view, else a dense channels_last repack."""
+    _lib.require_device_f32(name, t)
+    if t.dim() != 4:
+        raise ValueError(f"{name} must be [B,C,H,W], got {tuple(t.shape)}")
+    if _is_nhwc_view(t):
+        return t
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _strides(t):
+    """(batch stride, pixel stride) in elements of a channels-last view."""
+    b, c, h, w = t.shape
+    sb, _, _, sw = t.stride()
+    if b == 1:
+        sb = h * w * sw
+    return sb, sw
+
+
+def packed_weight(conv: nn.Conv2d):
+    w = conv.weight
+    _lib.require_device_f32("conv weight", w)
+    if conv.kernel_size[0] != conv.kernel_size[1] or conv.kernel_size[0] not in (1, 3) or conv.groups != 1 \
+            or conv.dilation != (1, 1) or conv.padding != (conv.kernel_size[0] // 2,) * 2 \
+            or conv.padding_mode != "zeros":
+        raise _lib.HipLibraryError(f"unsupported Conv2d configuration for the HIP path: {conv}")
+    hit = _PACKED.get(conv)
+    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+        return hit[2]
+    lib = _lib.lib()
+    co, ci, k, _ = w.shape
+    packed = torch.empty(lib.sr_conv_packed_weight_floats(co, ci, k), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = lib.sr_conv_pack_weights(_lib.ptr(w.detach().contiguous()), co, ci, k, _lib.ptr(packed),
+                                      _lib.stream_ptr(w.device))
+    _lib.check(rc, "sr_conv_pack_weights")
+    _PACKED[conv] = (w._version, w.data_ptr(), packed)
+    return packed
+
+
+def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
+    """act(conv(x) + bias [+ residual]) with the reference's Conv2d semantics; returns a channels-last view."""
+    _lib.refuse_autograd(x, conv.weight)
+    x = as_nhwc(x, "conv input")
+    b, ci, h, w = x.shape
+    if ci != conv.in_channels:
+        raise ValueError(f"conv expects {conv.in_channels} input channels, got {ci}")
+    k, s = conv.kernel_size[0], conv.stride[0]
+    if conv.stride[0] != conv.stride[1] or s not in (1, 2):
+        raise _lib.HipLibraryError(f"unsupported stride {conv.stride}")
+    ho, wo = conv_out_hw(h, w, s, k)
+    co = conv.out_channels
+    if out is None:
+        out = empty_nhwc(b, co, ho, wo, x.device)
+    else:
+        if tuple(out.shape) != (b, co, ho, wo) or not _is_nhwc_view(out):
+            raise ValueError(f"`out` must be a channels-last view of shape {(b, co, ho, wo)}")
+        _lib.require_device_f32("out", out)
+    wp = packed_weight(conv)
+    bias = conv.bias.detach() if conv.bias is not None else None
+    if residual is not None:
+        residual = as_nhwc(residual, "residual")
+        if tuple(residual.shape) != (b, co, ho, wo):
+            raise ValueError(f"residual shape {tuple(residual.shape)} != output shape {(b, co, ho, wo)}")
+    if b == 0:
+        return out
+    isb, isp = _strides(x)
+    osb, osp = _strides(out)
+    rsb, rsp = _strides(residual) if residual is not None else (0, 0)
+    lib = _lib.lib()
+    with torch.cuda.device(x.device):
+        rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb, rsp,
+                                    _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s,
+                                    C.c_float(-1.0 if leaky is None else float(leaky)), _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_conv2d_nhwc_fwd")
+    return out
+
+
+def basic_block(block, x, out=None):
+    """BasicBlock.forward of the reference (modules/layers.py:68-85) as 2 (or 3) fused launches."""
+    if not isinstance(block.bn1, nn.Identity) or not isinstance(block.bn2, nn.Identity):
+        raise _lib.HipLibraryError("the HIP BasicBlock implements norm_layer=nn.Identity only (what SimpleRecon uses)")
+    slope = block.relu.negative_slope
+    x = as_nhwc(x, "BasicBlock input")
+    t = conv2d(x, block.conv1, leaky=slope)
+    identity = x if block.downsample is None else conv2d(x, block.downsample[0])
+    return conv2d(t, block.conv2, residual=identity, leaky=slope, out=out)
+
+
+def upsample2x(x, out=None):
+    """Bilinear x2, align_corners=False (reference utils/generic_utils.py:96-105)."""
+    x = as_nhwc(x, "upsample input")
+    _lib.refuse_autograd(x)
+    b, c, h, w = x.shape
+    if out is None:
+        out = empty_nhwc(b, c, 2 * h, 2 * w, x.device)
+    elif tuple(out.shape) != (b, c, 2 * h, 2 * w) or not _is_nhwc_view(out):
+        raise ValueError(f"`out` must be a channels-last view of shape {(b, c, 2 * h, 2 * w)}")
+    if b == 0:
+        return out
+    isb, isp = _strides(x)
+    osb, osp = _strides(out)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().sr_upsample2x_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(out), osb, osp, b, h, w, c,
+                                               _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_upsample2x_nhwc_fwd")
+    return out
+
+
+def copy_into(dst_view, src):
+    """Copies a [B,C,H,W] tensor (any layout) into a channels-last slice (device-side strided copy)."""
+    _lib.require_device_f32("copy source", src)
+    dst_view.copy_(src)
+    return dst_view
