@@ -131,8 +131,182 @@ class DotCfg2:
                           f"(plain C + OpenMP, {oracle.num_threads()} threads of {os.cpu_count()} host CPUs)"}
 
 
+class HeroCfg3:
+    """BASELINE.json configs[2]: hero_model.yaml (metadata-MLP matching), batch 8, 7 source views,
+    64 planes, 640x480: the full hot path = FeatureVolumeManager sweep -> CVEncoder -> DepthDecoderPP
+    -> exp, all on hand-written HIP kernels.  Inputs = the encoders' outputs, resident in HBM."""
+    name = "hero_cfg3"
+    B, K, Cc, D, h, w = 8, 7, 16, 64, 120, 160
+    feature_volume_type = "mlp_feature_volume"
+
+    def __init__(self, dev, rank, B=None):
+        from simplerecon_amd import depth_model as dm
+        if B is not None:
+            self.B = B
+        self.dev = dev
+        self.frames_per_step = self.B
+        opts = dm.default_options(image_width=4 * self.w, image_height=4 * self.h, model_num_views=self.K + 1,
+                                  matching_num_depth_bins=self.D, feature_volume_type=self.feature_volume_type)
+        model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(), matching_encoder=dm.StandInMatchingEncoder())
+        synthetic.seeded_fill_(model.cost_volume_net, seed=1)
+        synthetic.seeded_fill_(model.depth_decoder, seed=2)
+        if hasattr(model.cost_volume, "mlp"):
+            synthetic.seeded_fill_(model.cost_volume.mlp, seed=3)
+        self.model = model.to(dev).eval()
+        inp = synthetic.cost_volume_inputs(self.B, self.K, self.Cc, self.h, self.w, seed=rank, device=dev)
+        self.inp = inp
+        self.pyramid = [f.contiguous(memory_format=torch.channels_last) for f in
+                        synthetic.image_prior_pyramid(self.B, self.h, self.w, seed=rank, device=dev)]
+        self.results = []
+        self.last = None
+
+    def step(self, i=0):
+        inp = self.inp
+        out = self.model.hot_path(self.pyramid, inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"],
+                                  inp["src_poses"], inp["src_Ks"], inp["cur_invK"], return_mask=True)
+        self.last = out
+
+    def finish(self, world):
+        if world > 1:
+            depth = self.last["depth_pred_s0_b1hw"].contiguous()
+            out = [torch.empty_like(depth) for _ in range(world)] if dist.get_rank() == 0 else None
+            dist.gather(depth, out, dst=0)
+
+    def config(self, world):
+        kind = "FeatureVolumeManager (metadata-MLP matching)" if self.feature_volume_type == "mlp_feature_volume" \
+            else "CostVolumeManager (dot-product matching)"
+        return {"workload": f"{self.name}: hot path = {kind} -> CVEncoder -> DepthDecoderPP -> exp, batch "
+                            f"{self.B}/GPU, {self.K} source views, {self.D} planes, 640x480 image ({self.h}x{self.w} "
+                            f"matching features x {self.Cc} ch, image-prior pyramid 24/48/64/160/256 ch), fp32, "
+                            f"random-init weights; image/matching encoders (third-party, out of scope) not timed",
+                "frames_per_step_per_gpu": self.B, "parallelism": f"replica x{world} (keyframes sharded)"}
+
+    def _profile_convs(self, n):
+        from simplerecon_amd import ops
+        inp = self.inp
+        with torch.inference_mode():
+            vol = self.model.cost_volume(cur_feats=inp["cur_feats"], src_feats=inp["src_feats"],
+                                         src_extrinsics=inp["src_extrinsics"], src_poses=inp["src_poses"],
+                                         src_Ks=inp["src_Ks"], cur_invK=inp["cur_invK"], min_depth=inp["min_depth"],
+                                         max_depth=inp["max_depth"])[0]
+            torch.cuda.synchronize()
+            ops.PROFILE = []
+            try:
+                for _ in range(n):
+                    feats = self.model.cost_volume_net(vol, self.pyramid[1:])
+                    self.model.depth_decoder(self.pyramid[:1] + feats)
+                torch.cuda.synchronize()
+                rec = ops.PROFILE
+            finally:
+                ops.PROFILE = None
+        agg = {}
+        for name, flops, e0, e1, _shape in rec:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        return agg
+
+    def _mlp_sweep_time(self, n):
+        lib = _lib.lib()
+        m, inp = self.model.cost_volume, self.inp
+        B, K, Cc, h, w, D = self.B, self.K, self.Cc, self.h, self.w, self.D
+        planes = m.generate_depth_planes(B, inp["min_depth"], inp["max_depth"])
+        vol = torch.empty((B, D, h, w), device=self.dev, memory_format=torch.channels_last)
+        ws = torch.empty(lib.sr_mlp_volume_workspace_bytes(B, K, Cc, h, w, 128), dtype=torch.uint8, device=self.dev)
+        st = _lib.stream_ptr(self.dev)
+        _lib.check(lib.sr_volume_prepare(_lib.ptr(inp["src_feats"]), _lib.ptr(inp["src_Ks"]),
+                                         _lib.ptr(inp["src_extrinsics"]), _lib.ptr(inp["src_poses"]), B, K, Cc, h, w,
+                                         _lib.ptr(ws), ws.numel(), st), "prepare")
+        lin = [mm for mm in m.mlp.net if isinstance(mm, torch.nn.Linear)]
+        prm = [t.detach().contiguous() for t in (lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
+                                                 lin[2].weight, lin[2].bias)]
+        _lib.check(lib.sr_mlp_pack_weights(*[_lib.ptr(t) for t in prm], 128, B, K, Cc, h, w, _lib.ptr(ws),
+                                           ws.numel(), st), "pack")
+
+        def sweep():
+            _lib.check(lib.sr_mlp_volume_sweep(_lib.ptr(inp["cur_feats"]), _lib.ptr(inp["cur_invK"]), _lib.ptr(planes),
+                                               *planes.stride(), C.c_float(0.01), B, K, Cc, h, w, D, _lib.ptr(vol),
+                                               D * h * w, 1, D, None, None, _lib.ptr(ws), ws.numel(), st), "sweep")
+        return _time_launches(sweep, n)
+
+    def roofline(self, n):
+        n = max(3, min(n, 10))
+        agg = self._profile_convs(n)
+        self._conv_agg = agg
+        name = max(agg, key=lambda k: agg[k][2])
+        calls, flops, t = agg[name]
+        achieved = flops / t / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": _pmc_traffic(self.name),
+                "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // n,
+                "algorithmic_flops_per_launch": flops / calls,
+                "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_32x32x2_f32); FLOPs = 2*B*Ho*Wo*Cout*Cin*k*k summed over the "
+                        "launches of this kernel in one step"}
+
+    def extra_kernels(self, n):
+        out = []
+        for name, (calls, flops, t) in sorted(self._conv_agg.items(), key=lambda kv: -kv[1][2])[1:]:
+            out.append({"kernel": name, "bound": "mfma", "achieved": flops / t / 1e12, "peak": FP32_MFMA_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF, "avg_launch_us": t / calls * 1e6})
+        if self.feature_volume_type == "mlp_feature_volume":
+            t = self._mlp_sweep_time(max(3, min(n, 10)))
+            N = self.h * self.w
+            cin = self.Cc * (self.K + 1) + 10 * self.K + 4
+            flops = 2.0 * (cin * 128 + 128 * 128 + 128) * self.B * self.D * N
+            out.append({"kernel": "sr_mlp_volume_kernel<true>", "bound": "mfma", "achieved": flops / t / 1e12,
+                        "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF,
+                        "avg_launch_us": t * 1e6, "algorithmic_flops_per_launch": flops,
+                        "algorithmic_bytes_per_launch": self.B * (4 * ((self.K + 1) * self.Cc * N + self.D * N + N))})
+        return out
+
+    def cpu_baseline(self):
+        import oracle
+        inp = {k: v[:1].cpu().numpy() if (v.dim() > 0 and v.shape[0] == self.B and k not in ("min_depth", "max_depth"))
+               else v.cpu().numpy() for k, v in self.inp.items()}
+        pyr = [f[:1].contiguous().cpu().numpy() for f in self.pyramid]
+        m = self.model
+        planes = m.cost_volume.generate_depth_planes(1, self.inp["min_depth"], self.inp["max_depth"])[:, :, 0, 0].cpu().numpy()
+        esd = {k: v.cpu().numpy() for k, v in m.cost_volume_net.state_dict().items()}
+        dsd = {k: v.cpu().numpy() for k, v in m.depth_decoder.state_dict().items()}
+        if self.feature_volume_type == "mlp_feature_volume":
+            sd = {k: v.cpu().numpy() for k, v in m.cost_volume.mlp.state_dict().items()}
+            mlp = dict(W1=sd["net.0.weight"], b1=sd["net.0.bias"], W2=sd["net.2.weight"], b2=sd["net.2.bias"],
+                       W3=sd["net.4.weight"], b3=sd["net.4.bias"])
+
+        def run():
+            if self.feature_volume_type == "mlp_feature_volume":
+                vol = oracle.mlp_volume(inp["cur_feats"], inp["src_feats"], inp["src_Ks"], inp["src_extrinsics"],
+                                        inp["src_poses"], inp["cur_invK"], planes, mlp)[0]
+            else:
+                vol = oracle.dot_volume(inp["cur_feats"], inp["src_feats"], inp["src_Ks"], inp["src_extrinsics"],
+                                        inp["cur_invK"], planes)[0]
+            feats = oracle.cv_encoder(vol, pyr[1:], esd)
+            return oracle.depth_decoder_pp([pyr[0]] + feats, dsd)
+        t0 = time.perf_counter()
+        run()
+        reps, first = 1, time.perf_counter() - t0
+        while time.perf_counter() - t0 < 12.0:
+            run()
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        return {"value": 1.0 / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+                "sample": f"{reps} repetition(s) of 1 frame of {self.name} (cost volume + CVEncoder + DepthDecoderPP) "
+                          f"through oracle/ (plain C + OpenMP restatement, {oracle.num_threads()} threads of "
+                          f"{os.cpu_count()} host CPUs)"}
+
+
+class DotFull(HeroCfg3):
+    """dot_product_model.yaml through the full hot path (cost volume + conv stack), batch 8."""
+    name = "dot_full"
+    feature_volume_type = "simple_cost_volume"
+
+
 WORKLOADS = {
+    "hero_cfg3": lambda dev, rank: HeroCfg3(dev, rank),
+    "hero_b1": lambda dev, rank: HeroCfg3(dev, rank, B=1),
+    "dot_full": lambda dev, rank: DotFull(dev, rank),
     "dot_cfg2": lambda dev, rank: DotCfg2(dev, rank),
     "dot_b8": lambda dev, rank: DotCfg2(dev, rank, B=8),
 }
-DEFAULT = "dot_cfg2"
+DEFAULT = "hero_cfg3"

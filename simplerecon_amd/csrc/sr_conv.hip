@@ -17,6 +17,8 @@
 //     (one coalesced 1 KiB read per wave feeds 4 k-steps x MT M-tiles); they never occupy LDS.
 //   * Epilogue in registers: + bias, + residual (identity or projected skip), LeakyReLU, and the
 //     store goes directly into a channel slice of the consumer's concat buffer.
+#include <stdlib.h>
+
 #include "sr_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,119 +34,237 @@ struct SrConvParams {
   const float* res; int64_t res_sb; int res_sp;     // residual (output geometry) or null
   float* out; int64_t out_sb; int out_sp;
   int H, W, Cin, Ho, Wo, Cout, Co_pad, G;           // G = 8-channel groups (even, zero padded)
-  int tiles_x;
+  int tiles_x, tiles_y, co_blocks, total_tiles;
   float slope;                                      // < 0: no activation
   int vec4;                                         // input rows 16-byte aligned
+  int debug;                                        // ablation bits (env SR_CONV_DEBUG), 0 in production
 };
 
-template <int KS, int S, int MT, int NT>
+// Stages global -> registers (issued before the MFMA phase of the previous slab) -> LDS (after it):
+// the HBM/L2 latency of the next slab hides under the current slab's MFMAs (double-buffered tile).
+template <int KS, int S, int MT>
+struct SrConvGeom {
+  static constexpr int TH = 4 * MT;
+  static constexpr int HH = (TH - 1) * S + KS;
+  static constexpr int HW = (SR_TW - 1) * S + KS;
+  static constexpr int ELEMS = HH * HW * 4;            // float4 elements per slab
+  static constexpr int PER_THREAD = (ELEMS + 255) / 256;
+  static constexpr int TILE_FLOATS = HH * HW * SR_LDS_ROW;
+};
+
+// Per-thread element offsets (in floats, relative to the image base; -1 = outside the image) of the
+// slab elements this thread stages; fixed for a tile, so the per-slab work is one add + one load each.
+template <int KS, int S, int MT>
+__device__ __forceinline__ void sr_conv_stage_setup(const SrConvParams& p, int iy0, int ix0,
+                                                    int (&offs)[SrConvGeom<KS, S, MT>::PER_THREAD]) {
+  using G = SrConvGeom<KS, S, MT>;
+#pragma unroll
+  for (int it = 0; it < G::PER_THREAD; ++it) {
+    const int e = threadIdx.x + it * 256;
+    const int px = e >> 2, q = e & 3;
+    const int hy = px / G::HW, hx = px - hy * G::HW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool ok = (e < G::ELEMS) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W) && !(p.debug & 4);
+    offs[it] = ok ? (iy * p.W + ix) * p.in_sp + 4 * q : -1;
+  }
+}
+
+// VEC4 = true: rows are 16-byte aligned and Cin % 4 == 0 -> branch-free: every lane issues exactly one
+// 16-byte load per element (out-of-image / out-of-range lanes read element 0 and are masked to zero).
+template <int KS, int S, int MT, bool VEC4>
+__device__ __forceinline__ void sr_conv_stage_load(const SrConvParams& p, const float* __restrict__ in_b, int c0,
+                                                   const int (&offs)[SrConvGeom<KS, S, MT>::PER_THREAD],
+                                                   float4 (&stg)[SrConvGeom<KS, S, MT>::PER_THREAD]) {
+  using G = SrConvGeom<KS, S, MT>;
+#pragma unroll
+  for (int it = 0; it < G::PER_THREAD; ++it) {
+    const int c = c0 + 4 * ((threadIdx.x + it * 256) & 3);
+    const bool ok = (offs[it] >= 0) && (c < p.Cin);
+    const float* src = in_b + (ok ? offs[it] + c0 : 0);
+    if (VEC4) {
+      const float4 v = *reinterpret_cast<const float4*>(src);  // always a valid address; masked below
+      stg[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        v.x = src[0];
+        if (c + 1 < p.Cin) v.y = src[1];
+        if (c + 2 < p.Cin) v.z = src[2];
+        if (c + 3 < p.Cin) v.w = src[3];
+      }
+      stg[it] = v;
+    }
+  }
+}
+
+template <int KS, int S, int MT>
+__device__ __forceinline__ void sr_conv_stage_store(float* __restrict__ tile,
+                                                    const float4 (&stg)[SrConvGeom<KS, S, MT>::PER_THREAD]) {
+  using G = SrConvGeom<KS, S, MT>;
+#pragma unroll
+  for (int it = 0; it < G::PER_THREAD; ++it) {
+    const int e = threadIdx.x + it * 256;
+    if (e < G::ELEMS) *reinterpret_cast<float4*>(&tile[(e >> 2) * SR_LDS_ROW + 4 * (e & 3)]) = stg[it];
+  }
+}
+
+struct SrTileCoord { int b, co0, oy0, ox0; };
+
+template <int TH, int NT>
+__device__ __forceinline__ SrTileCoord sr_conv_tile(const SrConvParams& p, int work) {
+  // work = ((b * co_blocks + cb) * tiles_y + ty) * tiles_x + tx
+  SrTileCoord t;
+  const int tx = work % p.tiles_x; work /= p.tiles_x;
+  const int ty = work % p.tiles_y; work /= p.tiles_y;
+  const int cb = work % p.co_blocks;
+  t.b = work / p.co_blocks;
+  t.co0 = cb * (32 * NT);
+  t.oy0 = ty * TH;
+  t.ox0 = tx * SR_TW;
+  return t;
+}
+
+// Persistent workgroups: each loops over output tiles, and the (tile, slab) sequence is ONE software
+// pipeline -- the first slab of the next tile is fetched during the last slab of the current one and
+// the epilogue stores drain while the next tile's MFMAs run, so there is no per-tile fill/drain.
+template <int KS, int S, int MT, int NT, bool VEC4>
 __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
-  constexpr int TH = 4 * MT;                         // output rows per workgroup (MT per wave)
-  constexpr int HH = (TH - 1) * S + KS;              // halo rows
-  constexpr int HW = (SR_TW - 1) * S + KS;           // halo cols
+  using G = SrConvGeom<KS, S, MT>;
+  constexpr int TH = G::TH, HW = G::HW;
   constexpr int PAD = KS / 2;
-  __shared__ __attribute__((aligned(16))) float tile[HH * HW * SR_LDS_ROW];
+  constexpr int STEPS = KS * KS * 2;  // (tap, 8-channel group) steps per 16-channel slab
+  __shared__ __attribute__((aligned(16))) float tiles[2][G::TILE_FLOATS];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i = lane & 31, kk = lane >> 5;
-  const int b = blockIdx.z;
-  const int co0 = blockIdx.y * (32 * NT);
-  const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
-  const int oy0 = ty * TH, ox0 = tx * SR_TW;
-  const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
 
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-
-  const float* in_b = p.in + (int64_t)b * p.in_sb;
-  // this lane's A-fragment base inside the halo tile (M-tile m = output row wave*MT + m)
-  int a_off[MT];
+  int a_off[MT];  // this lane's A-fragment base inside the halo tile (M-tile m = output row wave*MT + m)
 #pragma unroll
   for (int m = 0; m < MT; ++m) a_off[m] = (((wave * MT + m) * S) * HW + i * S) * SR_LDS_ROW + 4 * kk;
-  // this lane's B-fragment base inside the packed weights
-  const float4* wp4 = reinterpret_cast<const float4*>(p.wp);
-  const int w_lane = kk * p.Co_pad + co0 + i;  // float4 index within one (tap, g) record of 2*Co_pad float4
-
+  const int64_t rec = (int64_t)2 * p.Co_pad;  // float4 per (tap, g) weight record
   const int chunks = p.G >> 1;
-  for (int ch = 0; ch < chunks; ++ch) {
-    const int c0 = ch * SR_CK;
-    __syncthreads();  // previous slab fully consumed
-    // ---- stage the halo tile of channels [c0, c0+16) ----
-    for (int e = threadIdx.x; e < HH * HW * 4; e += 256) {
-      const int px = e >> 2, q = e & 3;
-      const int hy = px / HW, hx = px - hy * HW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      const int c = c0 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin) {
-        const float* src = in_b + ((int64_t)iy * p.W + ix) * p.in_sp + c;
-        if (p.vec4 && c + 3 < p.Cin) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          v.x = src[0];
-          if (c + 1 < p.Cin) v.y = src[1];
-          if (c + 2 < p.Cin) v.z = src[2];
-          if (c + 3 < p.Cin) v.w = src[3];
-        }
-      }
-      *reinterpret_cast<float4*>(&tile[px * SR_LDS_ROW + 4 * q]) = v;
-    }
-    __syncthreads();
-    // ---- MFMA over taps x 2 channel groups of this slab ----
-#pragma unroll
-    for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-        const int tap = ky * KS + kx;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          float4 a[MT], bw[NT];
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            a[m] = *reinterpret_cast<const float4*>(&tile[a_off[m] + (ky * HW + kx) * SR_LDS_ROW + 8 * g]);
-          const float4* wrec = wp4 + ((int64_t)(tap * p.G + 2 * ch + g) * 2) * p.Co_pad + w_lane;
-#pragma unroll
-          for (int n = 0; n < NT; ++n) bw[n] = wrec[32 * n];
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, bw[n].x, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, bw[n].y, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, bw[n].z, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, bw[n].w, acc[m][n], 0, 0, 0);
-            }
-        }
-      }
-  }
 
-  // ---- epilogue: C[row = pixel column, col = output channel] ----
+  // Weight (B) fragments stream from L2 with a prefetch distance of PD steps through NB rotating
+  // register sets.  VMEM returns in order, so the slab staging loads are issued when the next PD
+  // steps' weights are already in flight: nothing younger than them is needed for >= PD steps.
+  constexpr int PD = (STEPS % 3 == 0) ? 2 : 1;
+  constexpr int NB = PD + 1;
+  static_assert(STEPS % NB == 0, "rotating buffers must line up across slabs");
+  float4 b_f[NB][NT], a_f[2][MT], stg[G::PER_THREAD];
+  int offs[G::PER_THREAD];
+
+  int work = blockIdx.x;
+  if (work >= p.total_tiles) return;
+  SrTileCoord t = sr_conv_tile<TH, NT>(p, work);
+  const float4* wp4 = reinterpret_cast<const float4*>(p.wp) + (kk * p.Co_pad + t.co0 + i);
+  auto load_b = [&](const float4* base, int ch, int s, float4 (&dst)[NT]) {
+    const int tap = s >> 1, g = s & 1;
+    const float4* wrec = base + (int64_t)(tap * p.G + 2 * ch + g) * rec;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int oy = oy0 + wave * MT + m;
-    if (oy >= p.Ho) continue;
+    for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
+  };
+
+  sr_conv_stage_setup<KS, S, MT>(p, t.oy0 * S - PAD, t.ox0 * S - PAD, offs);
+  sr_conv_stage_load<KS, S, MT, VEC4>(p, p.in + (int64_t)t.b * p.in_sb, 0, offs, stg);
+  sr_conv_stage_store<KS, S, MT>(tiles[0], stg);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int co = co0 + 32 * n + i;
-      if (co >= p.Cout) continue;
-      const float bv = p.bias ? p.bias[co] : 0.0f;
+  for (int s = 0; s < PD; ++s) load_b(wp4, 0, s, b_f[s]);
+  __syncthreads();
+  int buf = 0;
+
+  while (true) {
+    const int next_work = work + gridDim.x;
+    const bool have_next = next_work < p.total_tiles;
+    SrTileCoord tn = t;
+    if (have_next) tn = sr_conv_tile<TH, NT>(p, next_work);
+    const float4* wp4n = reinterpret_cast<const float4*>(p.wp) + (kk * p.Co_pad + tn.co0 + i);
+
+    f32x16 acc[MT][NT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (ox >= p.Wo) continue;
-        const int64_t opix = (int64_t)oy * p.Wo + ox;
-        float v = acc[m][n][r] + bv;
-        if (p.res) v += p.res[(int64_t)b * p.res_sb + opix * p.res_sp + co];
-        if (p.slope >= 0.0f) v = v > 0.0f ? v : v * p.slope;
-        p.out[(int64_t)b * p.out_sb + opix * p.out_sp + co] = v;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    for (int ch = 0; ch < chunks; ++ch) {
+      const float* tile = tiles[buf];
+      const bool last = ch + 1 == chunks;
+      const bool more = !last || have_next;        // is there a following slab in the pipeline?
+      if (more) {
+        if (last) sr_conv_stage_setup<KS, S, MT>(p, tn.oy0 * S - PAD, tn.ox0 * S - PAD, offs);  // next tile
+        sr_conv_stage_load<KS, S, MT, VEC4>(p, p.in + (int64_t)(last ? tn.b : t.b) * p.in_sb,
+                                            last ? 0 : (ch + 1) * SR_CK, offs, stg);
+      }
+      const float4* wnext = last ? wp4n : wp4;
+      const int chn = last ? 0 : ch + 1;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a_f[0][m] = *reinterpret_cast<const float4*>(&tile[a_off[m]]);
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        const int cb = s % NB, ca = s & 1;
+        // request: weights of step s+PD (possibly of the next slab), LDS fragments of step s+1
+        if (s + PD < STEPS) load_b(wp4, ch, s + PD, b_f[(s + PD) % NB]);
+        else if (more) load_b(wnext, chn, s + PD - STEPS, b_f[(s + PD) % NB]);
+        if (s + 1 < STEPS) {
+          const int tap = (s + 1) >> 1, g = (s + 1) & 1;
+          const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            a_f[ca ^ 1][m] = *reinterpret_cast<const float4*>(&tile[a_off[m] + (ky * HW + kx) * SR_LDS_ROW + 8 * g]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca][m].x, b_f[cb][n].x, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca][m].y, b_f[cb][n].y, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca][m].z, b_f[cb][n].z, acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca][m].w, b_f[cb][n].w, acc[m][n], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) sr_conv_stage_store<KS, S, MT>(tiles[buf ^ 1], stg);
+      __syncthreads();
+      buf ^= 1;
+    }
+
+    // ---- epilogue of tile t: C[row = pixel column, col = output channel] ----
+    // The residual loads of a whole 32x32 fragment are issued back to back BEFORE any store (out and
+    // residual may alias in the type system; interleaving them would serialise on memory latency).
+    {
+      const float* __restrict__ resp = p.res ? p.res + (int64_t)t.b * p.res_sb : nullptr;
+      float* __restrict__ outp = p.out + (int64_t)t.b * p.out_sb;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oy = t.oy0 + wave * MT + m;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int co = t.co0 + 32 * n + i;
+          const bool okc = (oy < p.Ho) && (co < p.Cout);
+          const float bv = (p.bias && okc) ? p.bias[co] : 0.0f;
+          float rv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ox = t.ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            rv[r] = (resp && okc && ox < p.Wo && !(p.debug & 2)) ? resp[((int64_t)oy * p.Wo + ox) * p.res_sp + co] : 0.0f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ox = t.ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            float v = acc[m][n][r] + bv + rv[r];
+            if (p.slope >= 0.0f) v = v > 0.0f ? v : v * p.slope;
+            if (okc && ox < p.Wo && (!(p.debug & 1) || v == 1.2345e33f)) outp[((int64_t)oy * p.Wo + ox) * p.out_sp + co] = v;
+          }
+        }
       }
     }
+    if (!have_next) break;
+    work = next_work;
+    t = tn;
+    wp4 = wp4n;
   }
 }
 
@@ -222,14 +342,37 @@ extern "C" int sr_conv_pack_weights(const float* weight, int Cout, int Cin, int 
   return sr_hip_rc(hipGetLastError());
 }
 
+static int sr_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else cus = 256;
+  }
+  return cus;
+}
+
 template <int KS, int S, int MT>
-static int sr_conv_dispatch_nt(const SrConvParams& p, int B, hipStream_t stream) {
+static int sr_conv_dispatch_nt(SrConvParams& p, int B, hipStream_t stream) {
   const int TH = 4 * MT;
-  const int tiles_y = (p.Ho + TH - 1) / TH;
+  p.tiles_y = (p.Ho + TH - 1) / TH;
   const int nt = (p.Co_pad % 64 == 0) ? 2 : 1;
-  dim3 grid(p.tiles_x * tiles_y, p.Co_pad / (32 * nt), B), block(256);
-  if (nt == 2) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 2>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 1>), grid, block, 0, stream, p);
+  p.co_blocks = p.Co_pad / (32 * nt);
+  p.total_tiles = p.tiles_x * p.tiles_y * p.co_blocks * B;
+  // persistent grid: as many workgroups as can be co-resident (LDS / register limited)
+  const int lds = 2 * SrConvGeom<KS, S, MT>::TILE_FLOATS * (int)sizeof(float);
+  int per_cu = (160 * 1024) / lds;
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  int blocks = sr_num_cus() * per_cu;
+  if (blocks > p.total_tiles) blocks = p.total_tiles;
+  dim3 grid(blocks), block(256);
+  const bool v4 = p.vec4 && (p.Cin % 4 == 0);
+  if (nt == 2 && v4) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 2, true>), grid, block, 0, stream, p);
+  else if (nt == 2) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 2, false>), grid, block, 0, stream, p);
+  else if (v4) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 1, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 1, false>), grid, block, 0, stream, p);
   return sr_hip_rc(hipGetLastError());
 }
 
@@ -255,6 +398,7 @@ extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int 
   p.G = ((Cin + SR_CK - 1) / SR_CK) * 2;
   p.tiles_x = (p.Wo + SR_TW - 1) / SR_TW;
   p.slope = leaky_slope;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0);
   hipStream_t stream = (hipStream_t)stream_;
   if (ksize == 3 && stride == 1) return sr_conv_dispatch_nt<3, 1, 2>(p, B, stream);

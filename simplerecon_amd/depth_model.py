@@ -1,0 +1,215 @@
+"""DepthModel shell -- the caller of the hot path, API-compatible with the reference's
+experiment_modules/depth_model.py `DepthModel.forward` (:247-407) and `__init__` (:68-189),
+without the PyTorch-Lightning / losses / training machinery (out of scope).
+
+    model = DepthModel(opts)                      # opts: reference options.Options or default_options()
+    outputs = model("test", cur_data, src_data, unbatched_matching_encoder_forward=True, return_mask=True)
+
+The two image encoders (timm EfficientNetV2-S image prior, antialiased ResNet18 matching encoder,
+reference depth_model.py:110-116, networks.py:149-205) are third-party models that are NOT part of
+this hot path (SURVEY.md §8f "next" #1): they are pluggable.  By default the reference's own
+constructors are used when timm / antialiased_cnns are importable; `hot_path()` -- what bench.py
+times -- starts from their outputs.
+"""
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from .cost_volume import CostVolumeManager, FeatureVolumeManager
+from .layers import TensorFormatter
+from .networks import CVEncoder, DepthDecoderPP
+
+
+@dataclass
+class Options:
+    """The subset of the reference's options.Options (options.py:9-216) this path reads."""
+    image_encoder_name: str = "efficientnet"
+    cv_encoder_type: str = "multi_scale_encoder"
+    depth_decoder_name: str = "unet_pp"
+    matching_encoder_type: str = "resnet"
+    feature_volume_type: str = "mlp_feature_volume"   # hero_model.yaml; "simple_cost_volume" = dot_product_model.yaml
+    matching_num_depth_bins: int = 64
+    matching_scale: int = 1
+    matching_feature_dims: int = 16
+    model_num_views: int = 8
+    image_width: int = 512
+    image_height: int = 384
+    min_matching_depth: float = 0.25
+    max_matching_depth: float = 5.0
+    loss_type: str = "log_l1"
+
+
+def default_options(**kw):
+    return Options(**kw)
+
+
+IMAGE_PRIOR_CHANNELS = [24, 48, 64, 160, 256]  # tf_efficientnetv2_s features_only (depth_model.py:110-118)
+
+
+def tensor_B_to_bM(t, batch_size, num_views):
+    return t.view([batch_size, num_views] + list(t.shape[1:]))  # reference generic_utils.py:110-118
+
+
+def tensor_bM_to_B(t):
+    return t.view([t.shape[0] * t.shape[1]] + list(t.shape[2:]))  # reference generic_utils.py:121-130
+
+
+def _reference_image_encoder():
+    try:
+        import timm
+    except ImportError as e:
+        raise ImportError("the image-prior encoder needs `timm` (reference depth_model.py:110-116); pass "
+                          "image_encoder=... to DepthModel to plug in another 5-scale pyramid encoder") from e
+    enc = timm.create_model("tf_efficientnetv2_s_in21ft1k", pretrained=True, features_only=True)
+    enc.num_ch_enc = enc.feature_info.channels()
+    return enc
+
+
+def _reference_matching_encoder(dims):
+    try:
+        import antialiased_cnns  # noqa: F401
+    except ImportError as e:
+        raise ImportError("the matching encoder needs `antialiased_cnns` (reference networks.py:163-174); pass "
+                          "matching_encoder=... to DepthModel to plug in another /4-resolution encoder") from e
+    raise NotImplementedError("construct reference modules.networks.ResnetMatchingEncoder and pass it in")
+
+
+class DepthModel(nn.Module):
+    def __init__(self, opts, image_encoder=None, matching_encoder=None):
+        super().__init__()
+        self.run_opts = opts
+        if image_encoder is None:
+            if "efficientnet" not in opts.image_encoder_name:
+                raise ValueError("Unrecognized option for image encoder type!")
+            image_encoder = _reference_image_encoder()
+        self.encoder = image_encoder
+        num_ch_enc = list(getattr(self.encoder, "num_ch_enc", IMAGE_PRIOR_CHANNELS))
+
+        if opts.cv_encoder_type != "multi_scale_encoder":
+            raise ValueError("Unrecognized option for cost volume encoder type!")
+        self.cost_volume_net = CVEncoder(num_ch_cv=opts.matching_num_depth_bins,
+                                         num_ch_enc=num_ch_enc[opts.matching_scale:],
+                                         num_ch_outs=[64, 128, 256, 384])
+        dec_in = num_ch_enc[:opts.matching_scale] + self.cost_volume_net.num_ch_enc
+        if opts.depth_decoder_name != "unet_pp":
+            raise ValueError("Unrecognized option for depth decoder name!")
+        self.depth_decoder = DepthDecoderPP(dec_in)
+
+        if opts.feature_volume_type == "simple_cost_volume":
+            cost_volume_class = CostVolumeManager
+        elif opts.feature_volume_type == "mlp_feature_volume":
+            cost_volume_class = FeatureVolumeManager
+        else:
+            raise ValueError(f"Unrecognized option {opts.feature_volume_type} for feature volume type!")
+        self.cost_volume = cost_volume_class(
+            matching_height=opts.image_height // (2 ** (opts.matching_scale + 1)),
+            matching_width=opts.image_width // (2 ** (opts.matching_scale + 1)),
+            num_depth_bins=opts.matching_num_depth_bins,
+            matching_dim_size=opts.matching_feature_dims,
+            num_source_views=opts.model_num_views - 1,
+        )
+        # the HIP CVEncoder consumes the volume channels-last: have the sweep write it that way
+        self.cost_volume.volume_memory_format = torch.channels_last
+
+        if matching_encoder is None:
+            if opts.matching_encoder_type not in ("resnet", "unet_encoder"):
+                raise ValueError(f"Unrecognized option {opts.matching_encoder_type} for matching encoder type!")
+            matching_encoder = _reference_matching_encoder(opts.matching_feature_dims)
+        self.matching_model = matching_encoder
+        self.tensor_formatter = TensorFormatter()
+
+    # ---- reference depth_model.py:191-245 ----------------------------------------------------
+    def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward):
+        all_frames = torch.cat([cur_image.unsqueeze(1), src_image], dim=1)
+        batch_size, num_views = all_frames.shape[:2]
+        if unbatched_matching_encoder_forward:
+            feats = torch.cat([self.matching_model(f) for f in tensor_bM_to_B(all_frames).split(1, dim=0)], dim=0)
+            feats = tensor_B_to_bM(feats, batch_size=batch_size, num_views=num_views)
+        else:
+            feats = self.tensor_formatter(all_frames, apply_func=self.matching_model)
+        return feats[:, 0], feats[:, 1:].contiguous()
+
+    # ---- the hot path (reference depth_model.py:358-405) -------------------------------------
+    def hot_path(self, cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam, cur_cam_T_src_cam,
+                 src_K, cur_invK, return_mask=False, flip=False):
+        """Everything between the encoders and the output dict: cost volume -> CVEncoder ->
+        DepthDecoderPP -> exp.  `cur_feats` is the image-prior pyramid (list of 5)."""
+        o = self.run_opts
+        min_depth = torch.tensor(o.min_matching_depth).type_as(src_K).view(1, 1, 1, 1)
+        max_depth = torch.tensor(o.max_matching_depth).type_as(src_K).view(1, 1, 1, 1)
+        cost_volume, lowest_cost, _, overall_mask_bhw = self.cost_volume(
+            cur_feats=matching_cur_feats, src_feats=matching_src_feats, src_extrinsics=src_cam_T_cur_cam,
+            src_poses=cur_cam_T_src_cam, src_Ks=src_K, cur_invK=cur_invK, min_depth=min_depth,
+            max_depth=max_depth, return_mask=return_mask)
+        if flip:
+            cost_volume = torch.flip(cost_volume, (-1,))
+        cost_volume_features = self.cost_volume_net(cost_volume, cur_feats[o.matching_scale:])
+        feats = list(cur_feats[:o.matching_scale]) + cost_volume_features
+        depth_outputs = self.depth_decoder(feats)
+        for k in list(depth_outputs.keys()):
+            log_depth = depth_outputs[k].float()
+            if flip:
+                log_depth = torch.flip(log_depth, (-1,))
+            depth_outputs[k] = log_depth
+            depth_outputs[k.replace("log_", "")] = torch.exp(log_depth)
+        depth_outputs["lowest_cost_bhw"] = lowest_cost
+        depth_outputs["overall_mask_bhw"] = overall_mask_bhw
+        return depth_outputs
+
+    # ---- reference depth_model.py:247-407 ----------------------------------------------------
+    def forward(self, phase, cur_data, src_data, unbatched_matching_encoder_forward=False, return_mask=False):
+        o = self.run_opts
+        cur_image = cur_data["image_b3hw"]
+        src_image = src_data["image_b3hw"]
+        src_K = src_data[f"K_s{o.matching_scale}_b44"]
+        cur_invK = cur_data[f"invK_s{o.matching_scale}_b44"]
+        with torch.autocast("cuda", enabled=False):
+            src_cam_T_cur_cam = src_data["cam_T_world_b44"] @ cur_data["world_T_cam_b44"].unsqueeze(1)
+            cur_cam_T_src_cam = cur_data["cam_T_world_b44"].unsqueeze(1) @ src_data["world_T_cam_b44"]
+        flip = torch.rand(1).item() < (0.5 if phase == "train" else 0.0)
+        if flip:
+            cur_image = torch.flip(cur_image, (-1,))
+            src_image = torch.flip(src_image, (-1,))
+        cur_feats = self.encoder(cur_image)
+        matching_cur_feats, matching_src_feats = self.compute_matching_feats(
+            cur_image, src_image, unbatched_matching_encoder_forward)
+        if flip:
+            matching_cur_feats = torch.flip(matching_cur_feats, (-1,))
+            matching_src_feats = torch.flip(matching_src_feats, (-1,))
+        return self.hot_path(list(cur_feats), matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
+                             cur_cam_T_src_cam, src_K, cur_invK, return_mask=return_mask, flip=flip)
+
+
+class StandInPyramidEncoder(nn.Module):
+    """Shape-compatible stand-in for the image-prior encoder (5 scales, EfficientNetV2-S channel
+    counts) for synthetic runs where timm is unavailable.  NOT the reference's network."""
+
+    def __init__(self, chans=IMAGE_PRIOR_CHANNELS):
+        super().__init__()
+        self.num_ch_enc = list(chans)
+        cin = 3
+        self.stages = nn.ModuleList()
+        for c in chans:
+            self.stages.append(nn.Sequential(nn.Conv2d(cin, c, 3, stride=2, padding=1), nn.SiLU()))
+            cin = c
+
+    def forward(self, x):
+        out = []
+        for s in self.stages:
+            x = s(x)
+            out.append(x)
+        return out
+
+
+class StandInMatchingEncoder(nn.Module):
+    """Shape-compatible stand-in for ResnetMatchingEncoder (image/4 resolution, InstanceNorm'd
+    features).  NOT the reference's network."""
+
+    def __init__(self, dims=16):
+        super().__init__()
+        self.net = nn.Sequential(nn.Conv2d(3, 32, 7, stride=2, padding=3), nn.ReLU(),
+                                 nn.Conv2d(32, dims, 3, stride=2, padding=1), nn.InstanceNorm2d(dims))
+
+    def forward(self, x):
+        return self.net(x)

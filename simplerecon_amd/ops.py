@@ -12,6 +12,10 @@ from torch import nn
 
 from . import _lib
 
+# When set to a list, every conv launch appends (kernel symbol, algorithmic FLOPs, start event, end event):
+# bench.py uses it to time the dominant kernel with HIP events on the launch stream.
+PROFILE = None
+
 _PACKED = weakref.WeakKeyDictionary()  # nn.Conv2d -> (weight version, data_ptr, packed tensor)
 
 
@@ -104,10 +108,20 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
     osb, osp = _strides(out)
     rsb, rsp = _strides(residual) if residual is not None else (0, 0)
     lib = _lib.lib()
+    prof = PROFILE
     with torch.cuda.device(x.device):
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb, rsp,
                                     _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s,
                                     C.c_float(-1.0 if leaky is None else float(leaky)), _lib.stream_ptr(x.device))
+        if prof is not None:
+            ev1.record()
+            nt = 2 if ((co + 31) // 32 * 32) % 64 == 0 else 1
+            v4 = x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0 and ci % 4 == 0
+            prof.append((f"sr_conv_kernel<{k},{s},{2 if s == 1 else 1},{nt},{'true' if v4 else 'false'}>", 2.0 * b * ho * wo * co * ci * k * k,
+                         ev0, ev1, (b, ci, h, w, co, k, s)))
     _lib.check(rc, "sr_conv2d_nhwc_fwd")
     return out
 

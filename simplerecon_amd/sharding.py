@@ -1,0 +1,48 @@
+"""Multi-GPU layout of the hot path: keyframes are independent units (reference
+datasets/generic_mvs_dataset.py:602-661; test.py:257-280 keeps no cross-batch state), so the
+stream is sharded round-robin over ranks -- one process per GPU -- with NO collective on the data
+path.  The only exchange is the gather of the finished depth maps to rank 0 (RCCL over xGMI when
+the backend is "nccl"; "gloo" in the CPU tests), once per run / per chunk, never per frame."""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Keyframe i goes to rank i mod world."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return list(range(rank, n_items, world))
+
+
+def batches(indices: List[int], batch_size: int) -> List[List[int]]:
+    """Splits a rank's keyframes into batches; the last one may be ragged."""
+    return [indices[i:i + batch_size] for i in range(0, len(indices), batch_size)]
+
+
+def gather_results(local: torch.Tensor, n_items: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """`local[j]` is the result of keyframe shard_indices(n_items, rank, world)[j].  Returns, on
+    rank `dst`, the [n_items, ...] tensor in keyframe order; None elsewhere.  One collective:
+    shards are padded to the longest shard so a plain gather works with ragged counts."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (n_items + world - 1) // world
+    if local.shape[0] != len(shard_indices(n_items, rank, world)):
+        raise ValueError(f"rank {rank} holds {local.shape[0]} results, expected "
+                         f"{len(shard_indices(n_items, rank, world))}")
+    if local.shape[0] < per:
+        pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    local = local.contiguous()
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    dist.gather(local, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = shard_indices(n_items, r, world)
+        if idx:
+            out[torch.as_tensor(idx, device=local.device)] = bufs[r][:len(idx)]
+    return out

@@ -1,0 +1,81 @@
+"""End-to-end hot path (DepthModel.hot_path: sweep -> CVEncoder -> DepthDecoderPP -> exp) on the GPU
+against the same chain through the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from parity import assert_close, mismatch_fraction
+from simplerecon_amd import depth_model as dm
+from simplerecon_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("fvt", ["mlp_feature_volume", "simple_cost_volume"])
+def test_hot_path_matches_oracle_chain(fvt):
+    B, K, C, D, h, w = 2, 3, 16, 8, 24, 32
+    opts = dm.default_options(image_width=4 * w, image_height=4 * h, model_num_views=K + 1,
+                              matching_num_depth_bins=D, feature_volume_type=fvt)
+    model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(), matching_encoder=dm.StandInMatchingEncoder())
+    synthetic.seeded_fill_(model.cost_volume_net, seed=1)
+    synthetic.seeded_fill_(model.depth_decoder, seed=2)
+    if fvt == "mlp_feature_volume":
+        synthetic.seeded_fill_(model.cost_volume.mlp, seed=3)
+    model = model.to(DEV).eval()
+    inp = synthetic.cost_volume_inputs(B, K, C, h, w, seed=5)
+    pyr = synthetic.image_prior_pyramid(B, h, w, seed=5)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    with torch.inference_mode():
+        out = model.hot_path([f.to(DEV) for f in pyr], d["cur_feats"], d["src_feats"], d["src_extrinsics"],
+                             d["src_poses"], d["src_Ks"], d["cur_invK"], return_mask=True)
+    torch.cuda.synchronize()
+    n = {k: v.numpy() for k, v in inp.items()}
+    planes = model.cost_volume.generate_depth_planes(B, d["min_depth"], d["max_depth"])[:, :, 0, 0].cpu().numpy()
+    if fvt == "mlp_feature_volume":
+        sd = {k: v.cpu().numpy() for k, v in model.cost_volume.mlp.state_dict().items()}
+        mlp = dict(W1=sd["net.0.weight"], b1=sd["net.0.bias"], W2=sd["net.2.weight"], b2=sd["net.2.bias"],
+                   W3=sd["net.4.weight"], b3=sd["net.4.bias"])
+        vol, low, mask = oracle.mlp_volume(n["cur_feats"], n["src_feats"], n["src_Ks"], n["src_extrinsics"],
+                                           n["src_poses"], n["cur_invK"], planes, mlp, want_mask=True)
+        assert mismatch_fraction(out["overall_mask_bhw"], mask) == 0.0
+    else:
+        vol, low, _ = oracle.dot_volume(n["cur_feats"], n["src_feats"], n["src_Ks"], n["src_extrinsics"],
+                                        n["cur_invK"], planes)
+        assert out["overall_mask_bhw"] is None
+    esd = {k: v.cpu().numpy() for k, v in model.cost_volume_net.state_dict().items()}
+    dsd = {k: v.cpu().numpy() for k, v in model.depth_decoder.state_dict().items()}
+    feats = oracle.cv_encoder(vol, [f.numpy() for f in pyr[1:]], esd)
+    ref = oracle.depth_decoder_pp([pyr[0].numpy()] + feats, dsd)
+    for i in range(4):
+        k = f"log_depth_pred_s{i}_b1hw"
+        assert_close(out[k], ref[k], what=k)
+        assert_close(out[k.replace("log_", "")], np.exp(ref[k]), what="depth " + k)
+    assert out["depth_pred_s0_b1hw"].shape == (B, 1, 2 * h, 2 * w)
+    assert out["lowest_cost_bhw"].shape == (B, h, w)
+
+
+def test_forward_api_with_stand_in_encoders():
+    """DepthModel.forward keeps the reference's call signature and output keys (depth_model.py:247-407)."""
+    B, K, H, W = 1, 2, 96, 128
+    opts = dm.default_options(image_width=W, image_height=H, model_num_views=K + 1, matching_num_depth_bins=8)
+    model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(), matching_encoder=dm.StandInMatchingEncoder())
+    model = model.to(DEV).eval()
+    inp = synthetic.cost_volume_inputs(B, K, 16, H // 4, W // 4, seed=2, device=DEV)
+    eye = torch.eye(4, device=DEV)
+    cur = {"image_b3hw": torch.randn(B, 3, H, W, device=DEV), "invK_s1_b44": inp["cur_invK"],
+           "cam_T_world_b44": eye.expand(B, 4, 4).contiguous(), "world_T_cam_b44": eye.expand(B, 4, 4).contiguous()}
+    src = {"image_b3hw": torch.randn(B, K, 3, H, W, device=DEV), "K_s1_b44": inp["src_Ks"],
+           "cam_T_world_b44": inp["src_extrinsics"], "world_T_cam_b44": inp["src_poses"]}
+    with torch.inference_mode():
+        out = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+    keys = set(out)
+    assert {f"log_depth_pred_s{i}_b1hw" for i in range(4)} <= keys and {f"depth_pred_s{i}_b1hw" for i in range(4)} <= keys
+    assert {"lowest_cost_bhw", "overall_mask_bhw"} <= keys
+    assert out["depth_pred_s0_b1hw"].shape == (B, 1, H // 2, W // 2) and torch.isfinite(out["depth_pred_s0_b1hw"]).all()
+    with pytest.raises(NotImplementedError):
+        with torch.enable_grad():
+            model.hot_path([t.requires_grad_() for t in model.encoder(cur["image_b3hw"])], inp["cur_feats"],
+                           inp["src_feats"].requires_grad_(), inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
+                           inp["cur_invK"])
