@@ -139,10 +139,11 @@ class HeroCfg3:
     B, K, Cc, D, h, w = 8, 7, 16, 64, 120, 160
     feature_volume_type = "mlp_feature_volume"
 
-    def __init__(self, dev, rank, B=None):
+    def __init__(self, dev, rank, B=None, streams=1):
         from simplerecon_amd import depth_model as dm
         if B is not None:
             self.B = B
+        self.streams = streams
         self.dev = dev
         self.frames_per_step = self.B
         opts = dm.default_options(image_width=4 * self.w, image_height=4 * self.h, model_num_views=self.K + 1,
@@ -153,6 +154,7 @@ class HeroCfg3:
         if hasattr(model.cost_volume, "mlp"):
             synthetic.seeded_fill_(model.cost_volume.mlp, seed=3)
         self.model = model.to(dev).eval()
+        self.model.num_streams = streams
         inp = synthetic.cost_volume_inputs(self.B, self.K, self.Cc, self.h, self.w, seed=rank, device=dev)
         self.inp = inp
         self.pyramid = [f.contiguous(memory_format=torch.channels_last) for f in
@@ -179,7 +181,8 @@ class HeroCfg3:
                             f"{self.B}/GPU, {self.K} source views, {self.D} planes, 640x480 image ({self.h}x{self.w} "
                             f"matching features x {self.Cc} ch, image-prior pyramid 24/48/64/160/256 ch), fp32, "
                             f"random-init weights; image/matching encoders (third-party, out of scope) not timed",
-                "frames_per_step_per_gpu": self.B, "parallelism": f"replica x{world} (keyframes sharded)"}
+                "frames_per_step_per_gpu": self.B, "hip_streams_per_gpu": self.streams,
+                "parallelism": f"replica x{world} (keyframes sharded)"}
 
     def _profile_convs(self, n):
         from simplerecon_amd import ops
@@ -305,6 +308,8 @@ class DotFull(HeroCfg3):
 WORKLOADS = {
     "hero_cfg3": lambda dev, rank: HeroCfg3(dev, rank),
     "hero_b1": lambda dev, rank: HeroCfg3(dev, rank, B=1),
+    "hero_cfg3_s2": lambda dev, rank: HeroCfg3(dev, rank, streams=2),
+    "hero_cfg3_s4": lambda dev, rank: HeroCfg3(dev, rank, streams=4),
     "dot_full": lambda dev, rank: DotFull(dev, rank),
     "dot_cfg2": lambda dev, rank: DotCfg2(dev, rank),
     "dot_b8": lambda dev, rank: DotCfg2(dev, rank, B=8),

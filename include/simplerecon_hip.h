@@ -161,6 +161,10 @@ int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stri
                        int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
                        int Cout, int ksize, int stride, float leaky_slope, void* stream);
 
+/* Name of the kernel instantiation sr_conv2d_nhwc_fwd launches for these arguments (tile shape is
+ * chosen per launch); `aligned16` = input pointer / strides are 16-byte aligned.  For profilers. */
+const char* sr_conv_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int aligned16);
+
 /* F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) -- `upsample` of the
  * reference (utils/generic_utils.py:96-105) -- on channels-last data, [B,H,W,C] -> [B,2H,2W,C]. */
 int sr_upsample2x_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out,

@@ -17,6 +17,7 @@
 //     (one coalesced 1 KiB read per wave feeds 4 k-steps x MT M-tiles); they never occupy LDS.
 //   * Epilogue in registers: + bias, + residual (identity or projected skip), LeakyReLU, and the
 //     store goes directly into a channel slice of the consumer's concat buffer.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sr_common.h"
@@ -25,7 +26,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SR_CK 16        // input channels per LDS slab
 #define SR_LDS_ROW 20   // floats per staged pixel (16 + 4 pad)
-#define SR_TW 32        // output columns per workgroup tile (= one 32-row MFMA M-tile per row)
 
 struct SrConvParams {
   const float* in; int64_t in_sb; int in_sp;        // batch stride, pixel stride (elements)
@@ -42,11 +42,15 @@ struct SrConvParams {
 
 // Stages global -> registers (issued before the MFMA phase of the previous slab) -> LDS (after it):
 // the HBM/L2 latency of the next slab hides under the current slab's MFMAs (double-buffered tile).
-template <int KS, int S, int MT>
+// An M-tile (the 32 rows of one MFMA) is RM x CM output pixels (RM * CM = 32): 1 x 32 for wide maps,
+// 4 x 8 for the low-resolution pyramid levels (less padding waste at widths 20 / 40).  A workgroup
+// (4 waves x MT M-tiles) covers TH = 4*MT*RM rows x CM columns.
+template <int KS, int S, int MT, int CM>
 struct SrConvGeom {
-  static constexpr int TH = 4 * MT;
+  static constexpr int RM = 32 / CM;
+  static constexpr int TH = 4 * MT * RM;
   static constexpr int HH = (TH - 1) * S + KS;
-  static constexpr int HW = (SR_TW - 1) * S + KS;
+  static constexpr int HW = (CM - 1) * S + KS;
   static constexpr int ELEMS = HH * HW * 4;            // float4 elements per slab
   static constexpr int PER_THREAD = (ELEMS + 255) / 256;
   static constexpr int TILE_FLOATS = HH * HW * SR_LDS_ROW;
@@ -54,10 +58,10 @@ struct SrConvGeom {
 
 // Per-thread element offsets (in floats, relative to the image base; -1 = outside the image) of the
 // slab elements this thread stages; fixed for a tile, so the per-slab work is one add + one load each.
-template <int KS, int S, int MT>
+template <int KS, int S, int MT, int CM>
 __device__ __forceinline__ void sr_conv_stage_setup(const SrConvParams& p, int iy0, int ix0,
-                                                    int (&offs)[SrConvGeom<KS, S, MT>::PER_THREAD]) {
-  using G = SrConvGeom<KS, S, MT>;
+                                                    int (&offs)[SrConvGeom<KS, S, MT, CM>::PER_THREAD]) {
+  using G = SrConvGeom<KS, S, MT, CM>;
 #pragma unroll
   for (int it = 0; it < G::PER_THREAD; ++it) {
     const int e = threadIdx.x + it * 256;
@@ -71,11 +75,11 @@ __device__ __forceinline__ void sr_conv_stage_setup(const SrConvParams& p, int i
 
 // VEC4 = true: rows are 16-byte aligned and Cin % 4 == 0 -> branch-free: every lane issues exactly one
 // 16-byte load per element (out-of-image / out-of-range lanes read element 0 and are masked to zero).
-template <int KS, int S, int MT, bool VEC4>
+template <int KS, int S, int MT, int CM, bool VEC4>
 __device__ __forceinline__ void sr_conv_stage_load(const SrConvParams& p, const float* __restrict__ in_b, int c0,
-                                                   const int (&offs)[SrConvGeom<KS, S, MT>::PER_THREAD],
-                                                   float4 (&stg)[SrConvGeom<KS, S, MT>::PER_THREAD]) {
-  using G = SrConvGeom<KS, S, MT>;
+                                                   const int (&offs)[SrConvGeom<KS, S, MT, CM>::PER_THREAD],
+                                                   float4 (&stg)[SrConvGeom<KS, S, MT, CM>::PER_THREAD]) {
+  using G = SrConvGeom<KS, S, MT, CM>;
 #pragma unroll
   for (int it = 0; it < G::PER_THREAD; ++it) {
     const int c = c0 + 4 * ((threadIdx.x + it * 256) & 3);
@@ -97,10 +101,10 @@ __device__ __forceinline__ void sr_conv_stage_load(const SrConvParams& p, const 
   }
 }
 
-template <int KS, int S, int MT>
+template <int KS, int S, int MT, int CM>
 __device__ __forceinline__ void sr_conv_stage_store(float* __restrict__ tile,
-                                                    const float4 (&stg)[SrConvGeom<KS, S, MT>::PER_THREAD]) {
-  using G = SrConvGeom<KS, S, MT>;
+                                                    const float4 (&stg)[SrConvGeom<KS, S, MT, CM>::PER_THREAD]) {
+  using G = SrConvGeom<KS, S, MT, CM>;
 #pragma unroll
   for (int it = 0; it < G::PER_THREAD; ++it) {
     const int e = threadIdx.x + it * 256;
@@ -110,7 +114,7 @@ __device__ __forceinline__ void sr_conv_stage_store(float* __restrict__ tile,
 
 struct SrTileCoord { int b, co0, oy0, ox0; };
 
-template <int TH, int NT>
+template <int TH, int NT, int CM>
 __device__ __forceinline__ SrTileCoord sr_conv_tile(const SrConvParams& p, int work) {
   // work = ((b * co_blocks + cb) * tiles_y + ty) * tiles_x + tx
   SrTileCoord t;
@@ -120,17 +124,17 @@ __device__ __forceinline__ SrTileCoord sr_conv_tile(const SrConvParams& p, int w
   t.b = work / p.co_blocks;
   t.co0 = cb * (32 * NT);
   t.oy0 = ty * TH;
-  t.ox0 = tx * SR_TW;
+  t.ox0 = tx * CM;
   return t;
 }
 
 // Persistent workgroups: each loops over output tiles, and the (tile, slab) sequence is ONE software
 // pipeline -- the first slab of the next tile is fetched during the last slab of the current one and
 // the epilogue stores drain while the next tile's MFMAs run, so there is no per-tile fill/drain.
-template <int KS, int S, int MT, int NT, bool VEC4>
+template <int KS, int S, int MT, int NT, int CM, bool VEC4>
 __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
-  using G = SrConvGeom<KS, S, MT>;
-  constexpr int TH = G::TH, HW = G::HW;
+  using G = SrConvGeom<KS, S, MT, CM>;
+  constexpr int TH = G::TH, HW = G::HW, RM = G::RM;
   constexpr int PAD = KS / 2;
   constexpr int STEPS = KS * KS * 2;  // (tap, 8-channel group) steps per 16-channel slab
   __shared__ __attribute__((aligned(16))) float tiles[2][G::TILE_FLOATS];
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
 
   int a_off[MT];  // this lane's A-fragment base inside the halo tile (M-tile m = output row wave*MT + m)
 #pragma unroll
-  for (int m = 0; m < MT; ++m) a_off[m] = (((wave * MT + m) * S) * HW + i * S) * SR_LDS_ROW + 4 * kk;
+  for (int m = 0; m < MT; ++m)
+    a_off[m] = ((((wave * MT + m) * RM + i / CM) * S) * HW + (i % CM) * S) * SR_LDS_ROW + 4 * kk;
   const int64_t rec = (int64_t)2 * p.Co_pad;  // float4 per (tap, g) weight record
   const int chunks = p.G >> 1;
 
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
 
   int work = blockIdx.x;
   if (work >= p.total_tiles) return;
-  SrTileCoord t = sr_conv_tile<TH, NT>(p, work);
+  SrTileCoord t = sr_conv_tile<TH, NT, CM>(p, work);
   const float4* wp4 = reinterpret_cast<const float4*>(p.wp) + (kk * p.Co_pad + t.co0 + i);
   auto load_b = [&](const float4* base, int ch, int s, float4 (&dst)[NT]) {
     const int tap = s >> 1, g = s & 1;
@@ -165,9 +170,9 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
     for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
   };
 
-  sr_conv_stage_setup<KS, S, MT>(p, t.oy0 * S - PAD, t.ox0 * S - PAD, offs);
-  sr_conv_stage_load<KS, S, MT, VEC4>(p, p.in + (int64_t)t.b * p.in_sb, 0, offs, stg);
-  sr_conv_stage_store<KS, S, MT>(tiles[0], stg);
+  sr_conv_stage_setup<KS, S, MT, CM>(p, t.oy0 * S - PAD, t.ox0 * S - PAD, offs);
+  sr_conv_stage_load<KS, S, MT, CM, VEC4>(p, p.in + (int64_t)t.b * p.in_sb, 0, offs, stg);
+  sr_conv_stage_store<KS, S, MT, CM>(tiles[0], stg);
 #pragma unroll
   for (int s = 0; s < PD; ++s) load_b(wp4, 0, s, b_f[s]);
   __syncthreads();
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
     const int next_work = work + gridDim.x;
     const bool have_next = next_work < p.total_tiles;
     SrTileCoord tn = t;
-    if (have_next) tn = sr_conv_tile<TH, NT>(p, next_work);
+    if (have_next) tn = sr_conv_tile<TH, NT, CM>(p, next_work);
     const float4* wp4n = reinterpret_cast<const float4*>(p.wp) + (kk * p.Co_pad + tn.co0 + i);
 
     f32x16 acc[MT][NT];
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
       const bool last = ch + 1 == chunks;
       const bool more = !last || have_next;        // is there a following slab in the pipeline?
       if (more) {
-        if (last) sr_conv_stage_setup<KS, S, MT>(p, tn.oy0 * S - PAD, tn.ox0 * S - PAD, offs);  // next tile
-        sr_conv_stage_load<KS, S, MT, VEC4>(p, p.in + (int64_t)(last ? tn.b : t.b) * p.in_sb,
+        if (last) sr_conv_stage_setup<KS, S, MT, CM>(p, tn.oy0 * S - PAD, tn.ox0 * S - PAD, offs);  // next tile
+        sr_conv_stage_load<KS, S, MT, CM, VEC4>(p, p.in + (int64_t)(last ? tn.b : t.b) * p.in_sb,
                                             last ? 0 : (ch + 1) * SR_CK, offs, stg);
       }
       const float4* wnext = last ? wp4n : wp4;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (more) sr_conv_stage_store<KS, S, MT>(tiles[buf ^ 1], stg);
+      if (more) sr_conv_stage_store<KS, S, MT, CM>(tiles[buf ^ 1], stg);
       __syncthreads();
       buf ^= 1;
     }
@@ -239,24 +244,28 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
       float* __restrict__ outp = p.out + (int64_t)t.b * p.out_sb;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int oy = t.oy0 + wave * MT + m;
+        const int oyb = t.oy0 + (wave * MT + m) * RM;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int co = t.co0 + 32 * n + i;
-          const bool okc = (oy < p.Ho) && (co < p.Cout);
+          const bool okc = co < p.Cout;
           const float bv = (p.bias && okc) ? p.bias[co] : 0.0f;
           float rv[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int ox = t.ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            rv[r] = (resp && okc && ox < p.Wo && !(p.debug & 2)) ? resp[((int64_t)oy * p.Wo + ox) * p.res_sp + co] : 0.0f;
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * kk;  // pixel index inside the M-tile (C row)
+            const int oy = oyb + j / CM, ox = t.ox0 + j % CM;
+            rv[r] = (resp && okc && oy < p.Ho && ox < p.Wo && !(p.debug & 2))
+                        ? resp[((int64_t)oy * p.Wo + ox) * p.res_sp + co] : 0.0f;
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int ox = t.ox0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int oy = oyb + j / CM, ox = t.ox0 + j % CM;
             float v = acc[m][n][r] + bv + rv[r];
             if (p.slope >= 0.0f) v = v > 0.0f ? v : v * p.slope;
-            if (okc && ox < p.Wo && (!(p.debug & 1) || v == 1.2345e33f)) outp[((int64_t)oy * p.Wo + ox) * p.out_sp + co] = v;
+            if (okc && oy < p.Ho && ox < p.Wo && (!(p.debug & 1) || v == 1.2345e33f))
+              outp[((int64_t)oy * p.Wo + ox) * p.out_sp + co] = v;
           }
         }
       }
@@ -353,27 +362,45 @@ static int sr_num_cus() {
   return cus;
 }
 
-template <int KS, int S, int MT>
-static int sr_conv_dispatch_nt(SrConvParams& p, int B, hipStream_t stream) {
-  const int TH = 4 * MT;
-  p.tiles_y = (p.Ho + TH - 1) / TH;
+template <int KS, int S, int MT, int CM>
+static int sr_conv_launch(SrConvParams& p, int B, hipStream_t stream) {
+  using G = SrConvGeom<KS, S, MT, CM>;
+  p.tiles_x = (p.Wo + CM - 1) / CM;
+  p.tiles_y = (p.Ho + G::TH - 1) / G::TH;
   const int nt = (p.Co_pad % 64 == 0) ? 2 : 1;
   p.co_blocks = p.Co_pad / (32 * nt);
   p.total_tiles = p.tiles_x * p.tiles_y * p.co_blocks * B;
-  // persistent grid: as many workgroups as can be co-resident (LDS / register limited)
-  const int lds = 2 * SrConvGeom<KS, S, MT>::TILE_FLOATS * (int)sizeof(float);
-  int per_cu = (160 * 1024) / lds;
-  if (per_cu > 2) per_cu = 2;
-  if (per_cu < 1) per_cu = 1;
-  int blocks = sr_num_cus() * per_cu;
+  int blocks = sr_num_cus() * 2;  // persistent grid: 2 workgroups per CU (register / LDS limit)
   if (blocks > p.total_tiles) blocks = p.total_tiles;
   dim3 grid(blocks), block(256);
   const bool v4 = p.vec4 && (p.Cin % 4 == 0);
-  if (nt == 2 && v4) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 2, true>), grid, block, 0, stream, p);
-  else if (nt == 2) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 2, false>), grid, block, 0, stream, p);
-  else if (v4) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 1, true>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 1, false>), grid, block, 0, stream, p);
+  if (nt == 2 && v4) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 2, CM, true>), grid, block, 0, stream, p);
+  else if (nt == 2) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 2, CM, false>), grid, block, 0, stream, p);
+  else if (v4) hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 1, CM, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((sr_conv_kernel<KS, S, MT, 1, CM, false>), grid, block, 0, stream, p);
   return sr_hip_rc(hipGetLastError());
+}
+
+// Tile-shape choice: minimise  rounds(tiles / resident workgroups) x MFMA work per tile  (padding waste
+// and tail quantisation both show up in it).  Candidates: (MT=2, CM=32) 8x32, (MT=1, CM=32) 4x32,
+// (MT=1, CM=8) 16x8 output pixels per workgroup.
+static int sr_conv_pick(const SrConvParams& p, int B, int stride) {
+  const int slots = sr_num_cus() * 2;
+  const int nt = (p.Co_pad % 64 == 0) ? 2 : 1;
+  const int cob = p.Co_pad / (32 * nt);
+  const int th[3] = {8, 4, 16}, tw[3] = {32, 32, 8}, mt[3] = {2, 1, 1};
+  int best = -1;
+  double best_cost = 0;
+  for (int c = 0; c < 3; ++c) {
+    if (stride == 2 && c == 0) continue;  // the 8x32 stride-2 halo does not fit LDS twice
+    const long tiles = (long)((p.Wo + tw[c] - 1) / tw[c]) * ((p.Ho + th[c] - 1) / th[c]) * cob * B;
+    const long rounds = (tiles + slots - 1) / slots;
+    // per-tile cost ~ MFMA work (mt); measured: a 4x32 tile costs 0.43x an 8x32 tile, so ties go to
+    // the smaller tile (finer tail)
+    const double cost = (double)rounds * (mt[c] == 2 ? 2.0 : 0.86);
+    if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
+  }
+  return best;
 }
 
 extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
@@ -396,15 +423,47 @@ extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int 
   p.Wo = (W + 2 * pad - ksize) / stride + 1;
   p.Co_pad = ((Cout + 31) / 32) * 32;
   p.G = ((Cin + SR_CK - 1) / SR_CK) * 2;
-  p.tiles_x = (p.Wo + SR_TW - 1) / SR_TW;
   p.slope = leaky_slope;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0);
   hipStream_t stream = (hipStream_t)stream_;
-  if (ksize == 3 && stride == 1) return sr_conv_dispatch_nt<3, 1, 2>(p, B, stream);
-  if (ksize == 3 && stride == 2) return sr_conv_dispatch_nt<3, 2, 1>(p, B, stream);
-  if (ksize == 1 && stride == 1) return sr_conv_dispatch_nt<1, 1, 2>(p, B, stream);
-  return sr_conv_dispatch_nt<1, 2, 1>(p, B, stream);
+  int cfg = sr_conv_pick(p, B, stride);
+  { static int force = -2; if (force == -2) { const char* e = getenv("SR_CONV_TILE"); force = e ? atoi(e) : -1; }
+    if (force >= 0 && !(stride == 2 && force == 0)) cfg = force; }
+  if (ksize == 3 && stride == 1) {
+    if (cfg == 0) return sr_conv_launch<3, 1, 2, 32>(p, B, stream);
+    if (cfg == 1) return sr_conv_launch<3, 1, 1, 32>(p, B, stream);
+    return sr_conv_launch<3, 1, 1, 8>(p, B, stream);
+  }
+  if (ksize == 3 && stride == 2) {
+    if (cfg == 1) return sr_conv_launch<3, 2, 1, 32>(p, B, stream);
+    return sr_conv_launch<3, 2, 1, 8>(p, B, stream);
+  }
+  if (ksize == 1 && stride == 1) {
+    if (cfg == 0) return sr_conv_launch<1, 1, 2, 32>(p, B, stream);
+    if (cfg == 1) return sr_conv_launch<1, 1, 1, 32>(p, B, stream);
+    return sr_conv_launch<1, 1, 1, 8>(p, B, stream);
+  }
+  if (cfg == 1) return sr_conv_launch<1, 2, 1, 32>(p, B, stream);
+  return sr_conv_launch<1, 2, 1, 8>(p, B, stream);
+}
+
+// Symbol of the kernel instantiation sr_conv2d_nhwc_fwd picks for these arguments (for profilers / bench).
+extern "C" const char* sr_conv_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                           int aligned16) {
+  static thread_local char buf[96];
+  SrConvParams p;
+  const int pad = ksize / 2;
+  p.Ho = (H + 2 * pad - ksize) / stride + 1;
+  p.Wo = (W + 2 * pad - ksize) / stride + 1;
+  p.Co_pad = ((Cout + 31) / 32) * 32;
+  int cfg = sr_conv_pick(p, B, stride);
+  { const char* e = getenv("SR_CONV_TILE"); const int force = e ? atoi(e) : -1;
+    if (force >= 0 && !(stride == 2 && force == 0)) cfg = force; }
+  const int mt = cfg == 0 ? 2 : 1, cm = cfg == 2 ? 8 : 32, nt = (p.Co_pad % 64 == 0) ? 2 : 1;
+  snprintf(buf, sizeof(buf), "sr_conv_kernel<%d, %d, %d, %d, %d, %s>", ksize, stride, mt, nt, cm,
+           (aligned16 && Cin % 4 == 0) ? "true" : "false");
+  return buf;
 }
 
 extern "C" int sr_upsample2x_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out,

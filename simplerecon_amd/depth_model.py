@@ -118,6 +118,10 @@ class DepthModel(nn.Module):
             matching_encoder = _reference_matching_encoder(opts.matching_feature_dims)
         self.matching_model = matching_encoder
         self.tensor_formatter = TensorFormatter()
+        # Keyframes of a batch are independent: hot_path() can run `num_streams` sub-batches on separate
+        # HIP streams so that one sub-batch's kernel tails / launch gaps are filled by the other's work.
+        self.num_streams = 1
+        self._streams = {}
 
     # ---- reference depth_model.py:191-245 ----------------------------------------------------
     def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward):
@@ -135,6 +139,43 @@ class DepthModel(nn.Module):
                  src_K, cur_invK, return_mask=False, flip=False):
         """Everything between the encoders and the output dict: cost volume -> CVEncoder ->
         DepthDecoderPP -> exp.  `cur_feats` is the image-prior pyramid (list of 5)."""
+        b = matching_cur_feats.shape[0]
+        n = min(self.num_streams, b)
+        if n <= 1:
+            return self._hot_path_one(cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
+                                      cur_cam_T_src_cam, src_K, cur_invK, return_mask, flip)
+        dev = matching_cur_feats.device
+        streams = self._streams.get(dev)
+        if streams is None or len(streams) < n:
+            streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+            self._streams[dev] = streams
+        main = torch.cuda.current_stream(dev)
+        bounds = [(b * i) // n for i in range(n + 1)]
+        parts = []
+        for i in range(n):
+            lo, hi = bounds[i], bounds[i + 1]
+            st = streams[i]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                parts.append(self._hot_path_one([f[lo:hi] for f in cur_feats], matching_cur_feats[lo:hi],
+                                                matching_src_feats[lo:hi], src_cam_T_cur_cam[lo:hi],
+                                                cur_cam_T_src_cam[lo:hi], src_K[lo:hi], cur_invK[lo:hi],
+                                                return_mask, flip))
+        for st in streams[:n]:
+            main.wait_stream(st)
+        out = {}
+        for k in parts[0]:
+            vals = [p[k] for p in parts]
+            if vals[0] is None:
+                out[k] = None
+            else:
+                for v in vals:
+                    v.record_stream(main)
+                out[k] = torch.cat(vals, 0)
+        return out
+
+    def _hot_path_one(self, cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam, cur_cam_T_src_cam,
+                      src_K, cur_invK, return_mask=False, flip=False):
         o = self.run_opts
         min_depth = torch.tensor(o.min_matching_depth).type_as(src_K).view(1, 1, 1, 1)
         max_depth = torch.tensor(o.max_matching_depth).type_as(src_K).view(1, 1, 1, 1)

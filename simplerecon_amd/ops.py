@@ -118,10 +118,9 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
                                     C.c_float(-1.0 if leaky is None else float(leaky)), _lib.stream_ptr(x.device))
         if prof is not None:
             ev1.record()
-            nt = 2 if ((co + 31) // 32 * 32) % 64 == 0 else 1
-            v4 = x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0 and ci % 4 == 0
-            prof.append((f"sr_conv_kernel<{k},{s},{2 if s == 1 else 1},{nt},{'true' if v4 else 'false'}>", 2.0 * b * ho * wo * co * ci * k * k,
-                         ev0, ev1, (b, ci, h, w, co, k, s)))
+            v4 = int(x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0)
+            name = lib.sr_conv_kernel_name(b, h, w, ci, co, k, s, v4).decode()
+            prof.append((name, 2.0 * b * ho * wo * co * ci * k * k, ev0, ev1, (b, ci, h, w, co, k, s)))
     _lib.check(rc, "sr_conv2d_nhwc_fwd")
     return out
 
