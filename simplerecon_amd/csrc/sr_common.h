@@ -61,13 +61,15 @@ __device__ __forceinline__ void sr_project_sample(const float* __restrict__ g /*
   const float fx0 = floorf(ix), fy0 = floorf(iy);
   const float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
   const float wm = (float)(w - 1), hm = (float)(h - 1);
-  const bool vx0 = (fx0 >= 0.0f) && (fx0 <= wm), vx1 = (fx1 >= 0.0f) && (fx1 <= wm);
-  const bool vy0 = (fy0 >= 0.0f) && (fy0 <= hm), vy1 = (fy1 >= 0.0f) && (fy1 <= hm);
+  // (bitwise & on purpose: short-circuit && makes hipcc emit divergent branches that split the
+  // scheduling region the callers want to interleave with MFMAs)
+  const bool vx0 = (fx0 >= 0.0f) & (fx0 <= wm), vx1 = (fx1 >= 0.0f) & (fx1 <= wm);
+  const bool vy0 = (fy0 >= 0.0f) & (fy0 <= hm), vy1 = (fy1 >= 0.0f) & (fy1 <= hm);
   const float ax1 = fx1 - ix, ax0 = ix - fx0, ay1 = fy1 - iy, ay0 = iy - fy0;
-  s.w_nw = (vx0 && vy0) ? ax1 * ay1 : 0.0f;
-  s.w_ne = (vx1 && vy0) ? ax0 * ay1 : 0.0f;
-  s.w_sw = (vx0 && vy1) ? ax1 * ay0 : 0.0f;
-  s.w_se = (vx1 && vy1) ? ax0 * ay0 : 0.0f;
+  s.w_nw = (vx0 & vy0) ? ax1 * ay1 : 0.0f;
+  s.w_ne = (vx1 & vy0) ? ax0 * ay1 : 0.0f;
+  s.w_sw = (vx0 & vy1) ? ax1 * ay0 : 0.0f;
+  s.w_se = (vx1 & vy1) ? ax0 * ay0 : 0.0f;
   // clamp (NaN-safe: fmaxf(NaN, 0) = 0) so every tap address is in-image; weight 0 kills it
   const int x0 = (int)fminf(fmaxf(fx0, 0.0f), wm), x1 = (int)fminf(fmaxf(fx1, 0.0f), wm);
   const int y0 = (int)fminf(fmaxf(fy0, 0.0f), hm), y1 = (int)fminf(fmaxf(fy1, 0.0f), hm);
@@ -79,7 +81,7 @@ __device__ __forceinline__ void sr_project_sample(const float* __restrict__ g /*
 
 // bounds test of get_mask (cost_volume.py:77-97)
 __device__ __forceinline__ bool sr_in_bounds(const SrSample& s, int h, int w) {
-  return (s.pix_x > 2.0f) && (s.pix_x < (float)(w - 2)) && (s.pix_y > 2.0f) && (s.pix_y < (float)(h - 2));
+  return (s.pix_x > 2.0f) & (s.pix_x < (float)(w - 2)) & (s.pix_y > 2.0f) & (s.pix_y < (float)(h - 2));
 }
 
 // workspace carving: [geom records | channels-last source features]

@@ -236,36 +236,61 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
       buf ^= 1;
     }
 
-    // ---- epilogue of tile t: C[row = pixel column, col = output channel] ----
-    // The residual loads of a whole 32x32 fragment are issued back to back BEFORE any store (out and
-    // residual may alias in the type system; interleaving them would serialise on memory latency).
+    // ---- epilogue of tile t: C[row = pixel j of the M-tile, col = output channel] ----
+    // j = (r&3) + 8*(r>>2) + 4*kk  ->  M-tile row (8*(r>>2))/CM, column (8*(r>>2))%CM + (r&3) + 4*kk: only the
+    // 4*kk part is per lane, the rest folds to immediates.  32-bit element offsets off one scalar base per
+    // tensor; all residual loads of a fragment are issued before its stores (out / residual may alias).
     {
       const float* __restrict__ resp = p.res ? p.res + (int64_t)t.b * p.res_sb : nullptr;
       float* __restrict__ outp = p.out + (int64_t)t.b * p.out_sb;
+      const int osp = p.out_sp, rsp = p.res_sp;
+      const bool no_res = (resp == nullptr) || (p.debug & 2);
+      // interior tiles (workgroup-uniform test) take a branch-free path
+      const bool full = (t.oy0 + TH <= p.Ho) && (t.ox0 + CM <= p.Wo) && (t.co0 + 32 * NT <= p.Cout) && !(p.debug & 1);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int oyb = t.oy0 + (wave * MT + m) * RM;
+        const int pixb = oyb * p.Wo + t.ox0 + 4 * kk;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int co = t.co0 + 32 * n + i;
           const bool okc = co < p.Cout;
           const float bv = (p.bias && okc) ? p.bias[co] : 0.0f;
+          const unsigned ob = (unsigned)(pixb * osp + co), rb = (unsigned)(pixb * rsp + co);
           float rv[16];
+          if (full) {
+            if (!no_res) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int j = (r & 3) + 8 * (r >> 2) + 4 * kk;  // pixel index inside the M-tile (C row)
-            const int oy = oyb + j / CM, ox = t.ox0 + j % CM;
-            rv[r] = (resp && okc && oy < p.Ho && ox < p.Wo && !(p.debug & 2))
-                        ? resp[((int64_t)oy * p.Wo + ox) * p.res_sp + co] : 0.0f;
-          }
+              for (int r = 0; r < 16; ++r) {
+                const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
+                rv[r] = resp[rb + (unsigned)((row * p.Wo + colc) * rsp)];
+              }
+            } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int j = (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const int oy = oyb + j / CM, ox = t.ox0 + j % CM;
-            float v = acc[m][n][r] + bv + rv[r];
-            if (p.slope >= 0.0f) v = v > 0.0f ? v : v * p.slope;
-            if (okc && oy < p.Ho && ox < p.Wo && (!(p.debug & 1) || v == 1.2345e33f))
-              outp[((int64_t)oy * p.Wo + ox) * p.out_sp + co] = v;
+              for (int r = 0; r < 16; ++r) rv[r] = 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
+              float v = acc[m][n][r] + bv + rv[r];
+              if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
+              outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
+            }
+          } else {
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
+              ok[r] = okc && (oyb + row < p.Ho) && (t.ox0 + colc + 4 * kk < p.Wo);
+              rv[r] = (!no_res && ok[r]) ? resp[rb + (unsigned)((row * p.Wo + colc) * rsp)] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
+              float v = acc[m][n][r] + bv + rv[r];
+              if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
+              if (ok[r] && (!(p.debug & 1) || v == 1.2345e33f)) outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
+            }
           }
         }
       }

@@ -121,7 +121,15 @@ __global__ __launch_bounds__(1024) void sr_dot_volume_kernel(SrDotParams p) {
   const int S = blockDim.x >> 6;
   const int b = blockIdx.y;
   const int N = p.h * p.w;
-  const int pix = blockIdx.x * 64 + lane;
+  // XCD-aware tile order: workgroup id % 8 selects the XCD (observed dispatch order; speed only, never
+  // correctness), so give each XCD a CONTIGUOUS band of pixel tiles -- its private L2 then holds one band
+  // (plus the disparity range) of every source map instead of all of them.  Bijective for any grid size.
+  int tile = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int pix = tile * 64 + lane;
   const bool active = pix < N;
   const int pc = active ? pix : N - 1;
   const int y = pc / p.w, x = pc - y * p.w;

@@ -198,50 +198,112 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
     const float* src_b = p.src_nhwc + (size_t)b * p.K * N * C;
     bool any_depth = false, any_bounds = false;
 
-#pragma unroll 1
-    for (int k = 0; k < p.K; ++k) {
-      const float* g = geom_b + k * SR_GEOM_STRIDE;
-      SrSample s;
-      sr_project_sample(g, X0, X1, X2, p.h, p.w, p.inv_w, p.inv_h, s);
+    // ---- layer 1, software-pipelined over views: the feature vector of view k+1 is assembled in 13 small
+    // VALU pieces, each placed in the shadow of one k-step (8 MFMAs = 512 cycles) of view k; its 16 tap
+    // loads are issued before step 0 and first touched at step 3.  sched_barrier(0) pins the placement.
+    SrSample smp;
+    float4 taps[16];
+    float f[SR_VIEW_SLOTS], fn[SR_VIEW_SLOTS];
+    float crn0, crn1, crn2;  // cur_ray / max(|cur_ray|, 1e-5)  (cosine_similarity's first operand)
+    {
+#pragma clang fp contract(off)
+      crn0 = cr0 / n1; crn1 = cr1 / n1; crn2 = cr2 / n1;
+    }
+    auto issue_view = [&](int k) {
+      sr_project_sample(geom_b + k * SR_GEOM_STRIDE, X0, X1, X2, p.h, p.w, p.inv_w, p.inv_h, smp);
       const float* img = src_b + (size_t)k * N * C;
-      const float4* t_nw = reinterpret_cast<const float4*>(img + (size_t)s.o_nw * C);
-      const float4* t_ne = reinterpret_cast<const float4*>(img + (size_t)s.o_ne * C);
-      const float4* t_sw = reinterpret_cast<const float4*>(img + (size_t)s.o_sw * C);
-      const float4* t_se = reinterpret_cast<const float4*>(img + (size_t)s.o_se * C);
-      float f[SR_VIEW_SLOTS];
+      const float4* t_nw = reinterpret_cast<const float4*>(img + (size_t)smp.o_nw * C);
+      const float4* t_ne = reinterpret_cast<const float4*>(img + (size_t)smp.o_ne * C);
+      const float4* t_sw = reinterpret_cast<const float4*>(img + (size_t)smp.o_sw * C);
+      const float4* t_se = reinterpret_cast<const float4*>(img + (size_t)smp.o_se * C);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float4 a = t_nw[i], bq = t_ne[i], c4 = t_sw[i], d4 = t_se[i];
-        f[4 * i + 0] = fmaf(s.w_se, d4.x, fmaf(s.w_sw, c4.x, fmaf(s.w_ne, bq.x, s.w_nw * a.x)));
-        f[4 * i + 1] = fmaf(s.w_se, d4.y, fmaf(s.w_sw, c4.y, fmaf(s.w_ne, bq.y, s.w_nw * a.y)));
-        f[4 * i + 2] = fmaf(s.w_se, d4.z, fmaf(s.w_sw, c4.z, fmaf(s.w_ne, bq.z, s.w_nw * a.z)));
-        f[4 * i + 3] = fmaf(s.w_se, d4.w, fmaf(s.w_sw, c4.w, fmaf(s.w_ne, bq.w, s.w_nw * a.w)));
+        taps[i] = t_nw[i]; taps[4 + i] = t_ne[i]; taps[8 + i] = t_sw[i]; taps[12 + i] = t_se[i];
       }
-      float dot = 0.0f;
-#pragma unroll
-      for (int c = 0; c < C; ++c) dot = fmaf(f[c], cur[c], dot);
-      const bool front = s.zp > 0.0f;
-      any_depth |= front;
-      any_bounds |= sr_in_bounds(s, p.h, p.w);
-      f[16] = front ? 1.0f : 0.0f;  // mask        (cost_volume.py:611-612)
-      f[17] = s.zp;                 // z'_k        (cost_volume.py:603-609)
-      f[18] = front ? dot : 0.0f;   // dot * mask  (cost_volume.py:691-695)
-      {
-#pragma clang fp contract(off)
-        // source ray: normalize(X - t_k) (cost_volume.py:654-669, geometry_utils.py:169-173)
-        const float v0 = X0 - g[12], v1 = X1 - g[13], v2 = X2 - g[14];
-        const float sn = sqrtf((v0 * v0 + v1 * v1) + v2 * v2);
-        const float sden = fmaxf(sn, 1e-12f);
-        const float s0 = v0 / sden, s1 = v1 / sden, s2 = v2 / sden;
-        // F.cosine_similarity(cur_ray, src_ray, eps=1e-5) (cost_volume.py:683-688)
-        const float n2 = fmaxf(sqrtf((s0 * s0 + s1 * s1) + s2 * s2), 1e-5f);
-        f[19] = ((cr0 / n1) * (s0 / n2) + (cr1 / n1) * (s1 / n2)) + (cr2 / n1) * (s2 / n2);
-        f[20] = s0; f[21] = s1; f[22] = s2;
-      }
-      f[23] = g[15]; f[24] = g[16]; f[25] = g[17];  // pose_dist, R_measure, t_measure
+    };
+    // pieces of the feature assembly (o = fn or f).  Ray pieces need no taps.
+    float rv0, rv1, rv2, rsd, rdot;
+#define SR_RAY_A(o, g)                                                                        \
+    {                                                                                         \
+      _Pragma("clang fp contract(off)")                                                       \
+      rv0 = X0 - (g)[12]; rv1 = X1 - (g)[13]; rv2 = X2 - (g)[14];                              \
+      rsd = fmaxf(sqrtf((rv0 * rv0 + rv1 * rv1) + rv2 * rv2), 1e-12f);                         \
+      (o)[23] = (g)[15]; (o)[24] = (g)[16]; (o)[25] = (g)[17];                                 \
+    }
+#define SR_RAY_B(o)                                                                           \
+    {                                                                                         \
+      _Pragma("clang fp contract(off)")                                                       \
+      (o)[20] = rv0 / rsd; (o)[21] = rv1 / rsd; (o)[22] = rv2 / rsd;                           \
+    }
+#define SR_RAY_C(o)                                                                           \
+    {                                                                                         \
+      _Pragma("clang fp contract(off)")                                                       \
+      const float n2 = fmaxf(sqrtf(((o)[20] * (o)[20] + (o)[21] * (o)[21]) + (o)[22] * (o)[22]), 1e-5f); \
+      (o)[19] = (crn0 * ((o)[20] / n2) + crn1 * ((o)[21] / n2)) + crn2 * ((o)[22] / n2);       \
+    }
+#define SR_INTERP2(o, i, lo)  /* channels 4i+lo, 4i+lo+1 */                                   \
+    {                                                                                         \
+      const float4 a = taps[i], bq = taps[4 + (i)], c4 = taps[8 + (i)], d4 = taps[12 + (i)];   \
+      if ((lo) == 0) {                                                                        \
+        (o)[4 * (i) + 0] = fmaf(smp.w_se, d4.x, fmaf(smp.w_sw, c4.x, fmaf(smp.w_ne, bq.x, smp.w_nw * a.x))); \
+        (o)[4 * (i) + 1] = fmaf(smp.w_se, d4.y, fmaf(smp.w_sw, c4.y, fmaf(smp.w_ne, bq.y, smp.w_nw * a.y))); \
+      } else {                                                                                \
+        (o)[4 * (i) + 2] = fmaf(smp.w_se, d4.z, fmaf(smp.w_sw, c4.z, fmaf(smp.w_ne, bq.z, smp.w_nw * a.z))); \
+        (o)[4 * (i) + 3] = fmaf(smp.w_se, d4.w, fmaf(smp.w_sw, c4.w, fmaf(smp.w_ne, bq.w, smp.w_nw * a.w))); \
+      }                                                                                       \
+    }
+#define SR_DOT_A(o)                                                                           \
+    {                                                                                         \
+      rdot = 0.0f;                                                                            \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) rdot = fmaf((o)[c], cur[c], rdot);         \
+    }
+#define SR_DOT_B(o)                                                                           \
+    {                                                                                         \
+      _Pragma("unroll") for (int c = 8; c < 16; ++c) rdot = fmaf((o)[c], cur[c], rdot);        \
+      const bool front = smp.zp > 0.0f;                                                       \
+      any_depth |= front;                                                                     \
+      any_bounds |= sr_in_bounds(smp, p.h, p.w);                                              \
+      (o)[16] = front ? 1.0f : 0.0f; /* mask (cost_volume.py:611-612) */                      \
+      (o)[17] = smp.zp;              /* z'_k (cost_volume.py:603-609) */                      \
+      (o)[18] = front ? rdot : 0.0f; /* dot * mask (cost_volume.py:691-695) */                \
+    }
+#define SR_SB __builtin_amdgcn_sched_barrier(0);
+
+    {  // view 0, not overlapped
+      const float* g = geom_b;
+      issue_view(0);
+      SR_RAY_A(f, g) SR_RAY_B(f) SR_RAY_C(f)
+      SR_INTERP2(f, 0, 0) SR_INTERP2(f, 0, 1) SR_INTERP2(f, 1, 0) SR_INTERP2(f, 1, 1)
+      SR_INTERP2(f, 2, 0) SR_INTERP2(f, 2, 1) SR_INTERP2(f, 3, 0) SR_INTERP2(f, 3, 1)
+      SR_DOT_A(f) SR_DOT_B(f)
+    }
+#pragma unroll 1
+    for (int k = 0; k < p.K; ++k) {
+      // branch-free: the last iteration re-derives view K-1 (results unused)
+      const int kn = min(k + 1, p.K - 1);
+      const float* g = geom_b + kn * SR_GEOM_STRIDE;
+      issue_view(kn);
       const float4* wk = W1p + (size_t)(13 * k) * 64 + lane;
+      float4 wA = wk[0], wN;
+#define SR_STEP(t)                                                        \
+      wN = wk[((t) + 1 < SR_VIEW_SLOTS / 2 ? (t) + 1 : (t)) * 64];       \
+      sr_l1_step(acc, wA, f[2 * (t)], f[2 * (t) + 1]);                    \
+      wA = wN;
+      SR_SB SR_STEP(0) SR_RAY_A(fn, g) SR_SB
+      SR_STEP(1) SR_RAY_B(fn) SR_SB
+      SR_STEP(2) SR_RAY_C(fn) SR_SB
+      SR_STEP(3) SR_INTERP2(fn, 0, 0) SR_SB
+      SR_STEP(4) SR_INTERP2(fn, 0, 1) SR_SB
+      SR_STEP(5) SR_INTERP2(fn, 1, 0) SR_SB
+      SR_STEP(6) SR_INTERP2(fn, 1, 1) SR_SB
+      SR_STEP(7) SR_INTERP2(fn, 2, 0) SR_SB
+      SR_STEP(8) SR_INTERP2(fn, 2, 1) SR_SB
+      SR_STEP(9) SR_INTERP2(fn, 3, 0) SR_SB
+      SR_STEP(10) SR_INTERP2(fn, 3, 1) SR_SB
+      SR_STEP(11) SR_DOT_A(fn) SR_SB
+      SR_STEP(12) SR_DOT_B(fn) SR_SB
 #pragma unroll
-      for (int t = 0; t < SR_VIEW_SLOTS / 2; ++t) sr_l1_step(acc, wk[t * 64], f[2 * t], f[2 * t + 1]);
+      for (int t = 0; t < SR_VIEW_SLOTS; ++t) f[t] = fn[t];
     }
     {
       // tail slots: d, cur[0..15], cur_ray[0..2], 1 (bias), 0
@@ -271,6 +333,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[g][m][r] = 0.0f;
     const float4* w2 = gW2 + lane;
+    asm volatile("" : "+v"(w2));  // keep hipcc from hoisting 65 loop-invariant 64-bit addresses (spills)
     float4 wn0 = w2[0], wn1 = w2[64];
 #pragma unroll
     for (int t = 0; t < 64; ++t) {
