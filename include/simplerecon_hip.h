@@ -96,6 +96,18 @@ int sr_dot_volume_fwd(const float* cur, const float* src, const float* K_src,
                       int64_t cv_sp, float* out_lowest, uint8_t* out_mask, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Materialising front end of the sweeps, for the reference's public helper
+ * CostVolumeManager.warp_features (cost_volume.py:139-234) / FastFeatureVolumeManager.warp_features
+ * (:812-964): for Dp depth planes writes the back-projected points out_world [B,Dp,4,N] (may be NULL),
+ * the source-camera depths z' out_depths [B,K,Dp,N], the bilinearly warped source features
+ * out_warped [B,K,Dp,C,N], out_mask = (z' > 0) as float [B,K,Dp,N] and the sampling coordinates
+ * out_pix [B,K,Dp,2,N] (may be NULL).  N = h*w.  B*K*Dp <= 65535. */
+int sr_warp_features_fwd(const float* src, const float* K_src, const float* T_src_cur,
+                         const float* invK_cur, const float* planes, int64_t ps_b, int64_t ps_d,
+                         int64_t ps_y, int64_t ps_x, int B, int K, int C, int h, int w, int Dp,
+                         float* out_world, float* out_depths, float* out_warped, float* out_mask,
+                         float* out_pix, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------ metadata-MLP volume --
  *
  * Fused plane sweep of the hero model: replaces FeatureVolumeManager.build_cost_volume + forward

@@ -135,6 +135,44 @@ class CostVolumeManager(nn.Module):
         # the dot model ignores return_mask and returns None (reference cost_volume.py:286, 335)
         return vol, lowest, planes, None
 
+    def _warp(self, src_feats, src_extrinsics, src_Ks, cur_invK, planes, want_pix):
+        """Runs sr_warp_features_fwd for the Dp planes of `planes` ([b,Dp,h,w], any strides)."""
+        for name, t in (("src_feats", src_feats), ("src_extrinsics", src_extrinsics), ("src_Ks", src_Ks),
+                        ("cur_invK", cur_invK), ("depth planes", planes)):
+            _lib.require_device_f32(name, t)
+        _lib.refuse_autograd(src_feats, src_extrinsics, src_Ks, cur_invK, planes)
+        b, k, c, h, w = src_feats.shape
+        dp = planes.shape[1]
+        dev = src_feats.device
+        n = h * w
+        world = torch.empty((b, dp, 4, n), dtype=torch.float32, device=dev)
+        depths = torch.empty((b, k, dp, h, w), dtype=torch.float32, device=dev)
+        warped = torch.empty((b, k, dp, c, h, w), dtype=torch.float32, device=dev)
+        mask = torch.empty((b, k, dp, h, w), dtype=torch.float32, device=dev)
+        pix = torch.empty((b, k, dp, 2, h, w), dtype=torch.float32, device=dev) if want_pix else None
+        if b == 0:
+            return world, depths, warped, mask, pix
+        lib = _lib.lib()
+        ws = self._get_workspace(lib.sr_volume_workspace_bytes(b, k, c, h, w), dev)
+        with torch.cuda.device(dev):
+            rc = lib.sr_warp_features_fwd(
+                _lib.ptr(src_feats.contiguous()), _lib.ptr(src_Ks.contiguous()), _lib.ptr(src_extrinsics.contiguous()),
+                _lib.ptr(cur_invK.contiguous()), _lib.ptr(planes), *planes.stride(), b, k, c, h, w, dp,
+                _lib.ptr(world), _lib.ptr(depths), _lib.ptr(warped), _lib.ptr(mask), _lib.ptr(pix), _lib.ptr(ws),
+                ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "sr_warp_features_fwd")
+        return world, depths, warped, mask, pix
+
+    def warp_features(self, src_feats, src_extrinsics, src_Ks, cur_invK, depth_plane_b1hw, batch_size,
+                      num_src_frames, num_feat_channels, uv_scale=None):
+        """One-plane warp with the reference's signature and return tuple (cost_volume.py:139-234):
+        (world_points_B4N, depths_bkhw, src_feat_warped_bkchw, mask_bkhw).  `uv_scale` is implied by
+        the feature-map size and accepted for signature compatibility only."""
+        world, depths, warped, mask, _ = self._warp(src_feats, src_extrinsics, src_Ks, cur_invK, depth_plane_b1hw,
+                                                    False)
+        world_B4N = world[:, 0].repeat_interleave(num_src_frames, dim=0)
+        return world_B4N, depths[:, :, 0], warped[:, :, 0], mask[:, :, 0]
+
     # -- the reference's entry points -------------------------------------------------------
     def build_cost_volume(self, cur_feats: Tensor, src_feats: Tensor, src_extrinsics: Tensor, src_poses: Tensor,
                           src_Ks: Tensor, cur_invK: Tensor, min_depth: Tensor, max_depth: Tensor,
@@ -237,6 +275,17 @@ class FastFeatureVolumeManager(FeatureVolumeManager):
     """The reference's batched variant (cost_volume.py:749-1164) trades O(B*D*N*202) memory for
     fewer launches.  The fused HIP sweep already is one launch with O(1) intermediates, so this
     class is the same kernel under the reference's second name."""
+
+    def warp_features(self, src_feats, src_extrinsics, src_Ks, cur_invK, depth_plane_bdhw, batch_size,
+                      num_src_frames, num_feat_channels, uv_scale=None):
+        """All-planes warp with the reference's signature and return tuple (cost_volume.py:812-964):
+        (world_points_bkd4hw, depths_bkdhw, src_feat_warped_bkdchw, mask_bkdhw, pix_coords_bkd2hw)."""
+        world, depths, warped, mask, pix = self._warp(src_feats, src_extrinsics, src_Ks, cur_invK,
+                                                      depth_plane_bdhw, True)
+        b, dp = world.shape[:2]
+        h, w = self.matching_height, self.matching_width
+        world_bkd4hw = world.view(b, 1, dp, 4, h, w).expand(b, num_src_frames, dp, 4, h, w)
+        return world_bkd4hw, depths, warped, mask, pix
 
 
 def to_hip(manager):

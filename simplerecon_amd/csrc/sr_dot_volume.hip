@@ -297,3 +297,83 @@ extern "C" int sr_dot_volume_fwd(const float* cur, const float* src, const float
   return sr_dot_volume_sweep(cur, invK_cur, planes, ps_b, ps_d, ps_y, ps_x, B, K, C, h, w, D, out_cv, cv_sb,
                              cv_sd, cv_sp, out_lowest, out_mask, workspace, workspace_bytes, stream_);
 }
+
+// ------------------------------------------------------------------ warp_features ---------
+// Materialising variant of the sweep's front end for the reference's public helper
+// CostVolumeManager.warp_features / FastFeatureVolumeManager.warp_features
+// (cost_volume.py:139-234, 812-964): one thread per (pixel, b, k, plane).
+struct SrWarpParams {
+  const float* src_nhwc; const float* invK; const float* geom;
+  SrPlanes planes;
+  float* world;   // [B,Dp,4,N] or null
+  float* depths;  // [B,K,Dp,N]
+  float* warped;  // [B,K,Dp,C,N]
+  float* mask;    // [B,K,Dp,N]
+  float* pix;     // [B,K,Dp,2,N] or null
+  int B, K, C, h, w, Dp;
+  float inv_w, inv_h;
+};
+
+__global__ __launch_bounds__(256) void sr_warp_features_kernel(SrWarpParams p) {
+  const int N = p.h * p.w;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= N) return;
+  int z = blockIdx.y;
+  const int j = z % p.Dp; z /= p.Dp;
+  const int k = z % p.K;
+  const int b = z / p.K;
+  const int y = pix / p.w, x = pix - y * p.w;
+  const float d = p.planes.ptr[b * p.planes.sb + j * p.planes.sd + y * p.planes.sy + x * p.planes.sx];
+  float X0, X1, X2;
+  {
+#pragma clang fp contract(off)
+    const float* iK = p.invK + 16 * (size_t)b;
+    const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+    X0 = d * (iK[0] * px + iK[1] * py + iK[2]);
+    X1 = d * (iK[4] * px + iK[5] * py + iK[6]);
+    X2 = d * (iK[8] * px + iK[9] * py + iK[10]);
+  }
+  if (p.world && k == 0) {
+    float* wp = p.world + ((size_t)b * p.Dp + j) * 4 * N + pix;
+    wp[0] = X0; wp[N] = X1; wp[2 * (size_t)N] = X2; wp[3 * (size_t)N] = 1.0f;
+  }
+  SrSample s;
+  sr_project_sample(p.geom + ((size_t)b * p.K + k) * SR_GEOM_STRIDE, X0, X1, X2, p.h, p.w, p.inv_w, p.inv_h, s);
+  const size_t rec = ((size_t)b * p.K + k) * p.Dp + j;
+  p.depths[rec * N + pix] = s.zp;
+  p.mask[rec * N + pix] = s.zp > 0.0f ? 1.0f : 0.0f;
+  if (p.pix) { p.pix[(rec * 2 + 0) * N + pix] = s.pix_x; p.pix[(rec * 2 + 1) * N + pix] = s.pix_y; }
+  const float* img = p.src_nhwc + ((size_t)b * p.K + k) * N * p.C;
+  float* out = p.warped + rec * p.C * N + pix;
+  for (int c = 0; c < p.C; ++c) {
+    // same accumulation order as ATen's grid_sampler_2d: nw, ne, sw, se
+    float v = img[(size_t)s.o_nw * p.C + c] * s.w_nw;
+    v = fmaf(img[(size_t)s.o_ne * p.C + c], s.w_ne, v);
+    v = fmaf(img[(size_t)s.o_sw * p.C + c], s.w_sw, v);
+    v = fmaf(img[(size_t)s.o_se * p.C + c], s.w_se, v);
+    out[(size_t)c * N] = v;
+  }
+}
+
+extern "C" int sr_warp_features_fwd(const float* src, const float* K_src, const float* T_src_cur,
+                                    const float* invK_cur, const float* planes, int64_t ps_b, int64_t ps_d,
+                                    int64_t ps_y, int64_t ps_x, int B, int K, int C, int h, int w, int Dp,
+                                    float* out_world, float* out_depths, float* out_warped, float* out_mask,
+                                    float* out_pix, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (B < 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || Dp <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!invK_cur || !planes || !out_depths || !out_warped || !out_mask) return SR_ERR_INVALID_ARGUMENT;
+  int rc = sr_volume_prepare(src, K_src, T_src_cur, nullptr, B, K, C, h, w, workspace, workspace_bytes, stream_);
+  if (rc) return rc;
+  SrWarpParams p;
+  p.src_nhwc = sr_ws_src_nhwc(workspace, B, K); p.invK = invK_cur; p.geom = sr_ws_geom(workspace);
+  p.planes = {planes, ps_b, ps_d, ps_y, ps_x};
+  p.world = out_world; p.depths = out_depths; p.warped = out_warped; p.mask = out_mask; p.pix = out_pix;
+  p.B = B; p.K = K; p.C = C; p.h = h; p.w = w; p.Dp = Dp;
+  p.inv_w = (float)(1.0 / (double)w);
+  p.inv_h = (float)(1.0 / (double)h);
+  const int N = h * w;
+  if ((long)B * K * Dp > 65535) return SR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sr_warp_features_kernel, dim3((N + 255) / 256, B * K * Dp), dim3(256), 0, (hipStream_t)stream_, p);
+  return sr_hip_rc(hipGetLastError());
+}

@@ -50,3 +50,14 @@ def pose_distance(pose_b44):
     r_m = torch.sqrt(2 * (1 - torch.minimum(torch.ones_like(tr) * 3.0, tr) / 3))
     t_m = torch.norm(t, dim=1)
     return torch.sqrt(t_m ** 2 + r_m ** 2), r_m, t_m
+
+
+def get_camera_rays(world_T_cam_b44, world_points_b3N, in_camera_frame, cam_T_world_b44=None, eps=1e-4):
+    """Unit rays from the camera centre to the points (reference geometry_utils.py:143-175); plain torch
+    helper kept for API parity -- inside the feature volume the rays are computed in the HIP sweep."""
+    if in_camera_frame:
+        ones = torch.ones_like(world_points_b3N[:, :1])
+        rays = torch.matmul(cam_T_world_b44[:, :3, :4], torch.cat([world_points_b3N, ones], 1))
+    else:
+        rays = world_points_b3N - world_T_cam_b44[:, 0:3, 3][:, :, None]
+    return torch.nn.functional.normalize(rays, dim=1)

@@ -35,7 +35,17 @@ class MLP(nn.Module):
         self.net = nn.Sequential(*layer_list)
 
     def forward(self, x):
-        return self.net(x)
+        """Applies the stack over the last dimension.  Device fp32 inputs run on the HIP 1x1 kernel with
+        the LeakyReLU fused into each layer's epilogue."""
+        from . import ops
+        mods = list(self.net)
+        i = 0
+        while i < len(mods):
+            lin = mods[i]
+            act = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU) else None
+            x = ops.linear(x, lin, leaky=act.negative_slope if act is not None else None)
+            i += 2 if act is not None else 1
+        return x
 
 
 class CVEncoder(nn.Module):

@@ -78,6 +78,42 @@ def packed_weight(conv: nn.Conv2d):
     return packed
 
 
+_PACKED_LIN = weakref.WeakKeyDictionary()  # nn.Linear -> (weight version, data_ptr, packed tensor)
+
+
+def linear(x, lin: nn.Linear, leaky=None):
+    """act(x @ W^T + b) over the last dimension through the 1x1 instantiation of the HIP conv kernel
+    ([M, Cin] row-major IS a 1 x M channels-last image).  Used by networks.MLP.forward."""
+    _lib.require_device_f32("linear input", x)
+    _lib.refuse_autograd(x, lin.weight)
+    cin, cout = lin.in_features, lin.out_features
+    if x.shape[-1] != cin:
+        raise ValueError(f"linear expects {cin} input features, got {x.shape[-1]}")
+    x2 = x.reshape(-1, cin).contiguous()
+    m = x2.shape[0]
+    out = torch.empty((m, cout), dtype=torch.float32, device=x.device)
+    if m == 0:
+        return out.view(*x.shape[:-1], cout)
+    w = lin.weight
+    hit = _PACKED_LIN.get(lin)
+    lib = _lib.lib()
+    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+        wp = hit[2]
+    else:
+        wp = torch.empty(lib.sr_conv_packed_weight_floats(cout, cin, 1), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(lib.sr_conv_pack_weights(_lib.ptr(w.detach().contiguous()), cout, cin, 1, _lib.ptr(wp),
+                                                _lib.stream_ptr(w.device)), "sr_conv_pack_weights")
+        _PACKED_LIN[lin] = (w._version, w.data_ptr(), wp)
+    bias = lin.bias.detach() if lin.bias is not None else None
+    with torch.cuda.device(x.device):
+        rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x2), m * cin, cin, _lib.ptr(wp), _lib.ptr(bias), None, 0, 0,
+                                    _lib.ptr(out), m * cout, cout, 1, 1, m, cin, cout, 1, 1,
+                                    C.c_float(-1.0 if leaky is None else float(leaky)), _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_conv2d_nhwc_fwd (linear)")
+    return out.view(*x.shape[:-1], cout)
+
+
 def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
     """act(conv(x) + bias [+ residual]) with the reference's Conv2d semantics; returns a channels-last view."""
     _lib.refuse_autograd(x, conv.weight)

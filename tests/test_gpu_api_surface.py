@@ -1,0 +1,116 @@
+"""GPU tests of the remaining public API surface of the reference's hot-path classes:
+warp_features (slow + fast signatures), MLP.forward, the K=15 / D=96 stress shape (BASELINE.json configs[4])."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_cases as gc
+import oracle
+from parity import assert_close, mismatch_fraction, rel_err
+from simplerecon_amd import geometry, synthetic
+from simplerecon_amd.cost_volume import CostVolumeManager, FastFeatureVolumeManager, FeatureVolumeManager
+from simplerecon_amd.networks import MLP
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _torch_warp(inp, planes_b1hw, h, w):
+    """Plain PyTorch fp32 reference of the op (same composition as reference cost_volume.py:139-234)."""
+    b, k, c = inp["src_feats"].shape[:3]
+    bp, pr = geometry.BackprojectDepth(h, w).to(DEV), geometry.Project3D().to(DEV)
+    wp = bp(planes_b1hw, inp["cur_invK"]).repeat_interleave(k, dim=0)
+    cam = pr(wp, inp["src_Ks"].view(-1, 4, 4), inp["src_extrinsics"].view(-1, 4, 4)).view(-1, 3, h, w)
+    scale = torch.tensor([1 / w, 1 / h], device=DEV).view(1, 1, 1, 2)
+    uv = 2 * cam[:, :2].permute(0, 2, 3, 1) * scale - 1
+    warped = F.grid_sample(inp["src_feats"].view(-1, c, h, w), uv, padding_mode="zeros", mode="bilinear",
+                           align_corners=False).view(b, k, c, h, w)
+    depths = cam[:, 2:].view(b, k, h, w)
+    return wp, depths, warped, (depths > 0).float(), cam[:, :2].view(b, k, 2, h, w)
+
+
+@pytest.mark.parametrize("name", ["dot_small", "dot_edge"])
+def test_warp_features_matches_torch_reference(name):
+    case = gc.VOLUME_CASES[name]
+    inp = {k: v.to(DEV) for k, v in gc.volume_inputs(case).items()}
+    b, k, c, h, w, d = case["B"], case["K"], case["C"], case["h"], case["w"], case["D"]
+    mgr = CostVolumeManager(h, w, num_depth_bins=d).to(DEV)
+    planes = mgr.generate_depth_planes(b, inp["min_depth"], inp["max_depth"])
+    with torch.inference_mode():
+        for j in (0, d - 1):
+            plane = planes[:, j].unsqueeze(1)
+            wp, depths, warped, mask = mgr.warp_features(inp["src_feats"], inp["src_extrinsics"], inp["src_Ks"],
+                                                         inp["cur_invK"], plane, b, k, c, None)
+            wp_r, depths_r, warped_r, mask_r, _ = _torch_warp(inp, plane.contiguous(), h, w)
+            assert wp.shape == wp_r.shape and warped.shape == (b, k, c, h, w)
+            assert_close(wp, wp_r, tol=1e-6, what="world points")
+            assert_close(depths, depths_r, tol=1e-5, what="depths")
+            assert_close(warped, warped_r, tol=1e-4, what="warped features")
+            assert mismatch_fraction(mask, mask_r) < 1e-3
+        # consistency with the fused sweep: sum_k mask * sum_c warped * cur == volume plane
+        vol = mgr(**inp)[0]
+        plane = planes[:, d - 1].unsqueeze(1)
+        _, _, warped, mask = mgr.warp_features(inp["src_feats"], inp["src_extrinsics"], inp["src_Ks"], inp["cur_invK"],
+                                               plane, b, k, c, None)
+        dot = ((warped * inp["cur_feats"].unsqueeze(1)).sum(2) * mask).sum(1)
+        assert_close(dot, vol[:, d - 1], tol=2e-6, what="warp_features vs fused sweep")
+
+
+def test_fast_warp_features_all_planes():
+    case = gc.VOLUME_CASES["hero_small"]
+    inp = {k: v.to(DEV) for k, v in gc.volume_inputs(case).items()}
+    b, k, c, h, w, d = case["B"], case["K"], case["C"], case["h"], case["w"], case["D"]
+    mgr = FastFeatureVolumeManager(h, w, num_depth_bins=d, num_source_views=k).to(DEV)
+    planes = mgr.generate_depth_planes(b, inp["min_depth"], inp["max_depth"])
+    with torch.inference_mode():
+        wp, depths, warped, mask, pix = mgr.warp_features(inp["src_feats"], inp["src_extrinsics"], inp["src_Ks"],
+                                                          inp["cur_invK"], planes, b, k, c, None)
+        assert wp.shape == (b, k, d, 4, h, w) and depths.shape == (b, k, d, h, w)
+        assert warped.shape == (b, k, d, c, h, w) and pix.shape == (b, k, d, 2, h, w)
+        for j in (0, 3, d - 1):
+            _, depths_r, warped_r, mask_r, pix_r = _torch_warp(inp, planes[:, j].unsqueeze(1).contiguous(), h, w)
+            assert_close(depths[:, :, j], depths_r, tol=1e-5, what="depths")
+            assert_close(warped[:, :, j], warped_r, tol=1e-4, what="warped")
+            assert_close(pix[:, :, j], pix_r, tol=1e-4, what="pix coords")
+        assert bool((mgr.get_mask(pix[:, :, -1]).any(1) & (mask[:, :, -1] > 0).any(1)).any())
+
+
+def test_mlp_forward_hip():
+    mlp = synthetic.seeded_fill_(MLP([202, 128, 128, 1], disable_final_activation=True), seed=5).to(DEV)
+    x = torch.randn(3, 7, 11, 202, device=DEV)
+    with torch.inference_mode():
+        y = mlp(x)
+        ref = mlp.net(x)  # plain PyTorch fp32 reference of the same op
+    assert y.shape == (3, 7, 11, 1)
+    assert_close(y, ref, tol=1e-5, what="MLP.forward")
+
+
+def test_stress_shape_k15_d96():
+    """BASELINE.json configs[4] channel layout: 15 source views (410-input MLP, W1 streamed from L2 because it
+    exceeds the LDS), 96 planes -- at a reduced spatial size so the oracle finishes in seconds."""
+    B, K, C, D, h, w = 1, 15, 16, 96, 18, 24
+    inp = synthetic.cost_volume_inputs(B, K, C, h, w, seed=77)
+    mgr = FeatureVolumeManager(h, w, num_depth_bins=D, matching_dim_size=C, num_source_views=K)
+    assert mgr.mlp.net[0].in_features == 410
+    synthetic.seeded_fill_(mgr.mlp, seed=9)
+    mgr = mgr.to(DEV)
+    with torch.inference_mode():
+        vol, lowest, planes, mask = mgr(return_mask=True, **{k: v.to(DEV) for k, v in inp.items()})
+    torch.cuda.synchronize()
+    n = {k: v.numpy() for k, v in inp.items()}
+    sd = {k: v.cpu().numpy() for k, v in mgr.mlp.state_dict().items()}
+    mlp = dict(W1=sd["net.0.weight"], b1=sd["net.0.bias"], W2=sd["net.2.weight"], b2=sd["net.2.bias"],
+               W3=sd["net.4.weight"], b3=sd["net.4.bias"])
+    cv_o, low_o, mask_o = oracle.mlp_volume(n["cur_feats"], n["src_feats"], n["src_Ks"], n["src_extrinsics"],
+                                            n["src_poses"], n["cur_invK"], planes[:, :, 0, 0].cpu().numpy(), mlp,
+                                            want_mask=True)
+    assert_close(vol, cv_o, tol=2e-5, what="K=15, D=96 vs oracle")
+    assert mismatch_fraction(mask, mask_o) == 0.0
+    # dot model on the same stress shape
+    dm = CostVolumeManager(h, w, num_depth_bins=D).to(DEV)
+    with torch.inference_mode():
+        dv = dm(**{k: v.to(DEV) for k, v in inp.items()})[0]
+    dv_o = oracle.dot_volume(n["cur_feats"], n["src_feats"], n["src_Ks"], n["src_extrinsics"], n["cur_invK"],
+                             planes[:, :, 0, 0].cpu().numpy())[0]
+    assert_close(dv, dv_o, tol=2e-6, what="dot K=15, D=96 vs oracle")
