@@ -299,6 +299,58 @@ class HeroCfg3:
                           f"{os.cpu_count()} host CPUs)"}
 
 
+class HeroVolumeOnly:
+    """FeatureVolumeManager alone (metadata-MLP sweep); default shape = BASELINE.json configs[4], the stress
+    config: 15 source views, 96 planes, 960x720 (matching 180x240), batch 4.  The UNet++ cannot run at
+    960x720 (reference bug: 23 -> 46 != 45 rows), so this config is the cost volume only."""
+    name = "hero_cfg5_volume"
+
+    def __init__(self, dev, rank, B=4, K=15, D=96, h=180, w=240):
+        from simplerecon_amd.cost_volume import FeatureVolumeManager
+        self.B, self.K, self.D, self.h, self.w, self.Cc = B, K, D, h, w, 16
+        self.dev = dev
+        self.frames_per_step = B
+        self.inp = synthetic.cost_volume_inputs(B, K, 16, h, w, seed=rank, device=dev)
+        mgr = FeatureVolumeManager(h, w, num_depth_bins=D, matching_dim_size=16, num_source_views=K)
+        synthetic.seeded_fill_(mgr.mlp, seed=3)
+        self.mgr = mgr.to(dev)
+        self.mgr.volume_memory_format = torch.channels_last
+        self.last = None
+
+    def step(self, i=0):
+        self.last = self.mgr(return_mask=True, **self.inp)
+
+    def finish(self, world):
+        if world > 1:
+            lowest = self.last[1].contiguous()
+            out = [torch.empty_like(lowest) for _ in range(world)] if dist.get_rank() == 0 else None
+            dist.gather(lowest, out, dst=0)
+
+    def config(self, world):
+        return {"workload": f"{self.name}: FeatureVolumeManager (metadata-MLP sweep) only, batch {self.B}/GPU, {self.K} "
+                            f"source views, {self.D} planes, {4*self.w}x{4*self.h} image -> {self.h}x{self.w} matching "
+                            f"features x 16 ch, fp32 (BASELINE.json configs[4], cost volume part)",
+                "frames_per_step_per_gpu": self.B, "parallelism": f"replica x{world} (keyframes sharded)"}
+
+    def roofline(self, n):
+        t = _time_launches(lambda: self.step(), max(3, min(n, 10)))
+        N = self.h * self.w
+        cin = 16 * (self.K + 1) + 10 * self.K + 4
+        flops = 2.0 * (cin * 128 + 128 * 128 + 128) * self.B * self.D * N
+        name = "sr_mlp_volume_kernel<true>" if (13 * self.K + 11) * 1024 <= 160 * 1024 else "sr_mlp_volume_kernel<false>"
+        return {"kernel": name, "bound": "mfma", "achieved": flops / t / 1e12, "peak": FP32_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF, "traffic": _pmc_traffic(self.name),
+                "avg_launch_us": t * 1e6, "algorithmic_flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": self.B * 4 * ((self.K + 1) * 16 * N + self.D * N + N),
+                "note": "time = whole FeatureVolumeManager.forward (prepare + pack + sweep + argmax), sweep dominates"}
+
+    def extra_kernels(self, n):
+        return None
+
+    def cpu_baseline(self):
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "not run for this workload"}
+
+
 class DotFull(HeroCfg3):
     """dot_product_model.yaml through the full hot path (cost volume + conv stack), batch 8."""
     name = "dot_full"
@@ -311,6 +363,8 @@ WORKLOADS = {
     "hero_cfg3_s2": lambda dev, rank: HeroCfg3(dev, rank, streams=2),
     "hero_cfg3_s4": lambda dev, rank: HeroCfg3(dev, rank, streams=4),
     "dot_full": lambda dev, rank: DotFull(dev, rank),
+    "hero_cfg5_volume": lambda dev, rank: HeroVolumeOnly(dev, rank),
+    "hero_cfg3_volume": lambda dev, rank: HeroVolumeOnly(dev, rank, B=8, K=7, D=64, h=120, w=160),
     "dot_cfg2": lambda dev, rank: DotCfg2(dev, rank),
     "dot_b8": lambda dev, rank: DotCfg2(dev, rank, B=8),
 }

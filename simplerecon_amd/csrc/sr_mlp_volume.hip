@@ -14,18 +14,28 @@
 //     so activations never touch LDS or HBM.  Layer 3 (128 -> 1) is a per-lane dot + one swap.
 //   * W1 (packed in k-step order) lives in LDS for the whole persistent block; W2 streams from
 //     L2 with a register prefetch (both do not fit the 160 KB LDS in fp32).
+#include <stdlib.h>
+
 #include "sr_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SR_HID 128          // hidden width of the matching MLP (reference cost_volume.py:402)
-#define SR_VIEW_SLOTS 26    // per-view k-slots: 16 warped + mask, z', dot, angle, ray(3), pose(3)
-#define SR_TAIL_SLOTS 22    // d, cur(16), cur_ray(3), one (bias), zero pad
+// Layer-1 inputs are split into a depth-VARIANT part (per view: 16 warped channels, mask, z', dot, ray
+// angle, source ray(3) and one spare slot that carries the plane depth d for view 0) and a depth-INVARIANT
+// part (reference features 16, reference ray 3, the constant 1 that carries the bias, 3 pose measures per
+// view).  The invariant part is multiplied ONCE per (64-pixel tile, chunk of planes) and re-used as the
+// accumulator initialiser of every plane of the chunk (-17 % layer-1 MFMA work).
+#define SR_VIEW_SLOTS 24
+#define SR_INV_FIXED 20     // cur(16), cur_ray(3), one
+#define SR_PLANE_CHUNK 8    // planes per work unit
 
-static inline int sr_mlp_steps1(int K) { return (SR_VIEW_SLOTS * K + SR_TAIL_SLOTS) / 2; }
+static inline int sr_mlp_steps_var(int K) { return (SR_VIEW_SLOTS / 2) * K; }
+static inline int sr_mlp_steps_inv(int K) { return (SR_INV_FIXED + 3 * K + 1) / 2; }
+static inline int sr_mlp_steps1(int K) { return sr_mlp_steps_var(K) + sr_mlp_steps_inv(K); }
 #define SR_MLP_STEPS2 65    // 64 hidden pairs + one bias step
 
-// packed parameter block (floats): [W1p: steps1*256][W2p: 65*256][w3tab: 128][b3: 1][pad]
+// packed parameter block (floats): [W1p: steps1*256 (variant steps first)][W2p: 65*256][w3tab: 128][b3: 1][pad]
 static inline size_t sr_mlp_packed_floats(int K) { return (size_t)(sr_mlp_steps1(K) + SR_MLP_STEPS2) * 256 + 128 + 4; }
 
 // ------------------------------------------------------------------ weight packing ----
@@ -34,7 +44,8 @@ __global__ void sr_mlp_pack_kernel(const float* __restrict__ W1, const float* __
                                    const float* __restrict__ W2, const float* __restrict__ b2,
                                    const float* __restrict__ W3, const float* __restrict__ b3,
                                    float* __restrict__ packed, int K, int C) {
-  const int steps1 = (SR_VIEW_SLOTS * K + SR_TAIL_SLOTS) / 2;
+  const int steps_var = (SR_VIEW_SLOTS / 2) * K;
+  const int steps1 = steps_var + (SR_INV_FIXED + 3 * K + 1) / 2;
   const int Cin = C * (K + 1) + 10 * K + 4;
   // reference channel offsets (cost_volume.py:709-723)
   const int o_cur = K * C, o_mask = o_cur + C, o_z = o_mask + K, o_d = o_z + K, o_dot = o_d + 1;
@@ -46,9 +57,9 @@ __global__ void sr_mlp_pack_kernel(const float* __restrict__ W1, const float* __
     if (e < steps1 * 256) {
       const int t = e >> 8, lane = (e >> 2) & 63, mt = e & 3;
       const int row = 32 * mt + (lane & 31);
-      const int slot = 2 * t + (lane >> 5);
       int col = -1;  // -1: zero, -2: bias
-      if (slot < SR_VIEW_SLOTS * K) {
+      if (t < steps_var) {
+        const int slot = 2 * t + (lane >> 5);
         const int k = slot / SR_VIEW_SLOTS, s = slot - k * SR_VIEW_SLOTS;
         if (s < 16) col = k * C + s;
         else if (s == 16) col = o_mask + k;
@@ -56,15 +67,16 @@ __global__ void sr_mlp_pack_kernel(const float* __restrict__ W1, const float* __
         else if (s == 18) col = o_dot + k;
         else if (s == 19) col = o_ang + k;
         else if (s < 23) col = o_sray + 3 * k + (s - 20);
-        else if (s == 23) col = o_pd + k;
-        else if (s == 24) col = o_rm + k;
-        else col = o_tm + k;
+        else col = (k == 0) ? o_d : -1;
       } else {
-        const int s = slot - SR_VIEW_SLOTS * K;
-        if (s == 0) col = o_d;
-        else if (s <= 16) col = o_cur + (s - 1);
-        else if (s <= 19) col = o_cray + (s - 17);
-        else if (s == 20) col = -2;
+        const int u = 2 * (t - steps_var) + (lane >> 5);
+        if (u < 16) col = o_cur + u;
+        else if (u < 19) col = o_cray + (u - 16);
+        else if (u == 19) col = -2;
+        else if (u < SR_INV_FIXED + 3 * K) {
+          const int k = (u - SR_INV_FIXED) / 3, i = (u - SR_INV_FIXED) - 3 * k;
+          col = (i == 0 ? o_pd : (i == 1 ? o_rm : o_tm)) + k;
+        }
       }
       v = (col >= 0) ? W1[(size_t)row * Cin + col] : (col == -2 ? b1[row] : 0.0f);
     } else if (e < (steps1 + SR_MLP_STEPS2) * 256) {
@@ -103,7 +115,9 @@ struct SrMlpParams {
   SrVolumeOut out;
   int B, K, h, w, D;
   int tiles;              // ceil(h*w / 64)
+  int chunk, chunks;      // planes per work unit, ceil(D / chunk)
   float inv_w, inv_h, slope;
+  int debug;              // ablation bits (env SR_MLP_DEBUG), 0 in production
 };
 
 __device__ __forceinline__ void sr_swap_halves(float fa, float fb, float& bP, float& bQ) {
@@ -128,87 +142,119 @@ __device__ __forceinline__ void sr_l1_step(f32x16 (&acc)[2][4], const float4 wA,
   acc[1][3] = SR_MFMA(wA.w, bQ, acc[1][3]);
 }
 
+// first k-step of a plane: D = A*B + hc (the hoisted depth-invariant part), no accumulator copy
+__device__ __forceinline__ void sr_l1_step_init(f32x16 (&acc)[2][4], const f32x16 (&hc)[2][4], const float4 wA,
+                                                float fa, float fb) {
+  float bP, bQ;
+  sr_swap_halves(fa, fb, bP, bQ);
+  acc[0][0] = SR_MFMA(wA.x, bP, hc[0][0]);
+  acc[1][0] = SR_MFMA(wA.x, bQ, hc[1][0]);
+  acc[0][1] = SR_MFMA(wA.y, bP, hc[0][1]);
+  acc[1][1] = SR_MFMA(wA.y, bQ, hc[1][1]);
+  acc[0][2] = SR_MFMA(wA.z, bP, hc[0][2]);
+  acc[1][2] = SR_MFMA(wA.z, bQ, hc[1][2]);
+  acc[0][3] = SR_MFMA(wA.w, bP, hc[0][3]);
+  acc[1][3] = SR_MFMA(wA.w, bQ, hc[1][3]);
+}
+
+#define SR_LDS_W3_FLOATS 256  // w3tab (128) + b3 + pad, in front of W1 in LDS
+
 template <bool W1_LDS>
 __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int C = 16;
+  constexpr int VS = SR_VIEW_SLOTS / 2;  // k-steps per view
   const int lane = threadIdx.x & 63;
-  const int steps1 = (SR_VIEW_SLOTS * p.K + SR_TAIL_SLOTS) / 2;
+  const int steps_var = VS * p.K;
+  const int steps1 = steps_var + (SR_INV_FIXED + 3 * p.K + 1) / 2;
   const float4* gW1 = reinterpret_cast<const float4*>(p.packed);
+  const float4* gW1inv = gW1 + (size_t)steps_var * 64;
   const float4* gW2 = gW1 + (size_t)steps1 * 64;
   const float* gW3 = p.packed + (size_t)(steps1 + SR_MLP_STEPS2) * 256;
 
+  for (int i = threadIdx.x; i < 129; i += blockDim.x) lds[i] = gW3[i];
   if (W1_LDS) {
-    float4* l4 = reinterpret_cast<float4*>(lds);
-    for (int i = threadIdx.x; i < steps1 * 64; i += blockDim.x) l4[i] = gW1[i];
-    __syncthreads();
+    float4* l4 = reinterpret_cast<float4*>(lds + SR_LDS_W3_FLOATS);
+    for (int i = threadIdx.x; i < steps_var * 64; i += blockDim.x) l4[i] = gW1[i];
   }
-  const float4* W1p = W1_LDS ? reinterpret_cast<const float4*>(lds) : gW1;
+  __syncthreads();
+  const float4* W1p = W1_LDS ? reinterpret_cast<const float4*>(lds + SR_LDS_W3_FLOATS) : gW1;
 
   const int N = p.h * p.w;
-  const long nitems = (long)p.B * p.tiles * p.D;
+  const long nunits = (long)p.B * p.tiles * p.chunks;
   const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
   const int half = lane >> 5;
 
-  for (long item = wave0; item < nitems; item += nwaves) {
-    const int j = (int)(item % p.D);
-    const long tb = item / p.D;
+  for (long unit = wave0; unit < nunits; unit += nwaves) {
+    const int chunk = (int)(unit % p.chunks);
+    const long tb = unit / p.chunks;
     const int tile = (int)(tb % p.tiles);
     const int b = (int)(tb / p.tiles);
+    const int j0 = chunk * p.chunk, j1 = min(p.D, j0 + p.chunk);
     const int pix = tile * 64 + lane;
     const bool active = pix < N;
     const int pc = active ? pix : N - 1;
     const int y = pc / p.w, x = pc - y * p.w;
+    const float* plane_ptr = p.planes.ptr + b * p.planes.sb + y * p.planes.sy + x * p.planes.sx;
+    const float* geom_b = p.geom + (size_t)b * p.K * SR_GEOM_STRIDE;
+    const float* src_b = p.src_nhwc + (size_t)b * p.K * N * C;
 
     float cur[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) cur[c] = p.cur[((size_t)b * C + c) * N + pc];
 
-    float X0, X1, X2;
-    const float d = p.planes.ptr[b * p.planes.sb + j * p.planes.sd + y * p.planes.sy + x * p.planes.sx];
+    float r0, r1, r2;
     {
 #pragma clang fp contract(off)
       const float* iK = p.invK + 16 * (size_t)b;
       const float px = (float)x + 0.5f, py = (float)y + 0.5f;
-      const float r0 = iK[0] * px + iK[1] * py + iK[2];
-      const float r1 = iK[4] * px + iK[5] * py + iK[6];
-      const float r2 = iK[8] * px + iK[9] * py + iK[10];
-      X0 = d * r0; X1 = d * r1; X2 = d * r2;
+      r0 = iK[0] * px + iK[1] * py + iK[2];
+      r1 = iK[4] * px + iK[5] * py + iK[6];
+      r2 = iK[8] * px + iK[9] * py + iK[10];
     }
-    // current-frame ray: F.normalize(X) (cost_volume.py:641-651), eps 1e-12
-    float cr0, cr1, cr2, n1;
+    // current-frame ray F.normalize(X) (cost_volume.py:641-651, eps 1e-12): X = d * r, so the ray does not depend
+    // on the plane beyond rounding; it is formed from the chunk's first plane and shared by the chunk.
+    float cr0, cr1, cr2, crn0, crn1, crn2;
     {
 #pragma clang fp contract(off)
-      const float cn = sqrtf((X0 * X0 + X1 * X1) + X2 * X2);
-      const float cden = fmaxf(cn, 1e-12f);
+      const float d0 = plane_ptr[j0 * p.planes.sd];
+      const float X0 = d0 * r0, X1 = d0 * r1, X2 = d0 * r2;
+      const float cden = fmaxf(sqrtf((X0 * X0 + X1 * X1) + X2 * X2), 1e-12f);
       cr0 = X0 / cden; cr1 = X1 / cden; cr2 = X2 / cden;
-      n1 = fmaxf(sqrtf((cr0 * cr0 + cr1 * cr1) + cr2 * cr2), 1e-5f);
+      const float n1 = fmaxf(sqrtf((cr0 * cr0 + cr1 * cr1) + cr2 * cr2), 1e-5f);
+      crn0 = cr0 / n1; crn1 = cr1 / n1; crn2 = cr2 / n1;  // cosine_similarity's first operand
     }
 
-    f32x16 acc[2][4];
+    // ---- depth-invariant part of layer 1 (weights straight from L2, once per unit) ----
+    f32x16 hc[2][4];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][m][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) hc[g][m][r] = 0.0f;
+    {
+      const float4* wi = gW1inv + lane;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) sr_l1_step(hc, wi[t * 64], cur[2 * t], cur[2 * t + 1]);
+      sr_l1_step(hc, wi[8 * 64], cr0, cr1);
+      sr_l1_step(hc, wi[9 * 64], cr2, 1.0f);
+      const int npose = 3 * p.K;
+#pragma unroll 1
+      for (int u = 0; u < npose; u += 2) {  // pose measures: [b,k] scalars (geometry_utils.py:178-191)
+        const int ka = u / 3, ia = u - 3 * ka, kb = (u + 1) / 3, ib = (u + 1) - 3 * kb;
+        const float fa = geom_b[ka * SR_GEOM_STRIDE + 15 + ia];
+        const float fb = (u + 1 < npose) ? geom_b[kb * SR_GEOM_STRIDE + 15 + ib] : 0.0f;
+        sr_l1_step(hc, wi[(size_t)(10 + (u >> 1)) * 64], fa, fb);
+      }
+    }
 
-    const float* geom_b = p.geom + (size_t)b * p.K * SR_GEOM_STRIDE;
-    const float* src_b = p.src_nhwc + (size_t)b * p.K * N * C;
-    bool any_depth = false, any_bounds = false;
-
-    // ---- layer 1, software-pipelined over views: the feature vector of view k+1 is assembled in 13 small
-    // VALU pieces, each placed in the shadow of one k-step (8 MFMAs = 512 cycles) of view k; its 16 tap
-    // loads are issued before step 0 and first touched at step 3.  sched_barrier(0) pins the placement.
     SrSample smp;
     float4 taps[16];
     float f[SR_VIEW_SLOTS], fn[SR_VIEW_SLOTS];
-    float crn0, crn1, crn2;  // cur_ray / max(|cur_ray|, 1e-5)  (cosine_similarity's first operand)
-    {
-#pragma clang fp contract(off)
-      crn0 = cr0 / n1; crn1 = cr1 / n1; crn2 = cr2 / n1;
-    }
+    float X0, X1, X2, d;
+    bool any_depth, any_bounds;
     auto issue_view = [&](int k) {
       sr_project_sample(geom_b + k * SR_GEOM_STRIDE, X0, X1, X2, p.h, p.w, p.inv_w, p.inv_h, smp);
       const float* img = src_b + (size_t)k * N * C;
@@ -216,19 +262,21 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
       const float4* t_ne = reinterpret_cast<const float4*>(img + (size_t)smp.o_ne * C);
       const float4* t_sw = reinterpret_cast<const float4*>(img + (size_t)smp.o_sw * C);
       const float4* t_se = reinterpret_cast<const float4*>(img + (size_t)smp.o_se * C);
+      if (!(p.debug & 2)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        taps[i] = t_nw[i]; taps[4 + i] = t_ne[i]; taps[8 + i] = t_sw[i]; taps[12 + i] = t_se[i];
+        for (int i = 0; i < 4; ++i) {
+          taps[i] = t_nw[i]; taps[4 + i] = t_ne[i]; taps[8 + i] = t_sw[i]; taps[12 + i] = t_se[i];
+        }
       }
     };
-    // pieces of the feature assembly (o = fn or f).  Ray pieces need no taps.
+    // pieces of the per-view feature assembly (o = fn or f); the ray pieces need no taps
     float rv0, rv1, rv2, rsd, rdot;
-#define SR_RAY_A(o, g)                                                                        \
+#define SR_RAY_A(o, g, kview)                                                                 \
     {                                                                                         \
       _Pragma("clang fp contract(off)")                                                       \
       rv0 = X0 - (g)[12]; rv1 = X1 - (g)[13]; rv2 = X2 - (g)[14];                              \
       rsd = fmaxf(sqrtf((rv0 * rv0 + rv1 * rv1) + rv2 * rv2), 1e-12f);                         \
-      (o)[23] = (g)[15]; (o)[24] = (g)[16]; (o)[25] = (g)[17];                                 \
+      (o)[23] = ((kview) == 0) ? d : 0.0f; /* plane depth rides in view 0's spare slot */      \
     }
 #define SR_RAY_B(o)                                                                           \
     {                                                                                         \
@@ -252,14 +300,10 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
         (o)[4 * (i) + 3] = fmaf(smp.w_se, d4.w, fmaf(smp.w_sw, c4.w, fmaf(smp.w_ne, bq.w, smp.w_nw * a.w))); \
       }                                                                                       \
     }
-#define SR_DOT_A(o)                                                                           \
+#define SR_DOT(o)                                                                             \
     {                                                                                         \
       rdot = 0.0f;                                                                            \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) rdot = fmaf((o)[c], cur[c], rdot);         \
-    }
-#define SR_DOT_B(o)                                                                           \
-    {                                                                                         \
-      _Pragma("unroll") for (int c = 8; c < 16; ++c) rdot = fmaf((o)[c], cur[c], rdot);        \
+      _Pragma("unroll") for (int c = 0; c < 16; ++c) rdot = fmaf((o)[c], cur[c], rdot);        \
       const bool front = smp.zp > 0.0f;                                                       \
       any_depth |= front;                                                                     \
       any_bounds |= sr_in_bounds(smp, p.h, p.w);                                              \
@@ -269,123 +313,128 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
     }
 #define SR_SB __builtin_amdgcn_sched_barrier(0);
 
-    {  // view 0, not overlapped
-      const float* g = geom_b;
-      issue_view(0);
-      SR_RAY_A(f, g) SR_RAY_B(f) SR_RAY_C(f)
-      SR_INTERP2(f, 0, 0) SR_INTERP2(f, 0, 1) SR_INTERP2(f, 1, 0) SR_INTERP2(f, 1, 1)
-      SR_INTERP2(f, 2, 0) SR_INTERP2(f, 2, 1) SR_INTERP2(f, 3, 0) SR_INTERP2(f, 3, 1)
-      SR_DOT_A(f) SR_DOT_B(f)
-    }
 #pragma unroll 1
-    for (int k = 0; k < p.K; ++k) {
-      // branch-free: the last iteration re-derives view K-1 (results unused)
-      const int kn = min(k + 1, p.K - 1);
-      const float* g = geom_b + kn * SR_GEOM_STRIDE;
-      issue_view(kn);
-      const float4* wk = W1p + (size_t)(13 * k) * 64 + lane;
-      float4 wA = wk[0], wN;
-#define SR_STEP(t)                                                        \
-      wN = wk[((t) + 1 < SR_VIEW_SLOTS / 2 ? (t) + 1 : (t)) * 64];       \
-      sr_l1_step(acc, wA, f[2 * (t)], f[2 * (t) + 1]);                    \
-      wA = wN;
-      SR_SB SR_STEP(0) SR_RAY_A(fn, g) SR_SB
-      SR_STEP(1) SR_RAY_B(fn) SR_SB
-      SR_STEP(2) SR_RAY_C(fn) SR_SB
-      SR_STEP(3) SR_INTERP2(fn, 0, 0) SR_SB
-      SR_STEP(4) SR_INTERP2(fn, 0, 1) SR_SB
-      SR_STEP(5) SR_INTERP2(fn, 1, 0) SR_SB
-      SR_STEP(6) SR_INTERP2(fn, 1, 1) SR_SB
-      SR_STEP(7) SR_INTERP2(fn, 2, 0) SR_SB
-      SR_STEP(8) SR_INTERP2(fn, 2, 1) SR_SB
-      SR_STEP(9) SR_INTERP2(fn, 3, 0) SR_SB
-      SR_STEP(10) SR_INTERP2(fn, 3, 1) SR_SB
-      SR_STEP(11) SR_DOT_A(fn) SR_SB
-      SR_STEP(12) SR_DOT_B(fn) SR_SB
-#pragma unroll
-      for (int t = 0; t < SR_VIEW_SLOTS; ++t) f[t] = fn[t];
-    }
-    {
-      // tail slots: d, cur[0..15], cur_ray[0..2], 1 (bias), 0
-      const float4* wk = W1p + (size_t)(13 * p.K) * 64 + lane;
-      sr_l1_step(acc, wk[0 * 64], d, cur[0]);
-#pragma unroll
-      for (int t = 1; t < 8; ++t) sr_l1_step(acc, wk[t * 64], cur[2 * t - 1], cur[2 * t]);
-      sr_l1_step(acc, wk[8 * 64], cur[15], cr0);
-      sr_l1_step(acc, wk[9 * 64], cr1, cr2);
-      sr_l1_step(acc, wk[10 * 64], 1.0f, 0.0f);
-    }
-
-    // LeakyReLU(slope) on the hidden layer (networks.py:139): max(v, slope*v) for 0 < slope < 1
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][m][r] = fmaxf(acc[g][m][r], p.slope * acc[g][m][r]);
-
-    // layer 2: the layer-1 accumulators are the B operands; W2 streams from L2
-    f32x16 acc2[2][4];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[g][m][r] = 0.0f;
-    const float4* w2 = gW2 + lane;
-    asm volatile("" : "+v"(w2));  // keep hipcc from hoisting 65 loop-invariant 64-bit addresses (spills)
-    float4 wn0 = w2[0], wn1 = w2[64];
-#pragma unroll
-    for (int t = 0; t < 64; ++t) {
-      const float4 wA = wn0;
-      wn0 = wn1;
-      wn1 = w2[(size_t)min(t + 2, 64) * 64];
-      const float bP = acc[0][t >> 4][t & 15], bQ = acc[1][t >> 4][t & 15];
-      acc2[0][0] = SR_MFMA(wA.x, bP, acc2[0][0]);
-      acc2[1][0] = SR_MFMA(wA.x, bQ, acc2[1][0]);
-      acc2[0][1] = SR_MFMA(wA.y, bP, acc2[0][1]);
-      acc2[1][1] = SR_MFMA(wA.y, bQ, acc2[1][1]);
-      acc2[0][2] = SR_MFMA(wA.z, bP, acc2[0][2]);
-      acc2[1][2] = SR_MFMA(wA.z, bQ, acc2[1][2]);
-      acc2[0][3] = SR_MFMA(wA.w, bP, acc2[0][3]);
-      acc2[1][3] = SR_MFMA(wA.w, bQ, acc2[1][3]);
-    }
-    {
-      const float4 wA = wn0;  // bias step (t = 64)
-      const float one = half ? 0.0f : 1.0f;
-      acc2[0][0] = SR_MFMA(wA.x, one, acc2[0][0]);
-      acc2[1][0] = SR_MFMA(wA.x, one, acc2[1][0]);
-      acc2[0][1] = SR_MFMA(wA.y, one, acc2[0][1]);
-      acc2[1][1] = SR_MFMA(wA.y, one, acc2[1][1]);
-      acc2[0][2] = SR_MFMA(wA.z, one, acc2[0][2]);
-      acc2[1][2] = SR_MFMA(wA.z, one, acc2[1][2]);
-      acc2[0][3] = SR_MFMA(wA.w, one, acc2[0][3]);
-      acc2[1][3] = SR_MFMA(wA.w, one, acc2[1][3]);
-    }
-
-    // layer 3 (128 -> 1, no activation: disable_final_activation=True, cost_volume.py:438)
-    const float4* w3 = reinterpret_cast<const float4*>(gW3 + half * 64);
-    float oP = 0.0f, oQ = 0.0f;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 wv = w3[m * 4 + q];
-        const float wr[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float hp = acc2[0][m][4 * q + i], hq = acc2[1][m][4 * q + i];
-          oP = fmaf(wr[i], fmaxf(hp, p.slope * hp), oP);
-          oQ = fmaf(wr[i], fmaxf(hq, p.slope * hq), oQ);
-        }
+    for (int j = j0; j < j1; ++j) {
+      d = plane_ptr[j * p.planes.sd];
+      {
+#pragma clang fp contract(off)
+        X0 = d * r0; X1 = d * r1; X2 = d * r2;  // geometry_utils.py:56-57
       }
-    oP += __shfl_xor(oP, 32);
-    oQ += __shfl_xor(oQ, 32);
-    const float cost = (half ? oQ : oP) + gW3[128];
+      any_depth = false; any_bounds = false;
+      f32x16 acc[2][4];
 
-    if (active) {
-      p.out.cv[b * p.out.sb + j * p.out.sd + (int64_t)pix * p.out.sp] = cost;
-      if (j == p.D - 1 && p.out.mask) p.out.mask[(size_t)b * N + pix] = (uint8_t)(any_depth && any_bounds);
+      {  // view 0, not overlapped
+        issue_view(0);
+        SR_RAY_A(f, geom_b, 0) SR_RAY_B(f) SR_RAY_C(f)
+        SR_INTERP2(f, 0, 0) SR_INTERP2(f, 0, 1) SR_INTERP2(f, 1, 0) SR_INTERP2(f, 1, 1)
+        SR_INTERP2(f, 2, 0) SR_INTERP2(f, 2, 1) SR_INTERP2(f, 3, 0) SR_INTERP2(f, 3, 1)
+        SR_DOT(f)
+      }
+      // ---- layer 1, software-pipelined over views: the feature vector of view k+1 is assembled in 12 small
+      // VALU pieces, each placed in the shadow of one k-step (8 MFMAs = 512 cycles) of view k; its 16 tap
+      // loads are issued before step 0 and first touched at step 3.  sched_barrier(0) pins the placement.
+      // view 0's first step takes the hoisted invariant part as its C operand; the loop below handles the rest
+#define SR_STEP(t)                                           \
+        wN = wk[((t) + 1 < VS ? (t) + 1 : (t)) * 64];       \
+        sr_l1_step(acc, wA, f[2 * (t)], f[2 * (t) + 1]);     \
+        wA = wN;
+#define SR_VIEW_BODY(FIRST)                                                            \
+        {                                                                              \
+          const int kn = min(k + 1, p.K - 1); /* last iteration re-derives view K-1 */ \
+          const float* g = geom_b + kn * SR_GEOM_STRIDE;                               \
+          issue_view(kn);                                                              \
+          const float4* wk = W1p + (size_t)(VS * k) * 64 + lane;                       \
+          float4 wA = wk[0], wN;                                                       \
+          SR_SB                                                                        \
+          if (FIRST) { wN = wk[64]; sr_l1_step_init(acc, hc, wA, f[0], f[1]); wA = wN; } \
+          else { SR_STEP(0) }                                                          \
+          SR_RAY_A(fn, g, kn) SR_SB                                                    \
+          SR_STEP(1) SR_RAY_B(fn) SR_SB                                                \
+          SR_STEP(2) SR_RAY_C(fn) SR_SB                                                \
+          SR_STEP(3) SR_SB /* taps not touched before step 4 (>= 2k cycles after issue) */ \
+          SR_STEP(4) SR_INTERP2(fn, 0, 0) SR_SB                                        \
+          SR_STEP(5) SR_INTERP2(fn, 0, 1) SR_SB                                        \
+          SR_STEP(6) SR_INTERP2(fn, 1, 0) SR_SB                                        \
+          SR_STEP(7) SR_INTERP2(fn, 1, 1) SR_SB                                        \
+          SR_STEP(8) SR_INTERP2(fn, 2, 0) SR_SB                                        \
+          SR_STEP(9) SR_INTERP2(fn, 2, 1) SR_SB                                        \
+          SR_STEP(10) SR_INTERP2(fn, 3, 0) SR_SB                                       \
+          SR_STEP(11) SR_INTERP2(fn, 3, 1) SR_DOT(fn) SR_SB                            \
+          _Pragma("unroll") for (int t = 0; t < SR_VIEW_SLOTS; ++t) f[t] = fn[t];      \
+        }
+      {
+        const int k = 0;
+        SR_VIEW_BODY(true)
+      }
+#pragma unroll 1
+      for (int k = 1; k < p.K; ++k) SR_VIEW_BODY(false)
+
+      // layer 2: the layer-1 accumulators, passed through LeakyReLU(slope) = max(v, slope*v) (networks.py:139,
+      // 0 < slope < 1) on the fly, are the B operands; W2 streams from L2 three steps ahead
+      f32x16 acc2[2][4];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[g][m][r] = 0.0f;
+      const float4* w2 = gW2 + lane;
+      asm volatile("" : "+v"(w2));  // keep hipcc from hoisting 65 loop-invariant 64-bit addresses (spills)
+      float4 wn0 = w2[0], wn1 = w2[64], wn2 = w2[128];
+#pragma unroll
+      for (int t = 0; t < 64; ++t) {
+        const float4 wA = wn0;
+        wn0 = wn1;
+        wn1 = wn2;
+        if (!(p.debug & 1)) wn2 = w2[(size_t)min(t + 3, 64) * 64];
+        const float aP = acc[0][t >> 4][t & 15], aQ = acc[1][t >> 4][t & 15];
+        const float bP = fmaxf(aP, p.slope * aP), bQ = fmaxf(aQ, p.slope * aQ);
+        acc2[0][0] = SR_MFMA(wA.x, bP, acc2[0][0]);
+        acc2[1][0] = SR_MFMA(wA.x, bQ, acc2[1][0]);
+        acc2[0][1] = SR_MFMA(wA.y, bP, acc2[0][1]);
+        acc2[1][1] = SR_MFMA(wA.y, bQ, acc2[1][1]);
+        acc2[0][2] = SR_MFMA(wA.z, bP, acc2[0][2]);
+        acc2[1][2] = SR_MFMA(wA.z, bQ, acc2[1][2]);
+        acc2[0][3] = SR_MFMA(wA.w, bP, acc2[0][3]);
+        acc2[1][3] = SR_MFMA(wA.w, bQ, acc2[1][3]);
+      }
+      {
+        const float4 wA = wn0;  // bias step (t = 64)
+        const float one = half ? 0.0f : 1.0f;
+        acc2[0][0] = SR_MFMA(wA.x, one, acc2[0][0]);
+        acc2[1][0] = SR_MFMA(wA.x, one, acc2[1][0]);
+        acc2[0][1] = SR_MFMA(wA.y, one, acc2[0][1]);
+        acc2[1][1] = SR_MFMA(wA.y, one, acc2[1][1]);
+        acc2[0][2] = SR_MFMA(wA.z, one, acc2[0][2]);
+        acc2[1][2] = SR_MFMA(wA.z, one, acc2[1][2]);
+        acc2[0][3] = SR_MFMA(wA.w, one, acc2[0][3]);
+        acc2[1][3] = SR_MFMA(wA.w, one, acc2[1][3]);
+      }
+
+      // layer 3 (128 -> 1, no activation: disable_final_activation=True, cost_volume.py:438); w3tab in LDS
+      const float4* w3 = reinterpret_cast<const float4*>(lds + half * 64);
+      float oP = 0.0f, oQ = 0.0f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 wv = w3[m * 4 + q];
+          const float wr[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float hp = acc2[0][m][4 * q + i], hq = acc2[1][m][4 * q + i];
+            oP = fmaf(wr[i], fmaxf(hp, p.slope * hp), oP);
+            oQ = fmaf(wr[i], fmaxf(hq, p.slope * hq), oQ);
+          }
+        }
+      oP += __shfl_xor(oP, 32);
+      oQ += __shfl_xor(oQ, 32);
+      const float cost = (half ? oQ : oP) + lds[128];
+
+      if (active) {
+        p.out.cv[b * p.out.sb + j * p.out.sd + (int64_t)pix * p.out.sp] = cost;
+        if (j == p.D - 1 && p.out.mask) p.out.mask[(size_t)b * N + pix] = (uint8_t)(any_depth && any_bounds);
+      }
     }
   }
 }
@@ -444,22 +493,39 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
   p.inv_w = (float)(1.0 / (double)w);
   p.inv_h = (float)(1.0 / (double)h);
   p.slope = leaky_slope;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_MLP_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
 
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  const long nitems = (long)B * p.tiles * D;
-  const int blocks = (int)((nitems + 3) / 4 < cus ? (nitems + 3) / 4 : cus);
-  const size_t w1_bytes = (size_t)sr_mlp_steps1(K) * 1024;
-  if (w1_bytes <= 160 * 1024) {
+  // planes per work unit: as many as possible (the hoisted invariant part is paid once per unit) while the
+  // units still spread evenly over the 4*CUs persistent waves
+  {
+    const long waves = 4L * cus;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int c = SR_PLANE_CHUNK; c >= 1; c >>= 1) {
+      const long units = (long)B * p.tiles * ((D + c - 1) / c);
+      const long rounds = (units + waves - 1) / waves;
+      const double cost = (double)rounds * (c * 1192.0 + 168.0);  // MFMAs per unit: c planes + invariant part
+      if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    p.chunk = best;
+    p.chunks = (D + best - 1) / best;
+  }
+  const long nunits = (long)B * p.tiles * p.chunks;
+  const int blocks = (int)((nunits + 3) / 4 < cus ? (nunits + 3) / 4 : cus);
+  const size_t w3_bytes = SR_LDS_W3_FLOATS * sizeof(float);
+  const size_t w1_bytes = (size_t)sr_mlp_steps_var(K) * 1024;
+  if (w1_bytes + w3_bytes <= 160 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)sr_mlp_volume_kernel<true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)w1_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(w1_bytes + w3_bytes));
     if (e != hipSuccess) return sr_hip_rc(e);
-    hipLaunchKernelGGL(sr_mlp_volume_kernel<true>, dim3(blocks), dim3(256), w1_bytes, stream, p);
+    hipLaunchKernelGGL(sr_mlp_volume_kernel<true>, dim3(blocks), dim3(256), w1_bytes + w3_bytes, stream, p);
   } else {
-    hipLaunchKernelGGL(sr_mlp_volume_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(sr_mlp_volume_kernel<false>, dim3(blocks), dim3(256), w3_bytes, stream, p);
   }
   int rc = sr_hip_rc(hipGetLastError());
   if (rc) return rc;
