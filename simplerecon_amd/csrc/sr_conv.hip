@@ -24,8 +24,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define SR_CK 16        // input channels per LDS slab
-#define SR_LDS_ROW 20   // floats per staged pixel (16 + 4 pad)
+// input channels per LDS slab: 16 for 3x3 convs (18 k-steps per slab), 64 for 1x1 convs (8 k-steps per
+// slab instead of 2: a 1x1 slab of 16 channels is all barrier).  LDS rows carry 4 floats of padding:
+// row strides of 20 and 68 floats are both conflict-free for the 16-byte A-fragment reads.
+__host__ __device__ constexpr int sr_ck(int ks, int stride = 1) { return (ks == 1 && stride == 1) ? 64 : 16; }
 
 struct SrConvParams {
   const float* in; int64_t in_sb; int in_sp;        // batch stride, pixel stride (elements)
@@ -51,9 +53,12 @@ struct SrConvGeom {
   static constexpr int TH = 4 * MT * RM;
   static constexpr int HH = (TH - 1) * S + KS;
   static constexpr int HW = (CM - 1) * S + KS;
-  static constexpr int ELEMS = HH * HW * 4;            // float4 elements per slab
+  static constexpr int CK = sr_ck(KS, S);              // channels per slab
+  static constexpr int ROW = CK + 4;                   // floats per staged pixel
+  static constexpr int Q = CK / 4;                     // float4 per staged pixel
+  static constexpr int ELEMS = HH * HW * Q;            // float4 elements per slab
   static constexpr int PER_THREAD = (ELEMS + 255) / 256;
-  static constexpr int TILE_FLOATS = HH * HW * SR_LDS_ROW;
+  static constexpr int TILE_FLOATS = HH * HW * ROW;
 };
 
 // Per-thread element offsets (in floats, relative to the image base; -1 = outside the image) of the
@@ -65,7 +70,7 @@ __device__ __forceinline__ void sr_conv_stage_setup(const SrConvParams& p, int i
 #pragma unroll
   for (int it = 0; it < G::PER_THREAD; ++it) {
     const int e = threadIdx.x + it * 256;
-    const int px = e >> 2, q = e & 3;
+    const int px = e / G::Q, q = e % G::Q;
     const int hy = px / G::HW, hx = px - hy * G::HW;
     const int iy = iy0 + hy, ix = ix0 + hx;
     const bool ok = (e < G::ELEMS) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W) && !(p.debug & 4);
@@ -82,7 +87,7 @@ __device__ __forceinline__ void sr_conv_stage_load(const SrConvParams& p, const 
   using G = SrConvGeom<KS, S, MT, CM>;
 #pragma unroll
   for (int it = 0; it < G::PER_THREAD; ++it) {
-    const int c = c0 + 4 * ((threadIdx.x + it * 256) & 3);
+    const int c = c0 + 4 * ((threadIdx.x + it * 256) % G::Q);
     const bool ok = (offs[it] >= 0) && (c < p.Cin);
     const float* src = in_b + (ok ? offs[it] + c0 : 0);
     if (VEC4) {
@@ -108,7 +113,7 @@ __device__ __forceinline__ void sr_conv_stage_store(float* __restrict__ tile,
 #pragma unroll
   for (int it = 0; it < G::PER_THREAD; ++it) {
     const int e = threadIdx.x + it * 256;
-    if (e < G::ELEMS) *reinterpret_cast<float4*>(&tile[(e >> 2) * SR_LDS_ROW + 4 * (e & 3)]) = stg[it];
+    if (e < G::ELEMS) *reinterpret_cast<float4*>(&tile[(e / G::Q) * G::ROW + 4 * (e % G::Q)]) = stg[it];
   }
 }
 
@@ -136,7 +141,9 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
   using G = SrConvGeom<KS, S, MT, CM>;
   constexpr int TH = G::TH, HW = G::HW, RM = G::RM;
   constexpr int PAD = KS / 2;
-  constexpr int STEPS = KS * KS * 2;  // (tap, 8-channel group) steps per 16-channel slab
+  constexpr int GPS = G::CK / 8;        // 8-channel groups per slab
+  constexpr int STEPS = KS * KS * GPS;  // (tap, 8-channel group) steps per slab
+  constexpr int ROW = G::ROW;
   __shared__ __attribute__((aligned(16))) float tiles[2][G::TILE_FLOATS];
 
   const int lane = threadIdx.x & 63;
@@ -146,9 +153,9 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
   int a_off[MT];  // this lane's A-fragment base inside the halo tile (M-tile m = output row wave*MT + m)
 #pragma unroll
   for (int m = 0; m < MT; ++m)
-    a_off[m] = ((((wave * MT + m) * RM + i / CM) * S) * HW + (i % CM) * S) * SR_LDS_ROW + 4 * kk;
+    a_off[m] = ((((wave * MT + m) * RM + i / CM) * S) * HW + (i % CM) * S) * ROW + 4 * kk;
   const int64_t rec = (int64_t)2 * p.Co_pad;  // float4 per (tap, g) weight record
-  const int chunks = p.G >> 1;
+  const int chunks = p.G / GPS;
 
   // Weight (B) fragments stream from L2 with a prefetch distance of PD steps through NB rotating
   // register sets.  VMEM returns in order, so the slab staging loads are issued when the next PD
@@ -164,8 +171,8 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
   SrTileCoord t = sr_conv_tile<TH, NT, CM>(p, work);
   const float4* wp4 = reinterpret_cast<const float4*>(p.wp) + (kk * p.Co_pad + t.co0 + i);
   auto load_b = [&](const float4* base, int ch, int s, float4 (&dst)[NT]) {
-    const int tap = s >> 1, g = s & 1;
-    const float4* wrec = base + (int64_t)(tap * p.G + 2 * ch + g) * rec;
+    const int tap = s / GPS, g = s % GPS;
+    const float4* wrec = base + (int64_t)(tap * p.G + GPS * ch + g) * rec;
 #pragma unroll
     for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
   };
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
       if (more) {
         if (last) sr_conv_stage_setup<KS, S, MT, CM>(p, tn.oy0 * S - PAD, tn.ox0 * S - PAD, offs);  // next tile
         sr_conv_stage_load<KS, S, MT, CM, VEC4>(p, p.in + (int64_t)(last ? tn.b : t.b) * p.in_sb,
-                                            last ? 0 : (ch + 1) * SR_CK, offs, stg);
+                                            last ? 0 : (ch + 1) * G::CK, offs, stg);
       }
       const float4* wnext = last ? wp4n : wp4;
       const int chn = last ? 0 : ch + 1;
@@ -213,11 +220,11 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
         if (s + PD < STEPS) load_b(wp4, ch, s + PD, b_f[(s + PD) % NB]);
         else if (more) load_b(wnext, chn, s + PD - STEPS, b_f[(s + PD) % NB]);
         if (s + 1 < STEPS) {
-          const int tap = (s + 1) >> 1, g = (s + 1) & 1;
+          const int tap = (s + 1) / GPS, g = (s + 1) % GPS;
           const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            a_f[ca ^ 1][m] = *reinterpret_cast<const float4*>(&tile[a_off[m] + (ky * HW + kx) * SR_LDS_ROW + 8 * g]);
+            a_f[ca ^ 1][m] = *reinterpret_cast<const float4*>(&tile[a_off[m] + (ky * HW + kx) * ROW + 8 * g]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -363,14 +370,16 @@ __global__ void sr_upsample2x_kernel(const float* __restrict__ in, int64_t in_sb
 
 extern "C" size_t sr_conv_packed_weight_floats(int Cout, int Cin, int ksize) {
   if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
-  const size_t G = (size_t)((Cin + SR_CK - 1) / SR_CK) * 2, Co_pad = (size_t)((Cout + 31) / 32) * 32;
+  const int ck = sr_ck(ksize);
+  const size_t G = (size_t)((Cin + ck - 1) / ck) * (ck / 8), Co_pad = (size_t)((Cout + 31) / 32) * 32;
   return (size_t)ksize * ksize * G * 2 * Co_pad * 4;
 }
 
 extern "C" int sr_conv_pack_weights(const float* weight, int Cout, int Cin, int ksize, float* packed, void* stream_) {
   if (!weight || !packed || Cout <= 0 || Cin <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (ksize != 1 && ksize != 3) return SR_ERR_UNSUPPORTED;
-  const int G = ((Cin + SR_CK - 1) / SR_CK) * 2, Co_pad = ((Cout + 31) / 32) * 32;
+  const int ck = sr_ck(ksize);
+  const int G = ((Cin + ck - 1) / ck) * (ck / 8), Co_pad = ((Cout + 31) / 32) * 32;
   hipLaunchKernelGGL(sr_conv_pack_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream_, weight, packed, Cout, Cin,
                      ksize * ksize, G, Co_pad);
   return sr_hip_rc(hipGetLastError());
@@ -447,7 +456,7 @@ extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int 
   p.Ho = (H + 2 * pad - ksize) / stride + 1;
   p.Wo = (W + 2 * pad - ksize) / stride + 1;
   p.Co_pad = ((Cout + 31) / 32) * 32;
-  p.G = ((Cin + SR_CK - 1) / SR_CK) * 2;
+  p.G = ((Cin + sr_ck(ksize) - 1) / sr_ck(ksize)) * (sr_ck(ksize) / 8);
   p.slope = leaky_slope;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0);

@@ -214,11 +214,12 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
       r2 = iK[8] * px + iK[9] * py + iK[10];
     }
     // current-frame ray F.normalize(X) (cost_volume.py:641-651, eps 1e-12): X = d * r, so the ray does not depend
-    // on the plane beyond rounding; it is formed from the chunk's first plane and shared by the chunk.
+    // on the plane beyond rounding; it is formed from plane 0 for every chunk (so results do not depend on how
+    // planes are chunked into work units) and shared by all planes.
     float cr0, cr1, cr2, crn0, crn1, crn2;
     {
 #pragma clang fp contract(off)
-      const float d0 = plane_ptr[j0 * p.planes.sd];
+      const float d0 = plane_ptr[0];
       const float X0 = d0 * r0, X1 = d0 * r1, X2 = d0 * r2;
       const float cden = fmaxf(sqrtf((X0 * X0 + X1 * X1) + X2 * X2), 1e-12f);
       cr0 = X0 / cden; cr1 = X1 / cden; cr2 = X2 / cden;
