@@ -121,12 +121,13 @@ struct SrTileCoord { int b, co0, oy0, ox0; };
 
 template <int TH, int NT, int CM>
 __device__ __forceinline__ SrTileCoord sr_conv_tile(const SrConvParams& p, int work) {
-  // work = ((b * co_blocks + cb) * tiles_y + ty) * tiles_x + tx
+  // work = ((b * tiles_y + ty) * tiles_x + tx) * co_blocks + cb: the output-channel blocks of one pixel tile are
+  // neighbours in the work order, so they run at about the same time and share the input tile through L2
   SrTileCoord t;
+  const int cb = work % p.co_blocks; work /= p.co_blocks;
   const int tx = work % p.tiles_x; work /= p.tiles_x;
-  const int ty = work % p.tiles_y; work /= p.tiles_y;
-  const int cb = work % p.co_blocks;
-  t.b = work / p.co_blocks;
+  const int ty = work % p.tiles_y;
+  t.b = work / p.tiles_y;
   t.co0 = cb * (32 * NT);
   t.oy0 = ty * TH;
   t.ox0 = tx * CM;
@@ -397,12 +398,11 @@ static int sr_num_cus() {
 }
 
 template <int KS, int S, int MT, int CM>
-static int sr_conv_launch(SrConvParams& p, int B, hipStream_t stream) {
+static int sr_conv_launch(SrConvParams& p, int B, int nt, hipStream_t stream) {
   using G = SrConvGeom<KS, S, MT, CM>;
   p.tiles_x = (p.Wo + CM - 1) / CM;
   p.tiles_y = (p.Ho + G::TH - 1) / G::TH;
-  const int nt = (p.Co_pad % 64 == 0) ? 2 : 1;
-  p.co_blocks = p.Co_pad / (32 * nt);
+  p.co_blocks = (p.Co_pad + 32 * nt - 1) / (32 * nt);
   p.total_tiles = p.tiles_x * p.tiles_y * p.co_blocks * B;
   int blocks = sr_num_cus() * 2;  // persistent grid: 2 workgroups per CU (register / LDS limit)
   if (blocks > p.total_tiles) blocks = p.total_tiles;
@@ -415,26 +415,43 @@ static int sr_conv_launch(SrConvParams& p, int B, hipStream_t stream) {
   return sr_hip_rc(hipGetLastError());
 }
 
-// Tile-shape choice: minimise  rounds(tiles / resident workgroups) x MFMA work per tile  (padding waste
-// and tail quantisation both show up in it).  Candidates: (MT=2, CM=32) 8x32, (MT=1, CM=32) 4x32,
-// (MT=1, CM=8) 16x8 output pixels per workgroup.
-static int sr_conv_pick(const SrConvParams& p, int B, int stride) {
-  const int slots = sr_num_cus() * 2;
-  const int nt = (p.Co_pad % 64 == 0) ? 2 : 1;
-  const int cob = p.Co_pad / (32 * nt);
+// Tile-shape choice.  Tiles are indivisible and the MFMA pipes of a CU are shared by its resident
+// workgroups, so the launch time is ~ (max tiles on one CU) x (MFMA work of a tile): minimise
+//   ceil(tiles / CUs) * (MT * NT + per-tile overhead).
+// Candidates: pixels 8x32 (MT=2), 4x32 (MT=1), 16x8 (MT=1, 4x8 M-tiles) x output channels 64 (NT=2) or 32 (NT=1).
+// Padding waste (partial tiles) and tail quantisation both show up in the tile count.
+struct SrConvCfg { int shape, nt; };
+static SrConvCfg sr_conv_pick(const SrConvParams& p, int B, int stride, int ksize) {
+  const int cus = sr_num_cus();
+  // staging cost per pixel tile relative to its MFMA work: negligible for 3x3 (one slab feeds 9 taps), large for 1x1
+  const double stage_w = ksize == 1 ? 0.6 : 0.0;
   const int th[3] = {8, 4, 16}, tw[3] = {32, 32, 8}, mt[3] = {2, 1, 1};
-  int best = -1;
-  double best_cost = 0;
+  SrConvCfg best = {1, 1};
+  double best_cost = -1;
   for (int c = 0; c < 3; ++c) {
     if (stride == 2 && c == 0) continue;  // the 8x32 stride-2 halo does not fit LDS twice
-    const long tiles = (long)((p.Wo + tw[c] - 1) / tw[c]) * ((p.Ho + th[c] - 1) / th[c]) * cob * B;
-    const long rounds = (tiles + slots - 1) / slots;
-    // per-tile cost ~ MFMA work (mt); measured: a 4x32 tile costs 0.43x an 8x32 tile, so ties go to
-    // the smaller tile (finer tail)
-    const double cost = (double)rounds * (mt[c] == 2 ? 2.0 : 0.86);
-    if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
+    for (int nt = 2; nt >= 1; --nt) {
+      if (nt == 2 && p.Co_pad % 64 != 0) continue;
+      const long tiles = (long)((p.Wo + tw[c] - 1) / tw[c]) * ((p.Ho + th[c] - 1) / th[c]) *
+                         ((p.Co_pad + 32 * nt - 1) / (32 * nt)) * B;
+      // + 0.04*nt: weight fragments come from L2 (VMEM) per N-tile, A fragments from LDS -- measured: at equal
+      // MFMA work an 8x32x32 tile is ~4 % faster than a 4x32x64 tile
+      const double cost = (double)((tiles + cus - 1) / cus) * (mt[c] * nt + 0.12 + 0.04 * nt + stage_w * mt[c]);
+      if (best_cost < 0 || cost < best_cost) { best = {c, nt}; best_cost = cost; }
+    }
   }
   return best;
+}
+
+static SrConvCfg sr_conv_cfg(const SrConvParams& p, int B, int stride, int ksize) {
+  SrConvCfg cfg = sr_conv_pick(p, B, stride, ksize);
+  const char* e = getenv("SR_CONV_TILE");  // ablation override: shape + 10 * nt (nt = 0: keep)
+  if (e) {
+    const int v = atoi(e), shape = v % 10, nt = v / 10;
+    if (shape >= 0 && shape <= 2 && !(stride == 2 && shape == 0)) cfg.shape = shape;
+    if (nt == 1 || (nt == 2 && p.Co_pad % 64 == 0)) cfg.nt = nt;
+  }
+  return cfg;
 }
 
 extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
@@ -461,25 +478,24 @@ extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int 
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0);
   hipStream_t stream = (hipStream_t)stream_;
-  int cfg = sr_conv_pick(p, B, stride);
-  { static int force = -2; if (force == -2) { const char* e = getenv("SR_CONV_TILE"); force = e ? atoi(e) : -1; }
-    if (force >= 0 && !(stride == 2 && force == 0)) cfg = force; }
+  const SrConvCfg cfg = sr_conv_cfg(p, B, stride, ksize);
+  const int c = cfg.shape, nt = cfg.nt;
   if (ksize == 3 && stride == 1) {
-    if (cfg == 0) return sr_conv_launch<3, 1, 2, 32>(p, B, stream);
-    if (cfg == 1) return sr_conv_launch<3, 1, 1, 32>(p, B, stream);
-    return sr_conv_launch<3, 1, 1, 8>(p, B, stream);
+    if (c == 0) return sr_conv_launch<3, 1, 2, 32>(p, B, nt, stream);
+    if (c == 1) return sr_conv_launch<3, 1, 1, 32>(p, B, nt, stream);
+    return sr_conv_launch<3, 1, 1, 8>(p, B, nt, stream);
   }
   if (ksize == 3 && stride == 2) {
-    if (cfg == 1) return sr_conv_launch<3, 2, 1, 32>(p, B, stream);
-    return sr_conv_launch<3, 2, 1, 8>(p, B, stream);
+    if (c == 1) return sr_conv_launch<3, 2, 1, 32>(p, B, nt, stream);
+    return sr_conv_launch<3, 2, 1, 8>(p, B, nt, stream);
   }
   if (ksize == 1 && stride == 1) {
-    if (cfg == 0) return sr_conv_launch<1, 1, 2, 32>(p, B, stream);
-    if (cfg == 1) return sr_conv_launch<1, 1, 1, 32>(p, B, stream);
-    return sr_conv_launch<1, 1, 1, 8>(p, B, stream);
+    if (c == 0) return sr_conv_launch<1, 1, 2, 32>(p, B, nt, stream);
+    if (c == 1) return sr_conv_launch<1, 1, 1, 32>(p, B, nt, stream);
+    return sr_conv_launch<1, 1, 1, 8>(p, B, nt, stream);
   }
-  if (cfg == 1) return sr_conv_launch<1, 2, 1, 32>(p, B, stream);
-  return sr_conv_launch<1, 2, 1, 8>(p, B, stream);
+  if (c == 1) return sr_conv_launch<1, 2, 1, 32>(p, B, nt, stream);
+  return sr_conv_launch<1, 2, 1, 8>(p, B, nt, stream);
 }
 
 // Symbol of the kernel instantiation sr_conv2d_nhwc_fwd picks for these arguments (for profilers / bench).
@@ -491,10 +507,8 @@ extern "C" const char* sr_conv_kernel_name(int B, int H, int W, int Cin, int Cou
   p.Ho = (H + 2 * pad - ksize) / stride + 1;
   p.Wo = (W + 2 * pad - ksize) / stride + 1;
   p.Co_pad = ((Cout + 31) / 32) * 32;
-  int cfg = sr_conv_pick(p, B, stride);
-  { const char* e = getenv("SR_CONV_TILE"); const int force = e ? atoi(e) : -1;
-    if (force >= 0 && !(stride == 2 && force == 0)) cfg = force; }
-  const int mt = cfg == 0 ? 2 : 1, cm = cfg == 2 ? 8 : 32, nt = (p.Co_pad % 64 == 0) ? 2 : 1;
+  const SrConvCfg cfg = sr_conv_cfg(p, B, stride, ksize);
+  const int mt = cfg.shape == 0 ? 2 : 1, cm = cfg.shape == 2 ? 8 : 32, nt = cfg.nt;
   snprintf(buf, sizeof(buf), "sr_conv_kernel<%d, %d, %d, %d, %d, %s>", ksize, stride, mt, nt, cm,
            (aligned16 && Cin % 4 == 0) ? "true" : "false");
   return buf;
