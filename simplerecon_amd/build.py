@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libsimplerecon_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
-         "-Wall", "-Wno-unused-function", "-fno-fast-math"]
+         "-Wall", "-Wno-unused-function", "-fno-fast-math"] + os.environ.get("SR_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():

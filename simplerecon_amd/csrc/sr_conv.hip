@@ -24,6 +24,14 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// tuning knobs: weight prefetch depth with one N-tile, residual prefetch in the last slab
+#ifndef SR_NB1
+#define SR_NB1 6
+#endif
+#ifndef SR_RES_PF
+#define SR_RES_PF 0
+#endif
+
 // input channels per LDS slab: 16 for 3x3 convs (18 k-steps per slab), 64 for 1x1 convs (8 k-steps per
 // slab instead of 2: a 1x1 slab of 16 channels is all barrier).  LDS rows carry 4 floats of padding:
 // row strides of 20 and 68 floats are both conflict-free for the 16-byte A-fragment reads.
@@ -161,9 +169,13 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
   // Weight (B) fragments stream from L2 with a prefetch distance of PD steps through NB rotating
   // register sets.  VMEM returns in order, so the slab staging loads are issued when the next PD
   // steps' weights are already in flight: nothing younger than them is needed for >= PD steps.
-  constexpr int PD = (STEPS % 3 == 0) ? 2 : 1;
-  constexpr int NB = PD + 1;
-  static_assert(STEPS % NB == 0, "rotating buffers must line up across slabs");
+  // (deeper with one N-tile, where a buffer is 4 VGPRs: 5 steps ~ 2.5-5k cycles also cover the residual
+  // prefetch of the epilogue, which is issued in front of the last slab's weight stream)
+  constexpr int NB = (NT == 1) ? (STEPS % 6 == 0 ? SR_NB1 : STEPS % 4 == 0 ? 4 : STEPS % 3 == 0 ? 3 : 2)
+                               : (STEPS % 3 == 0 ? 3 : 2);
+  constexpr int PD = NB - 1;
+  static_assert(STEPS % NB == 0 && PD < STEPS + 1, "rotating buffers must line up across slabs");
+  constexpr bool RES_PF = (MT * NT <= 2) && SR_RES_PF;  // residual values of the tile prefetched during its last slab
   float4 b_f[NB][NT], a_f[2][MT], stg[G::PER_THREAD];
   int offs[G::PER_THREAD];
 
@@ -200,6 +212,8 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    float rpf[RES_PF ? MT : 1][RES_PF ? NT : 1][16];  // prefetched residual values (RES_PF only)
+    const float* __restrict__ resp = (p.res && !(p.debug & 2)) ? p.res + (int64_t)t.b * p.res_sb : nullptr;
 
     for (int ch = 0; ch < chunks; ++ch) {
       const float* tile = tiles[buf];
@@ -212,6 +226,27 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
       }
       const float4* wnext = last ? wp4n : wp4;
       const int chn = last ? 0 : ch + 1;
+      if (RES_PF && last) {
+        // residual of THIS tile: 16 x MT x NT dword loads, branch-free (masked), 5 k-steps of slack before the
+        // in-order VMEM queue is needed again
+#pragma unroll
+        for (int m = 0; m < (RES_PF ? MT : 0); ++m) {
+          const int oyb = t.oy0 + (wave * MT + m) * RM;
+          const int pixb = oyb * p.Wo + t.ox0 + 4 * kk;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int co = t.co0 + 32 * n + i;
+            const unsigned rb = (unsigned)(pixb * p.res_sp + co);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
+              const bool ok = (resp != nullptr) & (co < p.Cout) & (oyb + row < p.Ho) & (t.ox0 + colc + 4 * kk < p.Wo);
+              const float v = (resp ? resp : p.in)[ok ? rb + (unsigned)((row * p.Wo + colc) * p.res_sp) : 0u];
+              rpf[m][n][r] = ok ? v : 0.0f;
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m) a_f[0][m] = *reinterpret_cast<const float4*>(&tile[a_off[m]]);
 #pragma unroll
@@ -249,10 +284,9 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
     // 4*kk part is per lane, the rest folds to immediates.  32-bit element offsets off one scalar base per
     // tensor; all residual loads of a fragment are issued before its stores (out / residual may alias).
     {
-      const float* __restrict__ resp = p.res ? p.res + (int64_t)t.b * p.res_sb : nullptr;
       float* __restrict__ outp = p.out + (int64_t)t.b * p.out_sb;
       const int osp = p.out_sp, rsp = p.res_sp;
-      const bool no_res = (resp == nullptr) || (p.debug & 2);
+      const bool no_res = (resp == nullptr);
       // interior tiles (workgroup-uniform test) take a branch-free path
       const bool full = (t.oy0 + TH <= p.Ho) && (t.ox0 + CM <= p.Wo) && (t.co0 + 32 * NT <= p.Cout) && !(p.debug & 1);
 #pragma unroll
@@ -266,8 +300,13 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
           const float bv = (p.bias && okc) ? p.bias[co] : 0.0f;
           const unsigned ob = (unsigned)(pixb * osp + co), rb = (unsigned)(pixb * rsp + co);
           float rv[16];
+          if (RES_PF) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = rpf[RES_PF ? m : 0][RES_PF ? n : 0][r];
+          }
           if (full) {
-            if (!no_res) {
+            if (RES_PF) {
+            } else if (!no_res) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
@@ -290,7 +329,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
             for (int r = 0; r < 16; ++r) {
               const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
               ok[r] = okc && (oyb + row < p.Ho) && (t.ox0 + colc + 4 * kk < p.Wo);
-              rv[r] = (!no_res && ok[r]) ? resp[rb + (unsigned)((row * p.Wo + colc) * rsp)] : 0.0f;
+              if (!RES_PF) rv[r] = (!no_res && ok[r]) ? resp[rb + (unsigned)((row * p.Wo + colc) * rsp)] : 0.0f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
