@@ -79,3 +79,35 @@ def test_forward_api_with_stand_in_encoders():
             model.hot_path([t.requires_grad_() for t in model.encoder(cur["image_b3hw"])], inp["cur_feats"],
                            inp["src_feats"].requires_grad_(), inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
                            inp["cur_invK"])
+
+
+def test_full_size_hot_path_properties():
+    """BASELINE.json configs[2] shapes (640x480, 7 views, 64 planes), batch 2: size-independent properties --
+    finite outputs, run-to-run determinism, independence of the frames of a batch, positive depths that are
+    exp(log-depth), mask/argmax consistency of the sweep outputs."""
+    B, K, C, D, h, w = 2, 7, 16, 64, 120, 160
+    opts = dm.default_options(image_width=4 * w, image_height=4 * h, model_num_views=K + 1, matching_num_depth_bins=D)
+    model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(), matching_encoder=dm.StandInMatchingEncoder())
+    synthetic.seeded_fill_(model.cost_volume_net, seed=1)
+    synthetic.seeded_fill_(model.depth_decoder, seed=2)
+    synthetic.seeded_fill_(model.cost_volume.mlp, seed=3)
+    model = model.to(DEV).eval()
+    inp = synthetic.cost_volume_inputs(B, K, C, h, w, seed=11, device=DEV)
+    pyr = synthetic.image_prior_pyramid(B, h, w, seed=11, device=DEV)
+
+    def run(sl=slice(None)):
+        with torch.inference_mode():
+            return model.hot_path([f[sl] for f in pyr], inp["cur_feats"][sl], inp["src_feats"][sl],
+                                  inp["src_extrinsics"][sl], inp["src_poses"][sl], inp["src_Ks"][sl],
+                                  inp["cur_invK"][sl], return_mask=True)
+    a, b = run(), run()
+    one = run(slice(1, 2))
+    for i in range(4):
+        k = f"depth_pred_s{i}_b1hw"
+        assert a[k].shape == (B, 1, (2 * h) >> i, (2 * w) >> i)
+        assert torch.isfinite(a[k]).all() and bool((a[k] > 0).all())
+        assert torch.equal(a[k], b[k]), "hot path is not deterministic"
+        assert torch.equal(a[k], torch.exp(a[k.replace("depth_", "log_depth_")]))
+        assert torch.equal(one[k][0], a[k][1]), "frames of a batch are not independent"
+    assert torch.equal(a["lowest_cost_bhw"], b["lowest_cost_bhw"]) and a["overall_mask_bhw"].dtype == torch.bool
+    assert 0.5 < float(a["overall_mask_bhw"].float().mean()) <= 1.0
