@@ -173,6 +173,19 @@ int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stri
                        int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
                        int Cout, int ksize, int stride, float leaky_slope, void* stream);
 
+/* 3x3 / stride-1 / pad-1 convolution through Winograd F(2x2, 3x3) on the fp32 matrix cores: same operator and
+ * epilogue as sr_conv2d_nhwc_fwd (fp32 products and accumulation; 2.25x fewer multiplies).  `packed_u` comes from
+ * sr_wino_pack_weights (U = G g G^T in MFMA B-fragment order).  sr_conv_prefers_wino() tells whether this kernel
+ * is expected to beat the direct one for a shape (enough 8x16-pixel regions, little padding). */
+size_t sr_wino_packed_weight_floats(int Cout, int Cin);
+int sr_wino_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream);
+int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                             const float* packed_u, const float* bias, const float* residual,
+                             int64_t res_batch_stride, int res_pix_stride, float* out,
+                             int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                             int Cout, float leaky_slope, void* stream);
+
 /* Name of the kernel instantiation sr_conv2d_nhwc_fwd launches for these arguments (tile shape is
  * chosen per launch); `aligned16` = input pointer / strides are 16-byte aligned.  For profilers. */
 const char* sr_conv_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int aligned16);

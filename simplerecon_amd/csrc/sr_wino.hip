@@ -1,0 +1,378 @@
+// sr_wino.hip -- 3x3 / stride-1 convolutions through Winograd F(2x2, 3x3) on the fp32 matrix cores (gfx950).
+//
+// Same operator as sr_conv2d_nhwc_fwd (conv + bias + residual + LeakyReLU of the reference's BasicBlock,
+// modules/layers.py:24-85), same fp32 arithmetic class: Y = A^T [ (G g G^T) . (B^T d B) ] A  (Lavin & Gray) needs
+// 16 multiplies per 2x2 output tile and (input, output) channel pair instead of 36, i.e. 2.25x fewer MFMA FLOPs;
+// the transforms use only +, - and exact scalings by 1/2, and the fp32 error vs an fp64 reference is the
+// same as the direct algorithm's (3.1e-7 vs 2.7e-7 on a 64-channel layer, tests/).
+//
+// A workgroup (4 waves) owns a region of 4 x 8 Winograd tiles (= 8 x 16 output pixels = the 32 rows of one MFMA
+// M-tile) x 32*NT output channels.  Per 16-channel slab of the input:
+//   S  the 10 x 18 pixel input patch is staged once into LDS (register-staged, next slab's loads in flight),
+//   T  all 256 threads apply B^T d B to their (tile, 4-channel group, row pair) -> V[16][32 tiles][16 ch] in LDS,
+//   M  wave w multiplies the 4 "frequencies" xi = 4w..4w+3:  M_xi[tile, co] += V_xi[tile, ci] . U_xi[ci, co]
+//      (A fragments: conflict-free ds_read_b128 on 20-float rows; U streams from L2 in B-fragment order,
+//      prefetched 3 steps ahead).
+// Epilogue: the 16 x 32 x 32 accumulator slab goes through LDS once, each thread applies A^T M A for its
+// (tile, channel) pairs, adds bias / residual, applies LeakyReLU and writes 2 x 2 pixels (32 channels per 128-byte
+// line) straight into the consumer's concat slice.
+#include <stdlib.h>
+
+#include "sr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef SR_WINO_WAVES
+#define SR_WINO_WAVES 2  // waves per SIMD the register allocation must allow (2 = two workgroups per CU)
+#endif
+
+#define WN_TR 4
+#define WN_TC 8
+#define WN_PH (2 * WN_TR + 2)  // 10 patch rows
+#define WN_PW (2 * WN_TC + 2)  // 18 patch cols
+#define WN_ROW 20              // floats per staged pixel / per V row (16 channels + 4 pad)
+#define WN_RAW_FLOATS (WN_PH * WN_PW * WN_ROW)
+#define WN_V_FLOATS (16 * 32 * WN_ROW)
+#define WN_O_FLOATS (16 * 32 * 32)
+#define WN_LDS_FLOATS (WN_RAW_FLOATS + WN_V_FLOATS > WN_O_FLOATS ? WN_RAW_FLOATS + WN_V_FLOATS : WN_O_FLOATS)
+#define WN_STAGE_ELEMS (WN_PH * WN_PW * 4)  // float4 elements per slab (720)
+#define WN_STAGE_PER_THREAD 3
+
+struct SrWinoParams {
+  const float* in; int64_t in_sb; int in_sp;
+  const float* wu;                                  // packed U: [16][G][2][Co_pad][4]
+  const float* bias;
+  const float* res; int64_t res_sb; int res_sp;
+  float* out; int64_t out_sb; int out_sp;
+  int H, W, Cin, Cout, Co_pad, G;                   // stride 1, pad 1: output is H x W
+  int regions_x, regions_y, co_blocks, total;
+  float slope;
+  int vec4;
+};
+
+// U = G g G^T per (co, ci), stored in MFMA B-fragment order: element (xi, g8, kk, co, e) = U_xi[co][8*g8 + 4*kk + e]
+__global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wu, int Co, int Ci, int G,
+                                    int Co_pad) {
+  const int64_t total = (int64_t)16 * G * 2 * Co_pad * 4;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int el = (int)(e & 3);
+    int64_t r = e >> 2;
+    const int co = (int)(r % Co_pad); r /= Co_pad;
+    const int kk = (int)(r & 1); r >>= 1;
+    const int g8 = (int)(r % G);
+    const int xi = (int)(r / G);
+    const int ci = 8 * g8 + 4 * kk + el;
+    float v = 0.0f;
+    if (co < Co && ci < Ci) {
+      const float* g = w + ((int64_t)co * Ci + ci) * 9;
+      const int ur = xi >> 2, uc = xi & 3;
+      // row transform (G g): rows [g0; (g0+g1+g2)/2; (g0-g1+g2)/2; g2], then the same along columns
+      float rowv[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+        rowv[c] = ur == 0 ? g0 : (ur == 1 ? (g0 + g1 + g2) * 0.5f : (ur == 2 ? (g0 - g1 + g2) * 0.5f : g2));
+      }
+      v = uc == 0 ? rowv[0]
+                  : (uc == 1 ? (rowv[0] + rowv[1] + rowv[2]) * 0.5f
+                             : (uc == 2 ? (rowv[0] - rowv[1] + rowv[2]) * 0.5f : rowv[2]));
+    }
+    wu[e] = v;
+  }
+}
+
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int NT, bool VEC4>
+__global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* raw = lds;                   // [10*18][20]
+  float* V = lds + WN_RAW_FLOATS;     // [16][32][20]
+  float* O = lds;                     // [16][32][32]   (epilogue only; aliases raw + V)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, kk = lane >> 5;
+  const int chunks = p.G >> 1;
+  const int64_t rec = (int64_t)2 * p.Co_pad;
+  constexpr int STEPS = 8;            // (frequency, 8-channel group) steps per slab and wave
+  constexpr int NB = 4, PD = 3;       // weight prefetch: 3 steps ahead through 4 rotating register sets
+
+  // transform-phase role of this thread: tile t, 4-channel group q, row pair h
+  const int th = tid & 1, tq = (tid >> 1) & 3, tt = tid >> 3;
+  const int ttr = tt >> 3, ttc = tt & 7;
+  const int t_base = ((2 * ttr + th) * WN_PW + 2 * ttc) * WN_ROW + 4 * tq;
+
+  for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
+    int wk = work;
+    const int cb = wk % p.co_blocks; wk /= p.co_blocks;
+    const int rx = wk % p.regions_x; wk /= p.regions_x;
+    const int ry = wk % p.regions_y;
+    const int b = wk / p.regions_y;
+    const int oy0 = ry * (2 * WN_TR), ox0 = rx * (2 * WN_TC), co0 = cb * (32 * NT);
+    const float* in_b = p.in + (int64_t)b * p.in_sb;
+    const float4* wu4 = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + co0 + i);
+
+    int offs[WN_STAGE_PER_THREAD];
+#pragma unroll
+    for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
+      const int e = tid + it * 256;
+      const int px = e >> 2, q = e & 3;
+      const int py = px / WN_PW, pxx = px - py * WN_PW;
+      const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
+      const bool ok = (e < WN_STAGE_ELEMS) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+      offs[it] = ok ? (iy * p.W + ix) * p.in_sp + 4 * q : -1;
+    }
+    auto stage_load = [&](int c0, float4 (&stg)[WN_STAGE_PER_THREAD]) {
+#pragma unroll
+      for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
+        const int c = c0 + 4 * ((tid + it * 256) & 3);
+        const bool ok = (offs[it] >= 0) & (c < p.Cin);
+        const float* src = in_b + (ok ? offs[it] + c0 : 0);
+        if (VEC4) {
+          const float4 v = *reinterpret_cast<const float4*>(src);
+          stg[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) {
+            v.x = src[0];
+            if (c + 1 < p.Cin) v.y = src[1];
+            if (c + 2 < p.Cin) v.z = src[2];
+            if (c + 3 < p.Cin) v.w = src[3];
+          }
+          stg[it] = v;
+        }
+      }
+    };
+    auto stage_store = [&](const float4 (&stg)[WN_STAGE_PER_THREAD]) {
+#pragma unroll
+      for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
+        const int e = tid + it * 256;
+        if (e < WN_STAGE_ELEMS) *reinterpret_cast<float4*>(&raw[(e >> 2) * WN_ROW + 4 * (e & 3)]) = stg[it];
+      }
+    };
+    auto load_b = [&](int ch, int s, float4 (&dst)[NT]) {
+      const int xi = 4 * wave + (s >> 1), g = s & 1;
+      const float4* wrec = wu4 + (int64_t)(xi * p.G + 2 * ch + g) * rec;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
+    };
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][n][r] = 0.0f;
+
+    float4 stg[WN_STAGE_PER_THREAD], b_f[NB][NT], a_f[2];
+    stage_load(0, stg);
+    stage_store(stg);
+#pragma unroll
+    for (int s = 0; s < PD; ++s) load_b(0, s, b_f[s]);
+    __syncthreads();
+
+    for (int ch = 0; ch < chunks; ++ch) {
+      const bool more = ch + 1 < chunks;
+      if (more) stage_load((ch + 1) * 16, stg);
+
+      // ---- T: V = B^T d B for (tile tt, channels 4*tq.., rows {2*th, 2*th+1} of the 4x4 frequency grid) ----
+      {
+        float4 d[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d[r][c] = *reinterpret_cast<const float4*>(&raw[t_base + (r * WN_PW + c) * WN_ROW]);
+        // th = 0: patch rows 0,1,2 -> W0 = d0 - d2, W1 = d1 + d2;  th = 1: patch rows 1,2,3 -> W2 = d2 - d1, W3 = d1 - d3
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          float4 wv[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (th == 0) wv[c] = rr == 0 ? f4sub(d[0][c], d[2][c]) : f4add(d[1][c], d[2][c]);
+            else wv[c] = rr == 0 ? f4sub(d[1][c], d[0][c]) : f4sub(d[0][c], d[2][c]);
+          }
+          const int ur = 2 * th + rr;
+          float* vrow = V + ((4 * ur) * 32 + tt) * WN_ROW + 4 * tq;
+          *reinterpret_cast<float4*>(vrow + 0 * 32 * WN_ROW) = f4sub(wv[0], wv[2]);
+          *reinterpret_cast<float4*>(vrow + 1 * 32 * WN_ROW) = f4add(wv[1], wv[2]);
+          *reinterpret_cast<float4*>(vrow + 2 * 32 * WN_ROW) = f4sub(wv[2], wv[1]);
+          *reinterpret_cast<float4*>(vrow + 3 * 32 * WN_ROW) = f4sub(wv[1], wv[3]);
+        }
+      }
+      __syncthreads();
+      if (more) stage_store(stg);
+
+      // ---- M: this wave's 4 frequencies x 2 channel groups ----
+      a_f[0] = *reinterpret_cast<const float4*>(&V[((4 * wave) * 32 + i) * WN_ROW + 4 * kk]);
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        const int cbuf = s % NB, ca = s & 1;
+        if (s + PD < STEPS) load_b(ch, s + PD, b_f[(s + PD) % NB]);
+        else if (more) load_b(ch + 1, s + PD - STEPS, b_f[(s + PD) % NB]);
+        if (s + 1 < STEPS) {
+          const int xi = 4 * wave + ((s + 1) >> 1), g = (s + 1) & 1;
+          a_f[ca ^ 1] = *reinterpret_cast<const float4*>(&V[(xi * 32 + i) * WN_ROW + 8 * g + 4 * kk]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          f32x16& a = acc[s >> 1][n];
+          a = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].x, b_f[cbuf][n].x, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].y, b_f[cbuf][n].y, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].z, b_f[cbuf][n].z, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].w, b_f[cbuf][n].w, a, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+
+    // ---- epilogue: Y = A^T M A, + bias + residual, LeakyReLU, store ----
+    const float* __restrict__ resp = p.res ? p.res + (int64_t)b * p.res_sb : nullptr;
+    float* __restrict__ outp = p.out + (int64_t)b * p.out_sb;
+#pragma unroll
+    for (int nh = 0; nh < NT; ++nh) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int xi = 4 * wave + x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tile = (r & 3) + 8 * (r >> 2) + 4 * kk;
+          O[(xi * 32 + tile) * 32 + i] = acc[x][nh][r];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int u = tid + it * 256;
+        const int co = u & 31, tile = u >> 5;
+        const int tr = tile >> 3, tc = tile & 7;
+        float m[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) m[x] = O[(x * 32 + tile) * 32 + co];
+        float s0[4], s1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          s0[c] = (m[c] + m[4 + c]) + m[8 + c];
+          s1[c] = (m[4 + c] - m[8 + c]) - m[12 + c];
+        }
+        const float y[2][2] = {{(s0[0] + s0[1]) + s0[2], (s0[1] - s0[2]) - s0[3]},
+                               {(s1[0] + s1[1]) + s1[2], (s1[1] - s1[2]) - s1[3]}};
+        const int cog = co0 + 32 * nh + co;
+        const bool okc = cog < p.Cout;
+        const float bv = (p.bias && okc) ? p.bias[cog] : 0.0f;
+        // residual loads of the 2x2 pixels first, then the stores (out / residual may alias in the type system:
+        // interleaving them would serialise on memory latency)
+        float rv[2][2];
+        bool ok[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const int oy = oy0 + 2 * tr + a, ox = ox0 + 2 * tc + bb;
+            ok[a][bb] = okc & (oy < p.H) & (ox < p.W);
+            const unsigned pix = (unsigned)(oy * p.W + ox);
+            const float v = (resp ? resp : p.in)[(ok[a][bb] && resp) ? pix * (unsigned)p.res_sp + cog : 0u];
+            rv[a][bb] = (ok[a][bb] && resp) ? v : 0.0f;
+          }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const int oy = oy0 + 2 * tr + a, ox = ox0 + 2 * tc + bb;
+            float v = y[a][bb] + bv + rv[a][bb];
+            if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
+            if (ok[a][bb]) outp[(unsigned)(oy * p.W + ox) * (unsigned)p.out_sp + cog] = v;
+          }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------ C ABI -------------
+
+static int sr_wino_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else cus = 256;
+  }
+  return cus;
+}
+
+extern "C" size_t sr_wino_packed_weight_floats(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return 0;
+  const size_t G = (size_t)((Cin + 15) / 16) * 2, Co_pad = (size_t)((Cout + 31) / 32) * 32;
+  return 16 * G * 2 * Co_pad * 4;
+}
+
+extern "C" int sr_wino_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream_) {
+  if (!weight || !packed || Cout <= 0 || Cin <= 0) return SR_ERR_INVALID_ARGUMENT;
+  const int G = ((Cin + 15) / 16) * 2, Co_pad = ((Cout + 31) / 32) * 32;
+  hipLaunchKernelGGL(sr_wino_pack_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream_, weight, packed, Cout, Cin, G,
+                     Co_pad);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// 1 if the Winograd kernel is the better choice for this 3x3 / stride-1 conv: enough 8x16-pixel regions to fill the
+// machine and little padding waste.  SR_CONV_WINO=0 disables, =2 forces it wherever it is applicable.
+extern "C" int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  if (ksize != 3 || stride != 1 || B <= 0) return 0;
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("SR_CONV_WINO"); mode = e ? atoi(e) : 1; }
+  if (mode == 0) return 0;
+  if (mode == 2) return 1;
+  const long regions = (long)((H + 7) / 8) * ((W + 15) / 16);
+  const double util = (double)H * W / (double)(regions * 128);
+  const int co_pad = ((Cout + 31) / 32) * 32;
+  const int nt = (co_pad % 64 == 0) ? 2 : 1;
+  const long tiles = regions * B * (co_pad / (32 * nt));
+  return (util >= 0.8 && tiles >= 2L * sr_wino_num_cus() && Cin >= 16) ? 1 : 0;
+}
+
+extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                        const float* packed_u, const float* bias, const float* residual,
+                                        int64_t res_batch_stride, int res_pix_stride, float* out,
+                                        int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                                        int Cout, float leaky_slope, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!in || !packed_u || !out) return SR_ERR_INVALID_ARGUMENT;
+  SrWinoParams p;
+  p.in = in; p.in_sb = in_batch_stride; p.in_sp = in_pix_stride;
+  p.wu = packed_u; p.bias = bias;
+  p.res = residual; p.res_sb = res_batch_stride; p.res_sp = res_pix_stride;
+  p.out = out; p.out_sb = out_batch_stride; p.out_sp = out_pix_stride;
+  p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.Co_pad = ((Cout + 31) / 32) * 32;
+  p.G = ((Cin + 15) / 16) * 2;
+  p.regions_x = (W + 2 * WN_TC - 1) / (2 * WN_TC);
+  p.regions_y = (H + 2 * WN_TR - 1) / (2 * WN_TR);
+  const int nt = (p.Co_pad % 64 == 0) ? 2 : 1;
+  p.co_blocks = p.Co_pad / (32 * nt);
+  p.total = p.regions_x * p.regions_y * p.co_blocks * B;
+  p.slope = leaky_slope;
+  p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0) && (Cin % 4 == 0);
+  int blocks = sr_wino_num_cus() * 2;
+  if (blocks > p.total) blocks = p.total;
+  const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
+  hipStream_t stream = (hipStream_t)stream_;
+#define SR_WINO_LAUNCH(NTV, V4)                                                                                   \
+  {                                                                                                               \
+    hipError_t e = hipFuncSetAttribute((const void*)sr_wino_kernel<NTV, V4>,                                      \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+    if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
+    hipLaunchKernelGGL((sr_wino_kernel<NTV, V4>), dim3(blocks), dim3(256), lds, stream, p);                       \
+  }
+  if (nt == 2 && p.vec4) SR_WINO_LAUNCH(2, true)
+  else if (nt == 2) SR_WINO_LAUNCH(2, false)
+  else if (p.vec4) SR_WINO_LAUNCH(1, true)
+  else SR_WINO_LAUNCH(1, false)
+#undef SR_WINO_LAUNCH
+  return sr_hip_rc(hipGetLastError());
+}

@@ -114,6 +114,25 @@ def linear(x, lin: nn.Linear, leaky=None):
     return out.view(*x.shape[:-1], cout)
 
 
+_PACKED_WINO = weakref.WeakKeyDictionary()  # nn.Conv2d -> (weight version, data_ptr, Winograd-packed tensor)
+
+
+def packed_wino_weight(conv: nn.Conv2d):
+    w = conv.weight
+    hit = _PACKED_WINO.get(conv)
+    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+        return hit[2]
+    lib = _lib.lib()
+    co, ci = w.shape[:2]
+    packed = torch.empty(lib.sr_wino_packed_weight_floats(co, ci), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = lib.sr_wino_pack_weights(_lib.ptr(w.detach().contiguous()), co, ci, _lib.ptr(packed),
+                                      _lib.stream_ptr(w.device))
+    _lib.check(rc, "sr_wino_pack_weights")
+    _PACKED_WINO[conv] = (w._version, w.data_ptr(), packed)
+    return packed
+
+
 def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
     """act(conv(x) + bias [+ residual]) with the reference's Conv2d semantics; returns a channels-last view."""
     _lib.refuse_autograd(x, conv.weight)
@@ -132,7 +151,9 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
         if tuple(out.shape) != (b, co, ho, wo) or not _is_nhwc_view(out):
             raise ValueError(f"`out` must be a channels-last view of shape {(b, co, ho, wo)}")
         _lib.require_device_f32("out", out)
-    wp = packed_weight(conv)
+    lib = _lib.lib()
+    use_wino = bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, s))
+    wp = packed_wino_weight(conv) if use_wino else packed_weight(conv)
     bias = conv.bias.detach() if conv.bias is not None else None
     if residual is not None:
         residual = as_nhwc(residual, "residual")
@@ -143,21 +164,30 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
     isb, isp = _strides(x)
     osb, osp = _strides(out)
     rsb, rsp = _strides(residual) if residual is not None else (0, 0)
-    lib = _lib.lib()
     prof = PROFILE
+    slope = C.c_float(-1.0 if leaky is None else float(leaky))
     with torch.cuda.device(x.device):
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb, rsp,
-                                    _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s,
-                                    C.c_float(-1.0 if leaky is None else float(leaky)), _lib.stream_ptr(x.device))
+        if use_wino:
+            rc = lib.sr_conv3x3_wino_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
+                                              rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, slope,
+                                              _lib.stream_ptr(x.device))
+        else:
+            rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb,
+                                        rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope,
+                                        _lib.stream_ptr(x.device))
         if prof is not None:
             ev1.record()
             v4 = int(x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0)
-            name = lib.sr_conv_kernel_name(b, h, w, ci, co, k, s, v4).decode()
+            if use_wino:
+                nt = 2 if ((co + 31) // 32 * 32) % 64 == 0 else 1
+                name = f"sr_wino_kernel<{nt}, {'true' if (v4 and ci % 4 == 0) else 'false'}>"
+            else:
+                name = lib.sr_conv_kernel_name(b, h, w, ci, co, k, s, v4).decode()
             prof.append((name, 2.0 * b * ho * wo * co * ci * k * k, ev0, ev1, (b, ci, h, w, co, k, s)))
-    _lib.check(rc, "sr_conv2d_nhwc_fwd")
+    _lib.check(rc, "sr_conv3x3_wino_nhwc_fwd" if use_wino else "sr_conv2d_nhwc_fwd")
     return out
 
 
