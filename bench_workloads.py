@@ -203,11 +203,12 @@ class HeroCfg3:
             finally:
                 ops.PROFILE = None
         agg = {}
-        for name, flops, e0, e1, _shape in rec:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+        for name, flops, e0, e1, _shape, executed in rec:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += e0.elapsed_time(e1) * 1e-3
+            a[3] += executed if executed is not None else flops
         return agg
 
     def _mlp_sweep_time(self, n):
@@ -238,18 +239,25 @@ class HeroCfg3:
         agg = self._profile_convs(n)
         self._conv_agg = agg
         name = max(agg, key=lambda k: agg[k][2])
-        calls, flops, t = agg[name]
+        calls, flops, t, executed = agg[name]
         achieved = flops / t / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": _pmc_traffic(self.name),
-                "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // n,
-                "algorithmic_flops_per_launch": flops / calls,
-                "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_32x32x2_f32); FLOPs = 2*B*Ho*Wo*Cout*Cin*k*k summed over the "
-                        "launches of this kernel in one step"}
+        out = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+               "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": _pmc_traffic(self.name),
+               "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // n,
+               "algorithmic_flops_per_launch": flops / calls,
+               "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_32x32x2_f32); algorithmic FLOPs = 2*B*Ho*Wo*Cout*Cin*k*k (the "
+                       "direct-convolution count) summed over the launches of this kernel in one step"}
+        if "wino" in name:
+            out["executed_tflops"] = executed / t / 1e12
+            out["mfma_utilisation"] = executed / t / 1e12 / FP32_MFMA_PEAK_TF
+            out["note"] += ("; this kernel is Winograd F(2x2,3x3): it issues 16 instead of 36 multiplies per 2x2 tile and "
+                            "channel pair (executed_tflops = FLOPs actually issued / time, mfma_utilisation = that / "
+                            "peak), so `achieved` on the algorithmic count may exceed the direct-conv MFMA bound")
+        return out
 
     def extra_kernels(self, n):
         out = []
-        for name, (calls, flops, t) in sorted(self._conv_agg.items(), key=lambda kv: -kv[1][2])[1:]:
+        for name, (calls, flops, t, executed) in sorted(self._conv_agg.items(), key=lambda kv: -kv[1][2])[1:]:
             out.append({"kernel": name, "bound": "mfma", "achieved": flops / t / 1e12, "peak": FP32_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF, "avg_launch_us": t / calls * 1e6})
         if self.feature_volume_type == "mlp_feature_volume":

@@ -19,7 +19,7 @@ with torch.inference_mode():
     torch.cuda.synchronize()
 rec = ops.PROFILE; ops.PROFILE = None
 agg = collections.OrderedDict()
-for name, flops, e0, e1, shape in rec:
+for name, flops, e0, e1, shape, _ex in rec:
     a = agg.setdefault((name, shape), [0, 0.0, 0.0]); a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3
 tot = sum(a[2] for a in agg.values())
 print(f"B={B} total conv time {tot*1e3:.2f} ms, {sum(a[1] for a in agg.values())/tot/1e12:.1f} TF")
