@@ -263,15 +263,13 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
             a_f[ca ^ 1][m] = *reinterpret_cast<const float4*>(&tile[a_off[m] + (ky * HW + kx) * ROW + 8 * g]);
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca][m].x, b_f[cb][n].x, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca][m].y, b_f[cb][n].y, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca][m].z, b_f[cb][n].z, acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca][m].w, b_f[cb][n].w, acc[m][n], 0, 0, 0);
-          }
+        // k-step outer, accumulators inner: consecutive MFMAs hit different accumulators
+#define SR_CONV_KSTEP(E)                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                         \
+          _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                       \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca][m].E, b_f[cb][n].E, acc[m][n], 0, 0, 0);
+        SR_CONV_KSTEP(x) SR_CONV_KSTEP(y) SR_CONV_KSTEP(z) SR_CONV_KSTEP(w)
+#undef SR_CONV_KSTEP
         __builtin_amdgcn_sched_barrier(0);
       }
       if (more) sr_conv_stage_store<KS, S, MT, CM>(tiles[buf ^ 1], stg);
