@@ -21,6 +21,16 @@ HBM_PEAK_GBS = 8000.0
 FP32_MFMA_PEAK_TF = 157.3
 
 
+def _mlp_kernel_name(K):
+    """Which sr_mlp_volume_kernel<W1_LDS, W2_LDS> sr_mlp_volume_sweep dispatches (mirrors sr_mlp_volume.hip)."""
+    w1, w2, w3 = 12 * K * 1024, 65 * 1024, 1024
+    if w1 + w2 + w3 <= 160 * 1024:
+        return "sr_mlp_volume_kernel<true, true>"
+    if w1 + w3 <= 160 * 1024:
+        return "sr_mlp_volume_kernel<true, false>"
+    return "sr_mlp_volume_kernel<false, true>"
+
+
 def _time_launches(fn, n):
     """Average device time of fn() over n launches, HIP events on the launch stream."""
     fn()
@@ -265,7 +275,7 @@ class HeroCfg3:
             N = self.h * self.w
             cin = self.Cc * (self.K + 1) + 10 * self.K + 4
             flops = 2.0 * (cin * 128 + 128 * 128 + 128) * self.B * self.D * N
-            out.append({"kernel": "sr_mlp_volume_kernel<true>", "bound": "mfma", "achieved": flops / t / 1e12,
+            out.append({"kernel": _mlp_kernel_name(self.K), "bound": "mfma", "achieved": flops / t / 1e12,
                         "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF,
                         "avg_launch_us": t * 1e6, "algorithmic_flops_per_launch": flops,
                         "algorithmic_bytes_per_launch": self.B * (4 * ((self.K + 1) * self.Cc * N + self.D * N + N))})
@@ -345,7 +355,7 @@ class HeroVolumeOnly:
         N = self.h * self.w
         cin = 16 * (self.K + 1) + 10 * self.K + 4
         flops = 2.0 * (cin * 128 + 128 * 128 + 128) * self.B * self.D * N
-        name = "sr_mlp_volume_kernel<true>" if (13 * self.K + 11) * 1024 <= 160 * 1024 else "sr_mlp_volume_kernel<false>"
+        name = _mlp_kernel_name(self.K)
         return {"kernel": name, "bound": "mfma", "achieved": flops / t / 1e12, "peak": FP32_MFMA_PEAK_TF,
                 "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF, "traffic": _pmc_traffic(self.name),
                 "avg_launch_us": t * 1e6, "algorithmic_flops_per_launch": flops,

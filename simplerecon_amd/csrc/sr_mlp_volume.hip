@@ -159,7 +159,7 @@ __device__ __forceinline__ void sr_l1_step_init(f32x16 (&acc)[2][4], const f32x1
 
 #define SR_LDS_W3_FLOATS 256  // w3tab (128) + b3 + pad, in front of W1 in LDS
 
-template <bool W1_LDS>
+template <bool W1_LDS, bool W2_LDS>
 __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int C = 16;
@@ -173,12 +173,18 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
   const float* gW3 = p.packed + (size_t)(steps1 + SR_MLP_STEPS2) * 256;
 
   for (int i = threadIdx.x; i < 129; i += blockDim.x) lds[i] = gW3[i];
-  if (W1_LDS) {
+  // LDS: [w3tab + b3 | W2 (65 KB, when it fits) | depth-variant part of W1 (12*K KB, when it fits)]
+  constexpr int W2_FLOATS = W2_LDS ? SR_MLP_STEPS2 * 256 : 0;
+  if (W2_LDS) {
     float4* l4 = reinterpret_cast<float4*>(lds + SR_LDS_W3_FLOATS);
+    for (int i = threadIdx.x; i < SR_MLP_STEPS2 * 64; i += blockDim.x) l4[i] = gW2[i];
+  }
+  if (W1_LDS) {
+    float4* l4 = reinterpret_cast<float4*>(lds + SR_LDS_W3_FLOATS + W2_FLOATS);
     for (int i = threadIdx.x; i < steps_var * 64; i += blockDim.x) l4[i] = gW1[i];
   }
   __syncthreads();
-  const float4* W1p = W1_LDS ? reinterpret_cast<const float4*>(lds + SR_LDS_W3_FLOATS) : gW1;
+  const float4* W1p = W1_LDS ? reinterpret_cast<const float4*>(lds + SR_LDS_W3_FLOATS + W2_FLOATS) : gW1;
 
   const int N = p.h * p.w;
   const long nunits = (long)p.B * p.tiles * p.chunks;
@@ -379,8 +385,8 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc2[g][m][r] = 0.0f;
-      const float4* w2 = gW2 + lane;
-      asm volatile("" : "+v"(w2));  // keep hipcc from hoisting 65 loop-invariant 64-bit addresses (spills)
+      const float4* w2 = (W2_LDS ? reinterpret_cast<const float4*>(lds + SR_LDS_W3_FLOATS) : gW2) + lane;
+      if (!W2_LDS) asm volatile("" : "+v"(w2));  // keep hipcc from hoisting 65 loop-invariant 64-bit addresses (spills)
       float4 wn0 = w2[0], wn1 = w2[64], wn2 = w2[128];
 #pragma unroll
       for (int t = 0; t < 64; ++t) {
@@ -520,14 +526,19 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
   const int blocks = (int)((nunits + 3) / 4 < cus ? (nunits + 3) / 4 : cus);
   const size_t w3_bytes = SR_LDS_W3_FLOATS * sizeof(float);
   const size_t w1_bytes = (size_t)sr_mlp_steps_var(K) * 1024;
-  if (w1_bytes + w3_bytes <= 160 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)sr_mlp_volume_kernel<true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(w1_bytes + w3_bytes));
-    if (e != hipSuccess) return sr_hip_rc(e);
-    hipLaunchKernelGGL(sr_mlp_volume_kernel<true>, dim3(blocks), dim3(256), w1_bytes + w3_bytes, stream, p);
-  } else {
-    hipLaunchKernelGGL(sr_mlp_volume_kernel<false>, dim3(blocks), dim3(256), w3_bytes, stream, p);
+  const size_t w2_bytes = (size_t)SR_MLP_STEPS2 * 1024;
+  const size_t lds_max = 160 * 1024;
+#define SR_MLP_LAUNCH(L1, L2, BYTES)                                                                              \
+  {                                                                                                               \
+    hipError_t e = hipFuncSetAttribute((const void*)sr_mlp_volume_kernel<L1, L2>,                                 \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));                 \
+    if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
+    hipLaunchKernelGGL((sr_mlp_volume_kernel<L1, L2>), dim3(blocks), dim3(256), (BYTES), stream, p);              \
   }
+  if (w1_bytes + w2_bytes + w3_bytes <= lds_max) SR_MLP_LAUNCH(true, true, w1_bytes + w2_bytes + w3_bytes)
+  else if (w1_bytes + w3_bytes <= lds_max) SR_MLP_LAUNCH(true, false, w1_bytes + w3_bytes)
+  else SR_MLP_LAUNCH(false, true, w2_bytes + w3_bytes)
+#undef SR_MLP_LAUNCH
   int rc = sr_hip_rc(hipGetLastError());
   if (rc) return rc;
   if (out_lowest) {
