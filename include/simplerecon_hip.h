@@ -173,6 +173,14 @@ int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stri
                        int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
                        int Cout, int ksize, int stride, float leaky_slope, void* stream);
 
+/* Same operator with padding_mode="replicate" (border texels repeated instead of zeros): the 128 -> 16 conv of
+ * the matching encoder's tail (reference modules/networks.py:191-197). */
+int sr_conv2d_replicate_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                 const float* packed_weight, const float* bias, const float* residual,
+                                 int64_t res_batch_stride, int res_pix_stride, float* out,
+                                 int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                                 int Cout, int ksize, int stride, float leaky_slope, void* stream);
+
 /* 3x3 / stride-1 / pad-1 convolution through Winograd F(2x2, 3x3) on the fp32 matrix cores: same operator and
  * epilogue as sr_conv2d_nhwc_fwd (fp32 products and accumulation; 2.25x fewer multiplies).  `packed_u` comes from
  * sr_wino_pack_weights (U = G g G^T in MFMA B-fragment order).  sr_conv_prefers_wino() tells whether this kernel
@@ -195,6 +203,42 @@ const char* sr_conv_kernel_name(int B, int H, int W, int Cin, int Cout, int ksiz
 int sr_upsample2x_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out,
                            int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C,
                            void* stream);
+
+/* ------------------------------------------------------ matching-feature encoder -------
+ *
+ * ResnetMatchingEncoder (reference modules/networks.py:149-205): antialiased ResNet-18 stem + layer1, then
+ * conv1x1 -> InstanceNorm -> LeakyReLU(0.2) -> conv3x3 (replicate padding) -> InstanceNorm.  layer1 and the tail
+ * convolutions go through sr_conv2d_nhwc_fwd / sr_conv3x3_wino_nhwc_fwd / sr_conv2d_replicate_nhwc_fwd with the
+ * eval-mode BatchNorm folded into weight and bias by the caller; the entry points below cover the rest.
+ */
+
+/* Packed form of the stem weight nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False).weight ([64,3,7,7]);
+ * only Cout = 64 is implemented (returns 0 / SR_ERR_UNSUPPORTED otherwise). */
+size_t sr_stem_packed_weight_floats(int Cout);
+int sr_stem_pack_weights(const float* weight, int Cout, float* packed, void* stream);
+
+/* out[b, y, x, co] = act( conv7x7_s2_p3(in)[b, co, y, x] * scale[co] + shift[co] ): encoder.conv1 + bn1 (eval mode:
+ * scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale; NULL = identity) + ReLU
+ * (leaky_slope = 0; < 0: no activation) -- reference networks.py:176-179.  `in` is the image with arbitrary element
+ * strides (NCHW or channels-last), `out` is channels-last [B, H/2, W/2, 64]. */
+int sr_stem7x7_fwd(const float* in, int64_t in_batch_stride, int64_t in_chan_stride, int64_t in_row_stride,
+                   int64_t in_col_stride, const float* packed_weight, const float* scale, const float* shift,
+                   float leaky_slope, float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W,
+                   int Cout, void* stream);
+
+/* encoder.maxpool of the antialiased backbone: nn.MaxPool2d(kernel_size=2, stride=1) followed by
+ * BlurPool(filt_size=4, stride=2, reflect padding (1,2,1,2), taps outer([1,3,3,1])/64), fused.
+ * [B,H,W,C] -> [B,(H-2)/2+1,(W-2)/2+1,C] channels-last, C % 4 == 0, H, W >= 4. */
+int sr_maxblurpool_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out,
+                            int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C, void* stream);
+
+/* nn.InstanceNorm2d(C) (affine=False, biased variance over H*W per image and channel) optionally followed by
+ * LeakyReLU(leaky_slope) (< 0: none) -- reference networks.py:188-189, 198.  Deterministic (no atomics); `out` may
+ * alias `in`.  C % 4 == 0, C <= 256.  Workspace: sr_instance_norm_workspace_bytes, 16-byte aligned. */
+size_t sr_instance_norm_workspace_bytes(int B, int H, int W, int C);
+int sr_instance_norm_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out,
+                              int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C, float eps,
+                              float leaky_slope, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

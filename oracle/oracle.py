@@ -222,3 +222,94 @@ def depth_decoder_pp(feats, sd, precision="f32"):
                 hd, sd[f"convs.output_{i}.1.weight"], sd[f"convs.output_{i}.1.bias"], precision=precision)
         prev = outputs[::-1]
     return depth_outputs
+
+
+# ------------------------------------------------------- matching encoder (a16) --
+# ResnetMatchingEncoder (reference modules/networks.py:149-205).  Its ResNet-18 stem/layer1 come from
+# the third-party `antialiased_cnns` package (simplerecon_env.yml:20, unpinned, NOT under
+# /root/reference); the functions below restate that package's published architecture
+# (resnet.py / blurpool.py of adobe/antialiased-cnns: conv1 7x7/s2 -> BN -> ReLU ->
+# [MaxPool2d(2, stride 1), BlurPool(filt 4, stride 2, reflect)] -> layer1 = 2 x BasicBlock(64)).
+# The golden vectors for it are produced by the reference's own ResnetMatchingEncoder class built on
+# oracle/refshim.py's torch.nn restatement of that backbone: the tail (networks.py:187-201) is the
+# reference's code, the backbone is pinned against ATen ops only ("parity unpinned" vs the package).
+
+def batchnorm_eval(x, sd, prefix, eps=1e-5, precision="f32"):
+    """nn.BatchNorm2d in eval mode as ATen's CPU inference path computes it:
+    alpha = weight / sqrt(var + eps); beta = bias - mean * alpha; y = x * alpha + beta."""
+    dt, _ = _dt(precision)
+    x = np.asarray(x, dtype=dt)
+    w, b = np.asarray(sd[prefix + "weight"], dt), np.asarray(sd[prefix + "bias"], dt)
+    m, v = np.asarray(sd[prefix + "running_mean"], dt), np.asarray(sd[prefix + "running_var"], dt)
+    alpha = w * (dt(1) / np.sqrt(v + dt(eps)))
+    beta = b - m * alpha
+    return x * alpha[None, :, None, None] + beta[None, :, None, None]
+
+
+def maxpool2_s1(x):
+    """nn.MaxPool2d(kernel_size=2, stride=1): [B,C,H,W] -> [B,C,H-1,W-1]."""
+    return np.maximum(np.maximum(x[:, :, :-1, :-1], x[:, :, :-1, 1:]), np.maximum(x[:, :, 1:, :-1], x[:, :, 1:, 1:]))
+
+
+def blurpool4_s2(x):
+    """antialiased_cnns.BlurPool(filt_size=4, stride=2, pad_type='reflect'): ReflectionPad2d((1,2,1,2)) then a
+    depthwise conv with outer([1,3,3,1])/64, stride 2."""
+    dt = x.dtype.type
+    a = np.array([1.0, 3.0, 3.0, 1.0], dtype=x.dtype)
+    f = np.outer(a, a)
+    f = f / f.sum(dtype=x.dtype)
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 2), (1, 2)), mode="reflect")
+    Ho, Wo = (xp.shape[2] - 4) // 2 + 1, (xp.shape[3] - 4) // 2 + 1
+    out = np.zeros(x.shape[:2] + (Ho, Wo), x.dtype)
+    for i in range(4):
+        for j in range(4):
+            out += dt(f[i, j]) * xp[:, :, i:i + 2 * Ho:2, j:j + 2 * Wo:2]
+    return out
+
+
+def instance_norm(x, eps=1e-5, leaky=None):
+    """nn.InstanceNorm2d (affine=False, no running stats): per (image, channel) biased statistics over H*W."""
+    dt = x.dtype.type
+    mean = x.mean(axis=(2, 3), keepdims=True, dtype=x.dtype)
+    var = np.square(x - mean).mean(axis=(2, 3), keepdims=True, dtype=x.dtype)
+    y = (x - mean) * (dt(1) / np.sqrt(var + dt(eps)))
+    if leaky is not None:
+        y = np.where(y >= 0, y, y * dt(leaky))
+    return y
+
+
+def resnet_block(x, sd, prefix, precision="f32"):
+    """torchvision/antialiased_cnns BasicBlock, stride 1: conv3x3 -> bn -> relu -> conv3x3 -> bn -> += x -> relu."""
+    t = conv2d(x, sd[prefix + "conv1.weight"], None, precision=precision)
+    t = np.maximum(batchnorm_eval(t, sd, prefix + "bn1.", precision=precision), 0)
+    t = conv2d(t, sd[prefix + "conv2.weight"], None, precision=precision)
+    t = batchnorm_eval(t, sd, prefix + "bn2.", precision=precision) + x
+    return np.maximum(t, 0)
+
+
+def conv2d_replicate(x, wgt, bias, precision="f32"):
+    """nn.Conv2d(k, padding=k//2, padding_mode='replicate') (networks.py:191-197)."""
+    p = wgt.shape[-1] // 2
+    xp = np.pad(np.asarray(x), ((0, 0), (0, 0), (p, p), (p, p)), mode="edge")
+    return conv2d(xp, wgt, bias, pad=0, precision=precision)
+
+
+def resnet_matching_encoder(img, sd, precision="f32", taps=None):
+    """ResnetMatchingEncoder.forward (modules/networks.py:185-205), state-dict keys `net.<i>...` as nn.Sequential
+    numbers them.  `taps` (dict) optionally receives the intermediate activations."""
+    dt, _ = _dt(precision)
+    x = conv2d(np.asarray(img, dtype=dt), sd["net.0.weight"], None, stride=2, pad=3, precision=precision)
+    x = np.maximum(batchnorm_eval(x, sd, "net.1.", precision=precision), 0)
+    if taps is not None:
+        taps["stem"] = x
+    x = blurpool4_s2(maxpool2_s1(x))
+    if taps is not None:
+        taps["pool"] = x
+    x = resnet_block(x, sd, "net.4.0.", precision)
+    x = resnet_block(x, sd, "net.4.1.", precision)
+    if taps is not None:
+        taps["layer1"] = x
+    x = conv2d(x, sd["net.5.weight"], sd["net.5.bias"], precision=precision)
+    x = instance_norm(x, leaky=0.2)
+    x = conv2d_replicate(x, sd["net.8.weight"], sd["net.8.bias"], precision=precision)
+    return instance_norm(x)

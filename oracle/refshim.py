@@ -34,6 +34,72 @@ def spatial_gradient(input: torch.Tensor) -> torch.Tensor:
 '''
 
 
+def _aa_blurpool_class():
+    """torch.nn restatement of antialiased_cnns.BlurPool (adobe/antialiased-cnns, blurpool.py) for the one
+    configuration the reference reaches: filt_size=4, stride=2, pad_type='reflect', pad_off=0.  The package
+    itself is absent from this image and from /root/reference (simplerecon_env.yml:20, unpinned)."""
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    class BlurPool(nn.Module):
+        def __init__(self, channels, pad_type="reflect", filt_size=4, stride=2, pad_off=0):
+            super().__init__()
+            assert pad_type == "reflect" and pad_off == 0
+            self.filt_size, self.stride, self.channels = filt_size, stride, channels
+            lo, hi = int(1.0 * (filt_size - 1) / 2), int(np.ceil(1.0 * (filt_size - 1) / 2))
+            self.pad = nn.ReflectionPad2d([lo, hi, lo, hi])
+            a = {1: [1.0], 2: [1.0, 1.0], 3: [1.0, 2.0, 1.0], 4: [1.0, 3.0, 3.0, 1.0],
+                 5: [1.0, 4.0, 6.0, 4.0, 1.0]}[filt_size]
+            a = np.array(a)
+            filt = torch.Tensor(a[:, None] * a[None, :])
+            filt = filt / torch.sum(filt)
+            self.register_buffer("filt", filt[None, None, :, :].repeat((channels, 1, 1, 1)))
+
+        def forward(self, inp):
+            return F.conv2d(self.pad(inp), self.filt, stride=self.stride, groups=inp.shape[1])
+
+    return BlurPool
+
+
+def _aa_resnet18(pretrained=False, filter_size=4, pool_only=True, **kwargs):
+    """torch.nn restatement of the part of antialiased_cnns.resnet18 that ResnetMatchingEncoder keeps
+    (modules/networks.py:176-182: conv1, bn1, relu, maxpool, layer1).  layer2..4 and fc are never used by
+    the reference and are not built."""
+    import torch.nn as nn
+    if pretrained:
+        raise RuntimeError("no network: pretrained antialiased_cnns weights are unavailable")
+    BlurPool = _aa_blurpool_class()
+
+    class Block(nn.Module):  # stride-1 BasicBlock of (antialiased) ResNet-18
+        def __init__(self, planes):
+            super().__init__()
+            self.conv1 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+
+        def forward(self, x):
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            out += x
+            return self.relu(out)
+
+    class Stem(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.Sequential(nn.MaxPool2d(kernel_size=2, stride=1),
+                                         BlurPool(64, filt_size=filter_size, stride=2))
+            self.layer1 = nn.Sequential(Block(64), Block(64))
+
+    return Stem()
+
+
 def install_stubs():
     import tempfile
     if "kornia" in sys.modules and getattr(sys.modules["kornia"], "_sr_stub", False):
@@ -63,7 +129,8 @@ def install_stubs():
     if "timm" not in sys.modules:
         mod("timm")
     if "antialiased_cnns" not in sys.modules:
-        mod("antialiased_cnns")
+        mod("antialiased_cnns", resnet18=_aa_resnet18, resnet34=None, resnet50=None, resnet101=None,
+            resnet152=None, BlurPool=_aa_blurpool_class())
     if "pytorch_lightning" not in sys.modules:
         pass  # DepthModel itself is not importable; not needed for the hot path
 

@@ -40,12 +40,20 @@ SIGNATURES = {
     "sr_conv_packed_weight_floats": (_sz, [_i, _i, _i]),
     "sr_conv_pack_weights": (_i, [_p, _i, _i, _i, _p, _p]),
     "sr_conv2d_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "sr_conv2d_replicate_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i,
+                                          _f, _p]),
     "sr_wino_packed_weight_floats": (_sz, [_i, _i]),
     "sr_wino_pack_weights": (_i, [_p, _i, _i, _p, _p]),
     "sr_conv_prefers_wino": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_conv3x3_wino_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _p]),
     "sr_conv_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "sr_upsample2x_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "sr_stem_packed_weight_floats": (_sz, [_i]),
+    "sr_stem_pack_weights": (_i, [_p, _i, _p, _p]),
+    "sr_stem7x7_fwd": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _f, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "sr_maxblurpool_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "sr_instance_norm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "sr_instance_norm_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
 }
 
 

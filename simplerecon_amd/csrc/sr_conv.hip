@@ -48,6 +48,7 @@ struct SrConvParams {
   float slope;                                      // < 0: no activation
   int vec4;                                         // input rows 16-byte aligned
   int debug;                                        // ablation bits (env SR_CONV_DEBUG), 0 in production
+  int replicate;                                    // padding_mode="replicate": halo coordinates clamp to the border
 };
 
 // Stages global -> registers (issued before the MFMA phase of the previous slab) -> LDS (after it):
@@ -80,7 +81,11 @@ __device__ __forceinline__ void sr_conv_stage_setup(const SrConvParams& p, int i
     const int e = threadIdx.x + it * 256;
     const int px = e / G::Q, q = e % G::Q;
     const int hy = px / G::HW, hx = px - hy * G::HW;
-    const int iy = iy0 + hy, ix = ix0 + hx;
+    int iy = iy0 + hy, ix = ix0 + hx;
+    if (p.replicate) {
+      iy = min(max(iy, 0), p.H - 1);
+      ix = min(max(ix, 0), p.W - 1);
+    }
     const bool ok = (e < G::ELEMS) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W) && !(p.debug & 4);
     offs[it] = ok ? (iy * p.W + ix) * p.in_sp + 4 * q : -1;
   }
@@ -491,11 +496,11 @@ static SrConvCfg sr_conv_cfg(const SrConvParams& p, int B, int stride, int ksize
   return cfg;
 }
 
-extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
-                                  const float* packed_weight, const float* bias, const float* residual,
-                                  int64_t res_batch_stride, int res_pix_stride, float* out,
-                                  int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
-                                  int Cout, int ksize, int stride, float leaky_slope, void* stream_) {
+static int sr_conv2d_dispatch(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                             const float* packed_weight, const float* bias, const float* residual,
+                             int64_t res_batch_stride, int res_pix_stride, float* out, int64_t out_batch_stride,
+                             int out_pix_stride, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                             float leaky_slope, int replicate, void* stream_) {
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (B == 0) return SR_OK;
   if (!in || !packed_weight || !out) return SR_ERR_INVALID_ARGUMENT;
@@ -512,6 +517,7 @@ extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int 
   p.Co_pad = ((Cout + 31) / 32) * 32;
   p.G = ((Cin + sr_ck(ksize) - 1) / sr_ck(ksize)) * (sr_ck(ksize) / 8);
   p.slope = leaky_slope;
+  p.replicate = replicate;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0);
   hipStream_t stream = (hipStream_t)stream_;
@@ -533,6 +539,27 @@ extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int 
   }
   if (c == 1) return sr_conv_launch<1, 2, 1, 32>(p, B, nt, stream);
   return sr_conv_launch<1, 2, 1, 8>(p, B, nt, stream);
+}
+
+extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                  const float* packed_weight, const float* bias, const float* residual,
+                                  int64_t res_batch_stride, int res_pix_stride, float* out,
+                                  int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                                  int Cout, int ksize, int stride, float leaky_slope, void* stream_) {
+  return sr_conv2d_dispatch(in, in_batch_stride, in_pix_stride, packed_weight, bias, residual, res_batch_stride,
+                            res_pix_stride, out, out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, ksize, stride,
+                            leaky_slope, 0, stream_);
+}
+
+extern "C" int sr_conv2d_replicate_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                            const float* packed_weight, const float* bias, const float* residual,
+                                            int64_t res_batch_stride, int res_pix_stride, float* out,
+                                            int64_t out_batch_stride, int out_pix_stride, int B, int H, int W,
+                                            int Cin, int Cout, int ksize, int stride, float leaky_slope,
+                                            void* stream_) {
+  return sr_conv2d_dispatch(in, in_batch_stride, in_pix_stride, packed_weight, bias, residual, res_batch_stride,
+                            res_pix_stride, out, out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, ksize, stride,
+                            leaky_slope, 1, stream_);
 }
 
 // Symbol of the kernel instantiation sr_conv2d_nhwc_fwd picks for these arguments (for profilers / bench).

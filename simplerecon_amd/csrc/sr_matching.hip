@@ -1,0 +1,408 @@
+// sr_matching.hip -- matching-feature encoder kernels (reference
+// modules/networks.py:149-205 ResnetMatchingEncoder): the antialiased ResNet-18 stem
+//   conv1 7x7/s2 (+ BatchNorm affine + ReLU)            -> sr_stem_kernel        (fp32 MFMA implicit GEMM)
+//   MaxPool2d(2, stride 1) + BlurPool(filt 4, stride 2) -> sr_maxblurpool_kernel (HBM-bound)
+// and the InstanceNorm2d (+ LeakyReLU) of the tail       -> sr_inorm_* kernels    (HBM-bound, deterministic).
+// layer1 and the tail convolutions run on the conv kernels of sr_conv.hip / sr_wino.hip.
+// gfx950 only.
+#include "sr_common.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+#define SR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------ stem: conv 7x7 / stride 2 / pad 3, Cin = 3 ---
+//
+// Implicit GEMM  out[pixel, co] = sum_k patch[pixel, k] * W[k, co]  with k = (c, ky, kx) -- 147 real taps, laid out
+// as 84 MFMA k-steps of 2: step = (c*7 + ky)*4 + kxp, k-lane `half` selects kx = 2*kxp + half (kx = 7 is a zero tap).
+// A workgroup (4 waves) owns a 16x16 output tile; its 37x37x3 input patch sits in LDS and every A fragment is a
+// single ds_read_b32 at an immediate offset (stride-2 columns: 64 lanes hit each bank twice = the 2-cycle minimum).
+// The packed weight (42 KB) stays in LDS for the whole (persistent) workgroup: [step][half][32 cols][2 N-tiles].
+// Wave w computes output rows 4w..4w+3 (two 2x16 M-tiles) x 64 channels: 4 MFMAs per 3 LDS reads.
+#define SR_STEM_T 16
+#define SR_STEM_PR 37
+#define SR_STEM_PW 38   // column 37 only ever meets the zero weight of the padding tap, but must hold finite data
+#define SR_STEM_STEPS 84
+#define SR_STEM_WFLOATS (SR_STEM_STEPS * 128)
+#define SR_STEM_PFLOATS (3 * SR_STEM_PR * SR_STEM_PW)
+
+struct SrStemParams {
+  const float* in; int64_t sb, sc, sy, sx;   // image strides (elements): batch, channel, row, column
+  const float* wp;                           // packed weights
+  const float* scale; const float* shift;    // per-channel affine after the conv (BatchNorm eval), may be null
+  float slope;                               // LeakyReLU slope (0 = ReLU), < 0: none
+  float* out; int64_t out_sb; int out_sp;    // channels-last output
+  int H, W, Ho, Wo, tiles_x, tiles_y, total;
+};
+
+__global__ void sr_stem_pack_kernel(const float* __restrict__ w /*[64,3,7,7]*/, float* __restrict__ packed) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < SR_STEM_WFLOATS; idx += gridDim.x * blockDim.x) {
+    const int step = idx >> 7, r = idx & 127;
+    const int half = r >> 6, col = (r & 63) >> 1, nt = r & 1;
+    const int c = step / 28, ky = (step % 28) >> 2, kx = 2 * (step & 3) + half;
+    const int co = nt * 32 + col;
+    packed[idx] = kx < 7 ? w[((co * 3 + c) * 7 + ky) * 7 + kx] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void sr_stem_kernel(SrStemParams p) {
+  __shared__ __attribute__((aligned(16))) float wl[SR_STEM_WFLOATS];
+  __shared__ float patch[SR_STEM_PFLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, half = lane >> 5;
+
+  for (int e = threadIdx.x; e < SR_STEM_WFLOATS / 4; e += 256)
+    reinterpret_cast<float4*>(wl)[e] = reinterpret_cast<const float4*>(p.wp)[e];
+
+  // A-fragment bases: M-tile m of this wave = output rows 4*wave + 2*m + {0,1}, 16 columns
+  int abase[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) abase[m] = (2 * (4 * wave + 2 * m + (i >> 4))) * SR_STEM_PW + 2 * (i & 15) + half;
+  const float2* wl2 = reinterpret_cast<const float2*>(wl) + half * 32 + i;
+
+  float sc[2], sh[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    sc[n] = p.scale ? p.scale[n * 32 + i] : 1.f;
+    sh[n] = p.shift ? p.shift[n * 32 + i] : 0.f;
+  }
+
+  for (int tile = blockIdx.x; tile < p.total; tile += gridDim.x) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const int oy0 = ty * SR_STEM_T, ox0 = tx * SR_STEM_T;
+    const float* __restrict__ img = p.in + (int64_t)b * p.sb;
+    __syncthreads();  // the previous tile's fragment reads are done (and the weights are in place)
+    for (int e = threadIdx.x; e < SR_STEM_PFLOATS; e += 256) {
+      const int c = e / (SR_STEM_PR * SR_STEM_PW), rem = e - c * (SR_STEM_PR * SR_STEM_PW);
+      const int r = rem / SR_STEM_PW, x = rem - r * SR_STEM_PW;
+      const int gy = 2 * oy0 - 3 + r, gx = 2 * ox0 - 3 + x;
+      const bool ok = (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
+      patch[e] = ok ? img[c * p.sc + gy * p.sy + gx * p.sx] : 0.f;
+    }
+    __syncthreads();
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int kxp = 0; kxp < 4; ++kxp) {
+          const int step = (c * 7 + ky) * 4 + kxp;
+          const int aoff = (c * SR_STEM_PR + ky) * SR_STEM_PW + 2 * kxp;
+          const float a0 = patch[abase[0] + aoff], a1 = patch[abase[1] + aoff];
+          const float2 w = wl2[step * 64];
+          acc[0][0] = SR_MFMA(a0, w.x, acc[0][0]);
+          acc[1][0] = SR_MFMA(a1, w.x, acc[1][0]);
+          acc[0][1] = SR_MFMA(a0, w.y, acc[0][1]);
+          acc[1][1] = SR_MFMA(a1, w.y, acc[1][1]);
+        }
+
+    float* __restrict__ ob = p.out + (int64_t)b * p.out_sb;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int oy = oy0 + 4 * wave + 2 * m + (mrow >> 4), ox = ox0 + (mrow & 15);
+        if (oy < p.Ho && ox < p.Wo) {
+          float* o = ob + ((int64_t)oy * p.Wo + ox) * p.out_sp + i;
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            float v = acc[m][n][r] * sc[n] + sh[n];
+            if (p.slope >= 0.f) v = v >= 0.f ? v : v * p.slope;
+            o[n * 32] = v;
+          }
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------ MaxPool(2, s1) + BlurPool(4, s2, reflect) ---
+//
+// out[oy,ox] = sum_{i,j<4} f_i f_j MP[refl(2oy-1+i)][refl(2ox-1+j)],  f = (1,3,3,1)/8,  MP[y][x] = max in[y..y+1][x..x+1]
+// (MP is (H-1) x (W-1); reflection is on MP's index range, as nn.ReflectionPad2d((1,2,1,2)) applies it to the max-pooled
+// map).  One thread per (output pixel, 4 channels).  Interior pixels read their 5x5 window once (25 float4 loads,
+// vertical max then horizontal max); border pixels take the generic reflected path.
+__device__ __forceinline__ int sr_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+__device__ __forceinline__ float4 sr_max4(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float4 sr_axpy4(float s, float4 a, float4 acc) {
+  return make_float4(acc.x + s * a.x, acc.y + s * a.y, acc.z + s * a.z, acc.w + s * a.w);
+}
+
+__global__ __launch_bounds__(256) void sr_maxblurpool_kernel(const float* __restrict__ in, int64_t in_sb, int in_sp,
+                                                             float* __restrict__ out, int64_t out_sb, int out_sp,
+                                                             int H, int W, int Ho, int Wo, int C4) {
+  const int Hm = H - 1, Wm = W - 1;
+  const int64_t total = (int64_t)Ho * Wo * C4;
+  const float* __restrict__ ib = in + (int64_t)blockIdx.y * in_sb;
+  float* __restrict__ ob = out + (int64_t)blockIdx.y * out_sb;
+  const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    const int pix = (int)(idx / C4);
+    const int oy = pix / Wo, ox = pix - oy * Wo;
+    const int y0 = 2 * oy - 1, x0 = 2 * ox - 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y0 >= 0 && y0 + 3 < Hm && x0 >= 0 && x0 + 3 < Wm) {
+      float4 vm[4][5];  // vertical max of rows (y0+i, y0+i+1) at the 5 window columns
+      float4 prev[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        prev[j] = *reinterpret_cast<const float4*>(ib + ((int64_t)y0 * W + x0 + j) * in_sp + 4 * c4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 cur[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          cur[j] = *reinterpret_cast<const float4*>(ib + ((int64_t)(y0 + i + 1) * W + x0 + j) * in_sp + 4 * c4);
+          vm[i][j] = sr_max4(prev[j], cur[j]);
+          prev[j] = cur[j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row = sr_axpy4(f[j], sr_max4(vm[i][j], vm[i][j + 1]), row);
+        acc = sr_axpy4(f[i], row, acc);
+      }
+    } else {
+      for (int i = 0; i < 4; ++i) {
+        const int my = sr_reflect(y0 + i, Hm);
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 4; ++j) {
+          const int mx = sr_reflect(x0 + j, Wm);
+          const float* q = ib + ((int64_t)my * W + mx) * in_sp + 4 * c4;
+          const float4 a = *reinterpret_cast<const float4*>(q);
+          const float4 bq = *reinterpret_cast<const float4*>(q + in_sp);
+          const float4 c = *reinterpret_cast<const float4*>(q + (int64_t)W * in_sp);
+          const float4 d = *reinterpret_cast<const float4*>(q + (int64_t)W * in_sp + in_sp);
+          row = sr_axpy4(f[j], sr_max4(sr_max4(a, bq), sr_max4(c, d)), row);
+        }
+        acc = sr_axpy4(f[i], row, acc);
+      }
+    }
+    *reinterpret_cast<float4*>(ob + (int64_t)pix * out_sp + 4 * c4) = acc;
+  }
+}
+
+// ------------------------------------------------------------------ InstanceNorm2d (+ LeakyReLU) ----------------
+//
+// Per (image, channel) statistics over H*W, biased variance, no affine (nn.InstanceNorm2d defaults; reference
+// networks.py:188, 198).  Deterministic three-step reduction (no atomics):
+//   1. sr_inorm_partial_kernel: a workgroup owns (image, chunk of pixels): chunk mean, then chunk M2 = sum (x-mean)^2
+//      (the second read of the chunk hits L2), written to partial[b][chunk][{mean, M2}][C];
+//   2. sr_inorm_finalize_kernel: Chan merge of the chunks in index order -> stats[b][{mean, rstd}][C];
+//   3. sr_inorm_apply_kernel: y = (x - mean) * rstd, LeakyReLU, float4 streams (in place allowed).
+struct SrInormParams {
+  const float* in; int64_t in_sb; int in_sp;
+  float* out; int64_t out_sb; int out_sp;
+  float* partial; float* stats;
+  int HW, C, C4, chunks, chunk_pix;
+  float eps, slope;
+};
+
+__global__ __launch_bounds__(256) void sr_inorm_partial_kernel(SrInormParams p) {
+  __shared__ float4 red[256];
+  __shared__ float4 mean_s[64];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int lanes = p.C4;                 // float4 lanes across channels (<= 64)
+  const int rows = 256 / lanes;           // pixel rows handled concurrently
+  const int cl = threadIdx.x % lanes, pr = threadIdx.x / lanes;
+  const int p0 = chunk * p.chunk_pix, p1 = min(p.HW, p0 + p.chunk_pix);
+  const float* __restrict__ ib = p.in + (int64_t)b * p.in_sb + 4 * cl;
+  const bool active = pr < rows;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active)
+    for (int px = p0 + pr; px < p1; px += rows) {
+      const float4 v = *reinterpret_cast<const float4*>(ib + (int64_t)px * p.in_sp);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < lanes) {
+    float4 t = red[threadIdx.x];
+    for (int r = 1; r < rows; ++r) {
+      const float4 u = red[r * lanes + threadIdx.x];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    const float inv = 1.f / (float)(p1 - p0);
+    mean_s[threadIdx.x] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+  }
+  __syncthreads();
+  const float4 m = mean_s[cl];
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active)
+    for (int px = p0 + pr; px < p1; px += rows) {
+      const float4 v = *reinterpret_cast<const float4*>(ib + (int64_t)px * p.in_sp);
+      const float dx = v.x - m.x, dy = v.y - m.y, dz = v.z - m.z, dw = v.w - m.w;
+      q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+    }
+  __syncthreads();
+  red[threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < lanes) {
+    float4 t = red[threadIdx.x];
+    for (int r = 1; r < rows; ++r) {
+      const float4 u = red[r * lanes + threadIdx.x];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    float* o = p.partial + ((int64_t)(b * p.chunks + chunk) * 2) * p.C + 4 * threadIdx.x;
+    *reinterpret_cast<float4*>(o) = m;
+    *reinterpret_cast<float4*>(o + p.C) = t;
+  }
+}
+
+__global__ void sr_inorm_finalize_kernel(SrInormParams p, int B) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * p.C) return;
+  const int b = idx / p.C, c = idx - b * p.C;
+  const float* pb = p.partial + (int64_t)b * p.chunks * 2 * p.C + c;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int k = 0; k < p.chunks; ++k) {  // Chan et al. pairwise update, fixed order
+    const int p0 = k * p.chunk_pix;
+    const float nk = (float)(min(p.HW, p0 + p.chunk_pix) - p0);
+    const float mk = pb[(int64_t)k * 2 * p.C], qk = pb[(int64_t)k * 2 * p.C + p.C];
+    const float nn = n + nk, d = mk - mean;
+    mean += d * (nk / nn);
+    m2 += qk + d * d * (n * nk / nn);
+    n = nn;
+  }
+  p.stats[(int64_t)b * 2 * p.C + c] = mean;
+  p.stats[(int64_t)b * 2 * p.C + p.C + c] = 1.f / sqrtf(m2 / n + p.eps);
+}
+
+__global__ __launch_bounds__(256) void sr_inorm_apply_kernel(SrInormParams p) {
+  const int b = blockIdx.y;
+  const float* __restrict__ ib = p.in + (int64_t)b * p.in_sb;
+  float* __restrict__ ob = p.out + (int64_t)b * p.out_sb;
+  const float* st = p.stats + (int64_t)b * 2 * p.C;
+  const int64_t total = (int64_t)p.HW * p.C4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % p.C4);
+    const int64_t px = idx / p.C4;
+    const float4 m = *reinterpret_cast<const float4*>(st + 4 * c4);
+    const float4 r = *reinterpret_cast<const float4*>(st + p.C + 4 * c4);
+    float4 v = *reinterpret_cast<const float4*>(ib + px * p.in_sp + 4 * c4);
+    v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w;
+    if (p.slope >= 0.f) {
+      v.x = v.x >= 0.f ? v.x : v.x * p.slope; v.y = v.y >= 0.f ? v.y : v.y * p.slope;
+      v.z = v.z >= 0.f ? v.z : v.z * p.slope; v.w = v.w >= 0.f ? v.w : v.w * p.slope;
+    }
+    *reinterpret_cast<float4*>(ob + px * p.out_sp + 4 * c4) = v;
+  }
+}
+
+// ------------------------------------------------------------------ C ABI -------------
+
+static int sr_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else cus = 256;
+  }
+  return cus;
+}
+
+extern "C" size_t sr_stem_packed_weight_floats(int Cout) { return Cout == 64 ? (size_t)SR_STEM_WFLOATS : 0; }
+
+extern "C" int sr_stem_pack_weights(const float* weight, int Cout, float* packed, void* stream_) {
+  if (!weight || !packed) return SR_ERR_INVALID_ARGUMENT;
+  if (Cout != 64) return SR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sr_stem_pack_kernel, dim3(42), dim3(256), 0, (hipStream_t)stream_, weight, packed);
+  return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" int sr_stem7x7_fwd(const float* in, int64_t in_batch_stride, int64_t in_chan_stride, int64_t in_row_stride,
+                              int64_t in_col_stride, const float* packed_weight, const float* scale,
+                              const float* shift, float leaky_slope, float* out, int64_t out_batch_stride,
+                              int out_pix_stride, int B, int H, int W, int Cout, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (Cout != 64) return SR_ERR_UNSUPPORTED;
+  if (B == 0) return SR_OK;
+  if (!in || !packed_weight || !out) return SR_ERR_INVALID_ARGUMENT;
+  SrStemParams p;
+  p.in = in; p.sb = in_batch_stride; p.sc = in_chan_stride; p.sy = in_row_stride; p.sx = in_col_stride;
+  p.wp = packed_weight; p.scale = scale; p.shift = shift; p.slope = leaky_slope;
+  p.out = out; p.out_sb = out_batch_stride; p.out_sp = out_pix_stride;
+  p.H = H; p.W = W;
+  p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1;
+  p.tiles_x = (p.Wo + SR_STEM_T - 1) / SR_STEM_T; p.tiles_y = (p.Ho + SR_STEM_T - 1) / SR_STEM_T;
+  p.total = p.tiles_x * p.tiles_y * B;
+  int blocks = 2 * sr_cus();
+  if (blocks > p.total) blocks = p.total;
+  hipLaunchKernelGGL(sr_stem_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
+  return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" int sr_maxblurpool_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out,
+                                       int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C,
+                                       void* stream_) {
+  if (B < 0 || H < 4 || W < 4 || C <= 0) return SR_ERR_INVALID_ARGUMENT;  // reflection needs (H-1), (W-1) >= 3
+  if (B == 0) return SR_OK;
+  if (!in || !out) return SR_ERR_INVALID_ARGUMENT;
+  if ((C % 4) || (in_pix_stride % 4) || (out_pix_stride % 4) || (in_batch_stride % 4) || (out_batch_stride % 4) ||
+      ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+    return SR_ERR_UNSUPPORTED;
+  const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
+  const int64_t total = (int64_t)Ho * Wo * (C / 4);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(sr_maxblurpool_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, in, in_batch_stride,
+                     in_pix_stride, out, out_batch_stride, out_pix_stride, H, W, Ho, Wo, C / 4);
+  return sr_hip_rc(hipGetLastError());
+}
+
+static void sr_inorm_chunks(int B, int HW, int* chunks, int* chunk_pix) {
+  int want = (8 * sr_cus() + B - 1) / B;          // ~8 workgroups per CU over the batch
+  int most = (HW + 255) / 256;                    // at least 256 pixels per chunk
+  int n = want < most ? want : most;
+  if (n < 1) n = 1;
+  *chunk_pix = (HW + n - 1) / n;
+  *chunks = (HW + *chunk_pix - 1) / *chunk_pix;
+}
+
+extern "C" size_t sr_instance_norm_workspace_bytes(int B, int H, int W, int C) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  int chunks, chunk_pix;
+  sr_inorm_chunks(B, H * W, &chunks, &chunk_pix);
+  return ((size_t)B * chunks * 2 * C + (size_t)B * 2 * C) * sizeof(float);
+}
+
+extern "C" int sr_instance_norm_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out,
+                                         int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C,
+                                         float eps, float leaky_slope, void* workspace, size_t workspace_bytes,
+                                         void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!in || !out || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if ((C % 4) || C > 256 || (in_pix_stride % 4) || (out_pix_stride % 4) || (in_batch_stride % 4) ||
+      (out_batch_stride % 4) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((uintptr_t)workspace & 15))
+    return SR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sr_instance_norm_workspace_bytes(B, H, W, C)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  SrInormParams p;
+  p.in = in; p.in_sb = in_batch_stride; p.in_sp = in_pix_stride;
+  p.out = out; p.out_sb = out_batch_stride; p.out_sp = out_pix_stride;
+  p.HW = H * W; p.C = C; p.C4 = C / 4;
+  sr_inorm_chunks(B, p.HW, &p.chunks, &p.chunk_pix);
+  p.partial = (float*)workspace;
+  p.stats = p.partial + (size_t)B * p.chunks * 2 * C;
+  p.eps = eps; p.slope = leaky_slope;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(sr_inorm_partial_kernel, dim3(p.chunks, B), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(sr_inorm_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, p, B);
+  const int64_t total = (int64_t)p.HW * p.C4;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(sr_inorm_apply_kernel, dim3(blocks, B), dim3(256), 0, stream, p);
+  return sr_hip_rc(hipGetLastError());
+}

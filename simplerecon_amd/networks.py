@@ -148,3 +148,80 @@ class DepthDecoderPP(nn.Module):
             prev_outputs = outputs[::-1]
         # same key order as the reference's dict (s3, s2, s1, s0 first inserted at j = 1)
         return {k: depth_outputs[k] for k in sorted(depth_outputs, reverse=True)}
+
+
+class _BlurPool(nn.Module):
+    """Parameter/buffer holder for antialiased_cnns.BlurPool(filt_size=4, stride=2) -- keeps the `filt` buffer so
+    reference checkpoints load; the HIP kernel uses the fixed outer([1,3,3,1])/64 taps."""
+
+    def __init__(self, channels, filt_size=4, stride=2):
+        super().__init__()
+        if filt_size != 4 or stride != 2:
+            raise ValueError("the HIP path implements BlurPool(filt_size=4, stride=2) only")
+        a = torch.tensor([1.0, 3.0, 3.0, 1.0])
+        filt = a[:, None] * a[None, :]
+        self.register_buffer("filt", (filt / filt.sum())[None, None].repeat(channels, 1, 1, 1))
+
+
+class _ResnetBlock(nn.Module):
+    """Holder for a stride-1 ResNet-18 BasicBlock (conv1, bn1, conv2, bn2)."""
+
+    def __init__(self, planes):
+        super().__init__()
+        self.conv1 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+
+
+class ResnetMatchingEncoder(nn.Module):
+    """Matching-feature encoder (reference networks.py:149-205): antialiased ResNet-18 stem + layer1, then
+    conv1x1 64->128, InstanceNorm, LeakyReLU(0.2), conv3x3 128->num_ch_out (replicate padding), InstanceNorm.
+
+    `net` has the reference's nn.Sequential numbering (net.0 conv1, net.1 bn1, net.3.1 blur, net.4 layer1,
+    net.5 / net.8 tail convs) so its checkpoints load unchanged.  Inference only: BatchNorm uses running
+    statistics (folded into the conv weights at pack time).  The backbone definition follows the public
+    antialiased_cnns package, which is not available here -- parity for it is pinned against a torch.nn
+    restatement only (oracle/refshim.py)."""
+
+    def __init__(self, num_layers=18, num_ch_out=16, pretrained=False, antialiased=True):
+        super().__init__()
+        if num_layers != 18:
+            raise ValueError("{} is not a valid number of resnet layers".format(num_layers)
+                             if num_layers not in (34, 50, 101, 152) else
+                             "the HIP path implements the 18-layer backbone (what SimpleRecon uses)")
+        if not antialiased:
+            raise ValueError("the HIP path implements the antialiased backbone (what SimpleRecon uses)")
+        if pretrained:
+            raise ValueError("pretrained backbone weights are not downloadable here; load a state_dict instead")
+        self.num_ch_enc = np.array([64, 64])
+        self.num_ch_out = num_ch_out
+        self.net = nn.Sequential(
+            nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False),
+            nn.BatchNorm2d(64),
+            nn.ReLU(inplace=True),
+            nn.Sequential(nn.MaxPool2d(kernel_size=2, stride=1), _BlurPool(64)),
+            nn.Sequential(_ResnetBlock(64), _ResnetBlock(64)),
+            nn.Conv2d(64, 128, (1, 1)),
+            nn.InstanceNorm2d(128),
+            nn.LeakyReLU(0.2, True),
+            nn.Conv2d(128, num_ch_out, (3, 3), padding=1, padding_mode="replicate"),
+            nn.InstanceNorm2d(num_ch_out),
+        )
+
+    def forward(self, input_image):
+        """input_image [B,3,H,W] (H, W multiples of 4) -> [B,num_ch_out,H/4,W/4] (channels_last memory)."""
+        from . import ops
+        net = self.net
+        if self.training:
+            raise RuntimeError("ResnetMatchingEncoder on the HIP path is inference-only (call .eval())")
+        x = ops.stem7x7(input_image, net[0], net[1])                       # conv1 + bn1 + relu
+        x = ops.maxblurpool(x)                                              # MaxPool(2,1) + BlurPool(4,2)
+        for blk in net[4]:
+            t = ops.conv2d(x, blk.conv1, bn=blk.bn1, leaky=0.0)
+            x = ops.conv2d(t, blk.conv2, bn=blk.bn2, residual=x, leaky=0.0)
+        x = ops.conv2d(x, net[5])
+        x = ops.instance_norm(x, eps=net[6].eps, leaky=net[7].negative_slope, inplace=True)
+        x = ops.conv2d(x, net[8])
+        return ops.instance_norm(x, eps=net[9].eps, inplace=True)

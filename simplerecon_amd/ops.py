@@ -57,25 +57,63 @@ def _strides(t):
     return sb, sw
 
 
-def packed_weight(conv: nn.Conv2d):
-    w = conv.weight
-    _lib.require_device_f32("conv weight", w)
-    if conv.kernel_size[0] != conv.kernel_size[1] or conv.kernel_size[0] not in (1, 3) or conv.groups != 1 \
-            or conv.dilation != (1, 1) or conv.padding != (conv.kernel_size[0] // 2,) * 2 \
-            or conv.padding_mode != "zeros":
+def _state_key(conv, bn):
+    ts = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+    if bn is not None:
+        ts += [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
+    return tuple((t._version, t.data_ptr()) for t in ts)
+
+
+def bn_affine(bn):
+    """Eval-mode BatchNorm2d as the per-channel affine ATen's inference path applies:
+    scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale."""
+    if bn.running_mean is None or bn.running_var is None:
+        raise _lib.HipLibraryError("BatchNorm without running statistics cannot run in inference mode")
+    scale = torch.rsqrt(bn.running_var.detach() + bn.eps)
+    if bn.affine:
+        scale = scale * bn.weight.detach()
+    shift = -bn.running_mean.detach() * scale
+    if bn.affine:
+        shift = shift + bn.bias.detach()
+    return scale.contiguous(), shift.contiguous()
+
+
+def _effective_weight(conv, bn):
+    """(weight, bias) of `conv` with an eval-mode BatchNorm `bn` behind it folded in (one-off, at pack time)."""
+    w = conv.weight.detach()
+    b = conv.bias.detach() if conv.bias is not None else None
+    if bn is not None:
+        scale, shift = bn_affine(bn)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = shift if b is None else b * scale + shift
+    return w.contiguous(), b
+
+
+def _check_conv(conv):
+    k = conv.kernel_size[0]
+    if conv.kernel_size[0] != conv.kernel_size[1] or k not in (1, 3) or conv.groups != 1 \
+            or conv.dilation != (1, 1) or tuple(conv.padding) != (k // 2,) * 2 \
+            or conv.padding_mode not in ("zeros", "replicate"):
         raise _lib.HipLibraryError(f"unsupported Conv2d configuration for the HIP path: {conv}")
+
+
+def packed_weight(conv: nn.Conv2d, bn=None):
+    """(packed weight, bias) for the direct kernel; cached until a parameter changes."""
+    _lib.require_device_f32("conv weight", conv.weight)
+    _check_conv(conv)
+    key = _state_key(conv, bn)
     hit = _PACKED.get(conv)
-    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
-        return hit[2]
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
     lib = _lib.lib()
+    w, bias = _effective_weight(conv, bn)
     co, ci, k, _ = w.shape
     packed = torch.empty(lib.sr_conv_packed_weight_floats(co, ci, k), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
-        rc = lib.sr_conv_pack_weights(_lib.ptr(w.detach().contiguous()), co, ci, k, _lib.ptr(packed),
-                                      _lib.stream_ptr(w.device))
+        rc = lib.sr_conv_pack_weights(_lib.ptr(w), co, ci, k, _lib.ptr(packed), _lib.stream_ptr(w.device))
     _lib.check(rc, "sr_conv_pack_weights")
-    _PACKED[conv] = (w._version, w.data_ptr(), packed)
-    return packed
+    _PACKED[conv] = (key, packed, bias)
+    return packed, bias
 
 
 _PACKED_LIN = weakref.WeakKeyDictionary()  # nn.Linear -> (weight version, data_ptr, packed tensor)
@@ -117,24 +155,27 @@ def linear(x, lin: nn.Linear, leaky=None):
 _PACKED_WINO = weakref.WeakKeyDictionary()  # nn.Conv2d -> (weight version, data_ptr, Winograd-packed tensor)
 
 
-def packed_wino_weight(conv: nn.Conv2d):
-    w = conv.weight
+def packed_wino_weight(conv: nn.Conv2d, bn=None):
+    """(Winograd-packed weight U = G g G^T, bias); cached until a parameter changes."""
+    _check_conv(conv)
+    key = _state_key(conv, bn)
     hit = _PACKED_WINO.get(conv)
-    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
-        return hit[2]
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
     lib = _lib.lib()
+    w, bias = _effective_weight(conv, bn)
     co, ci = w.shape[:2]
     packed = torch.empty(lib.sr_wino_packed_weight_floats(co, ci), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
-        rc = lib.sr_wino_pack_weights(_lib.ptr(w.detach().contiguous()), co, ci, _lib.ptr(packed),
-                                      _lib.stream_ptr(w.device))
+        rc = lib.sr_wino_pack_weights(_lib.ptr(w), co, ci, _lib.ptr(packed), _lib.stream_ptr(w.device))
     _lib.check(rc, "sr_wino_pack_weights")
-    _PACKED_WINO[conv] = (w._version, w.data_ptr(), packed)
-    return packed
+    _PACKED_WINO[conv] = (key, packed, bias)
+    return packed, bias
 
 
-def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
-    """act(conv(x) + bias [+ residual]) with the reference's Conv2d semantics; returns a channels-last view."""
+def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None):
+    """act(bn(conv(x) + bias) [+ residual]) with nn.Conv2d semantics (zero or replicate padding); `bn` is an
+    eval-mode BatchNorm2d folded into weight and bias.  Returns a channels-last view."""
     _lib.refuse_autograd(x, conv.weight)
     x = as_nhwc(x, "conv input")
     b, ci, h, w = x.shape
@@ -152,9 +193,9 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
             raise ValueError(f"`out` must be a channels-last view of shape {(b, co, ho, wo)}")
         _lib.require_device_f32("out", out)
     lib = _lib.lib()
-    use_wino = bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, s))
-    wp = packed_wino_weight(conv) if use_wino else packed_weight(conv)
-    bias = conv.bias.detach() if conv.bias is not None else None
+    replicate = conv.padding_mode == "replicate"
+    use_wino = (not replicate) and bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, s))
+    wp, bias = packed_wino_weight(conv, bn) if use_wino else packed_weight(conv, bn)
     if residual is not None:
         residual = as_nhwc(residual, "residual")
         if tuple(residual.shape) != (b, co, ho, wo):
@@ -175,9 +216,9 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None):
                                               rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, slope,
                                               _lib.stream_ptr(x.device))
         else:
-            rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb,
-                                        rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope,
-                                        _lib.stream_ptr(x.device))
+            fwd = lib.sr_conv2d_replicate_nhwc_fwd if replicate else lib.sr_conv2d_nhwc_fwd
+            rc = fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb, rsp, _lib.ptr(out),
+                     osb, osp, b, h, w, ci, co, k, s, slope, _lib.stream_ptr(x.device))
         if prof is not None:
             ev1.record()
             v4 = int(x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0)
@@ -231,3 +272,110 @@ def copy_into(dst_view, src):
     _lib.require_device_f32("copy source", src)
     dst_view.copy_(src)
     return dst_view
+
+
+# ---------------------------------------------------------------- matching encoder ops --
+
+_PACKED_STEM = weakref.WeakKeyDictionary()  # nn.Conv2d -> (state key, packed weight, scale, shift)
+_WORKSPACES = {}                            # (device, tag) -> scratch tensor (grown on demand)
+
+
+def _workspace(device, tag, nbytes):
+    key = (device, tag)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def stem7x7(image, conv: nn.Conv2d, bn=None, leaky=0.0):
+    """act(bn(conv7x7_s2_p3(image))): encoder.conv1 + bn1 + relu of the ResNet stem (reference networks.py:176-179).
+    image [B,3,H,W], any strides; returns channels-last [B,64,H/2,W/2]."""
+    _lib.require_device_f32("image", image)
+    _lib.refuse_autograd(image, conv.weight)
+    if conv.kernel_size != (7, 7) or conv.stride != (2, 2) or tuple(conv.padding) != (3, 3) or conv.groups != 1 \
+            or conv.dilation != (1, 1) or conv.in_channels != 3 or conv.out_channels != 64 \
+            or conv.padding_mode != "zeros":
+        raise _lib.HipLibraryError(f"the HIP stem implements Conv2d(3, 64, 7, stride=2, padding=3) only, got {conv}")
+    if image.dim() != 4 or image.shape[1] != 3:
+        raise ValueError(f"stem expects [B,3,H,W], got {tuple(image.shape)}")
+    _lib.require_device_f32("stem weight", conv.weight)
+    lib = _lib.lib()
+    key = _state_key(conv, bn)
+    hit = _PACKED_STEM.get(conv)
+    if hit is None or hit[0] != key:
+        wp = torch.empty(lib.sr_stem_packed_weight_floats(64), dtype=torch.float32, device=conv.weight.device)
+        with torch.cuda.device(conv.weight.device):
+            _lib.check(lib.sr_stem_pack_weights(_lib.ptr(conv.weight.detach().contiguous()), 64, _lib.ptr(wp),
+                                                _lib.stream_ptr(conv.weight.device)), "sr_stem_pack_weights")
+        scale = shift = None
+        if bn is not None:
+            scale, shift = bn_affine(bn)
+        if conv.bias is not None:
+            cb = conv.bias.detach()
+            shift = (cb if scale is None else cb * scale) + (0 if shift is None else shift)
+            shift = shift.contiguous()
+        hit = (key, wp, scale, shift)
+        _PACKED_STEM[conv] = hit
+    _, wp, scale, shift = hit
+    b, _, h, w = image.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = empty_nhwc(b, 64, ho, wo, image.device)
+    if b == 0:
+        return out
+    sb, sc, sy, sx = image.stride()
+    osb, osp = _strides(out)
+    prof = PROFILE
+    with torch.cuda.device(image.device):
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        rc = lib.sr_stem7x7_fwd(_lib.ptr(image), sb, sc, sy, sx, _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift),
+                                C.c_float(-1.0 if leaky is None else float(leaky)), _lib.ptr(out), osb, osp, b, h, w,
+                                64, _lib.stream_ptr(image.device))
+        if prof is not None:
+            ev1.record()
+            prof.append(("sr_stem_kernel", 2.0 * b * ho * wo * 64 * 147, ev0, ev1, (b, 3, h, w, 64, 7, 2),
+                         2.0 * b * ((ho + 15) // 16) * ((wo + 15) // 16) * 256 * 64 * 168))
+    _lib.check(rc, "sr_stem7x7_fwd")
+    return out
+
+
+def maxblurpool(x):
+    """nn.MaxPool2d(2, stride=1) + antialiased_cnns.BlurPool(filt_size=4, stride=2), fused; channels-last."""
+    x = as_nhwc(x, "maxblurpool input")
+    b, c, h, w = x.shape
+    if h < 4 or w < 4:
+        raise ValueError(f"maxblurpool needs H, W >= 4, got {(h, w)}")
+    ho, wo = (h - 2) // 2 + 1, (w - 2) // 2 + 1
+    out = empty_nhwc(b, c, ho, wo, x.device)
+    if b == 0:
+        return out
+    isb, isp = _strides(x)
+    osb, osp = _strides(out)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().sr_maxblurpool_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(out), osb, osp, b, h, w, c,
+                                                _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_maxblurpool_nhwc_fwd")
+    return out
+
+
+def instance_norm(x, eps=1e-5, leaky=None, inplace=False):
+    """nn.InstanceNorm2d (affine=False) [+ LeakyReLU(leaky)] on channels-last data."""
+    x = as_nhwc(x, "instance_norm input")
+    b, c, h, w = x.shape
+    out = x if inplace else empty_nhwc(b, c, h, w, x.device)
+    if b == 0 or h * w == 0:
+        return out
+    lib = _lib.lib()
+    nbytes = lib.sr_instance_norm_workspace_bytes(b, h, w, c)
+    ws = _workspace(x.device, "inorm", nbytes)
+    isb, isp = _strides(x)
+    osb, osp = _strides(out)
+    with torch.cuda.device(x.device):
+        rc = lib.sr_instance_norm_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(out), osb, osp, b, h, w, c,
+                                           C.c_float(eps), C.c_float(-1.0 if leaky is None else float(leaky)),
+                                           _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_instance_norm_nhwc_fwd")
+    return out

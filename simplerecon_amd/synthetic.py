@@ -107,11 +107,24 @@ def seeded_fill_(module, seed=0, gain=1.0):
     """Deterministically (re)initialises every parameter of `module` from a numpy RNG keyed
     by the parameter NAME, so two modules with the same state-dict layout (ours and the
     reference's) get bit-identical weights without shipping them.  Weights ~ U(-a, a) with
-    a = gain*sqrt(3/fan_in) (variance-preserving), biases ~ U(-0.1, 0.1)."""
+    a = gain*sqrt(3/fan_in) (variance-preserving), biases ~ U(-0.1, 0.1).  BatchNorm layers get
+    non-trivial statistics: weight, running_var ~ U(0.5, 1.5); bias, running_mean ~ U(-0.2, 0.2)."""
+    bn_scale, bn_shift = set(), set()
+    for mname, m in module.named_modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            pre = mname + "." if mname else ""
+            bn_scale.update({pre + "weight", pre + "running_var"})
+            bn_shift.update({pre + "bias", pre + "running_mean"})
     with torch.no_grad():
-        for name, p in module.named_parameters():
+        named = list(module.named_parameters())
+        named += [(n, b) for n, b in module.named_buffers() if n in bn_scale or n in bn_shift]
+        for name, p in named:
             rng = np.random.default_rng((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
-            if p.dim() > 1:
+            if name in bn_scale:
+                v = rng.uniform(0.5, 1.5, size=tuple(p.shape)).astype(np.float32)
+            elif name in bn_shift:
+                v = rng.uniform(-0.2, 0.2, size=tuple(p.shape)).astype(np.float32)
+            elif p.dim() > 1:
                 fan_in = int(np.prod(p.shape[1:]))
                 a = gain * np.sqrt(3.0 / fan_in)
                 v = rng.uniform(-a, a, size=tuple(p.shape)).astype(np.float32)

@@ -92,6 +92,22 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"net_{name}.npz"), **save)
         print(name, {k: tuple(v.shape) for k, v in outs.items()})
 
+    # ---- matching encoder (a16): the reference's ResnetMatchingEncoder on refshim's torch.nn restatement of
+    # the antialiased_cnns ResNet-18 stem (the package is absent; see oracle/refshim.py)
+    for name, case in gc.MATCHING_CASES.items():
+        enc = nets.ResnetMatchingEncoder(18, 16, pretrained=False)
+        synthetic.seeded_fill_(enc, seed=case["seed"])
+        enc.eval()
+        x = gc.matching_input(case)
+        with torch.inference_mode():
+            stem = enc.net[2](enc.net[1](enc.net[0](x)))
+            pool = enc.net[3](stem)
+            layer1 = enc.net[4](pool)
+            y = enc(x)
+        np.savez_compressed(os.path.join(OUT, f"matching_{name}.npz"), out=y.numpy(), stem=stem.numpy(),
+                            pool=pool.numpy(), layer1=layer1.numpy())
+        print(name, y.shape, float(y.abs().max()))
+
 
 if __name__ == "__main__":
     main()

@@ -97,3 +97,18 @@ def net_inputs(case, device="cpu"):
     vol = torch.from_numpy(rng.standard_normal((case["B"], case["D"], case["h"], case["w"]), dtype=np.float32))
     feats = synthetic.image_prior_pyramid(case["B"], case["h"], case["w"], chans=case["enc_ch"], seed=case["seed"])
     return vol.to(device), [f.to(device) for f in feats]
+
+
+# ------------------------------------------------------------ matching encoder (a16)
+
+MATCHING_CASES = {
+    # image [B,3,H,W] -> features [B,16,H/4,W/4]
+    "small": dict(B=2, H=64, W=96, seed=41),
+    "ragged": dict(B=1, H=40, W=72, seed=42),     # H/4 = 10, W/4 = 18: partial tiles in every kernel
+}
+
+
+def matching_input(case, device="cpu"):
+    rng = np.random.default_rng(case["seed"])
+    x = rng.standard_normal((case["B"], 3, case["H"], case["W"]), dtype=np.float32)
+    return torch.from_numpy(x).to(device)

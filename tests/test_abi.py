@@ -58,3 +58,18 @@ def test_argument_validation():
     assert m2.mlp.net[0].in_features == 202
     assert [k for k in CostVolumeManager(8, 12, 4).state_dict()] == [
         "linear_ramp_1d11", "backprojector.pix_coords_13N", "projector.eps"]
+
+
+def test_matching_encoder_state_dict_names():
+    """Checkpoint compatibility: the key set of the reference's ResnetMatchingEncoder(18, 16) state_dict
+    (modules/networks.py:185-202 on the antialiased ResNet-18 backbone; verified against the reference class in the
+    build container through oracle/refshim.py)."""
+    from simplerecon_amd.networks import ResnetMatchingEncoder
+    keys = set(ResnetMatchingEncoder(18, 16).state_dict())
+    bn = ["weight", "bias", "running_mean", "running_var", "num_batches_tracked"]
+    expect = {"net.0.weight", "net.3.1.filt", "net.5.weight", "net.5.bias", "net.8.weight", "net.8.bias"}
+    expect |= {f"net.1.{k}" for k in bn}
+    for blk in (0, 1):
+        expect |= {f"net.4.{blk}.conv1.weight", f"net.4.{blk}.conv2.weight"}
+        expect |= {f"net.4.{blk}.bn{i}.{k}" for i in (1, 2) for k in bn}
+    assert keys == expect

@@ -1,0 +1,145 @@
+"""GPU parity of the matching-feature encoder (reference modules/networks.py:149-205) --
+stem conv7x7+BN+ReLU, MaxPool+BlurPool, layer1, InstanceNorm tail -- against the CPU oracle and the golden
+vectors of the reference's ResnetMatchingEncoder."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import golden_cases as gc
+import oracle
+from parity import assert_close
+from simplerecon_amd import ops, synthetic
+from simplerecon_amd.networks import ResnetMatchingEncoder
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _nchw(t):
+    return t.detach().cpu().contiguous().numpy()
+
+
+@pytest.mark.parametrize("name", list(gc.MATCHING_CASES))
+def test_matching_encoder_stages_vs_golden(name):
+    case = gc.MATCHING_CASES[name]
+    enc = synthetic.seeded_fill_(ResnetMatchingEncoder(18, 16), seed=case["seed"]).to(DEV).eval()
+    gold = gc.load_golden("matching", name)
+    x = gc.matching_input(case).to(DEV)
+    net = enc.net
+    with torch.inference_mode():
+        stem = ops.stem7x7(x, net[0], net[1])
+        pool = ops.maxblurpool(stem)
+        t = pool
+        for blk in net[4]:
+            u = ops.conv2d(t, blk.conv1, bn=blk.bn1, leaky=0.0)
+            t = ops.conv2d(u, blk.conv2, bn=blk.bn2, residual=t, leaky=0.0)
+        out = enc(x)
+    torch.cuda.synchronize()
+    assert_close(stem, gold["stem"], what=f"{name} stem conv+bn+relu")
+    assert_close(pool, gold["pool"], what=f"{name} maxpool+blurpool")
+    assert_close(t, gold["layer1"], what=f"{name} layer1")
+    assert tuple(out.shape) == gold["out"].shape
+    assert_close(out, gold["out"], what=f"{name} matching features vs reference golden")
+    sd = {k: v.cpu().numpy() for k, v in enc.state_dict().items()}
+    assert_close(out, oracle.resnet_matching_encoder(_nchw(x), sd), what=f"{name} matching features vs oracle")
+
+
+def test_stem_channels_last_image_and_no_bn():
+    """The stem reads the image through its strides (NCHW or channels-last) and without a BatchNorm."""
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((2, 3, 50, 70), dtype=np.float32)).to(DEV)
+    conv = synthetic.seeded_fill_(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=True), seed=3).to(DEV)
+    with torch.inference_mode():
+        a = ops.stem7x7(x, conv, None, leaky=None)
+        b = ops.stem7x7(x.contiguous(memory_format=torch.channels_last), conv, None, leaky=None)
+    assert torch.equal(a, b)
+    ref = oracle.conv2d(_nchw(x), _nchw(conv.weight), _nchw(conv.bias), stride=2, pad=3)
+    assert_close(a, ref, what="stem conv (bias, no BN, no activation)")
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 9, 11), (2, 64, 16, 24), (1, 4, 4, 4), (1, 12, 31, 6)])
+def test_maxblurpool(shape):
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape, dtype=np.float32)
+    with torch.inference_mode():
+        y = ops.maxblurpool(torch.from_numpy(x).to(DEV))
+    ref = oracle.blurpool4_s2(oracle.maxpool2_s1(x))
+    assert tuple(y.shape) == ref.shape
+    assert_close(y, ref, tol=1e-6, what=f"maxblurpool {shape}")
+
+
+@pytest.mark.parametrize("shape,leaky", [((2, 128, 10, 18), 0.2), ((3, 16, 30, 40), None), ((1, 16, 120, 160), None),
+                                         ((1, 48, 7, 5), 0.2), ((2, 128, 120, 160), 0.2)])
+def test_instance_norm(shape, leaky):
+    rng = np.random.default_rng(sum(shape))
+    # channel-dependent mean and spread, as a conv output has
+    x = rng.standard_normal(shape, dtype=np.float32) * rng.uniform(0.2, 3.0, size=(1, shape[1], 1, 1)).astype(np.float32) \
+        + rng.uniform(-2, 2, size=(shape[0], shape[1], 1, 1)).astype(np.float32)
+    xt = torch.from_numpy(x).to(DEV)
+    with torch.inference_mode():
+        y = ops.instance_norm(xt, leaky=leaky)
+        y2 = ops.instance_norm(xt.clone(memory_format=torch.channels_last), leaky=leaky, inplace=True)
+    assert torch.equal(y, y2), "in-place and out-of-place results differ"
+    ref = oracle.instance_norm(x.astype(np.float64), leaky=leaky)
+    assert_close(y, ref, tol=2e-5, what=f"instance_norm {shape}")
+    # deterministic (no atomics): a second launch is bit-identical
+    with torch.inference_mode():
+        assert torch.equal(y, ops.instance_norm(xt, leaky=leaky))
+
+
+def test_replicate_padded_conv():
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 128, 10, 18), dtype=np.float32)
+    conv = synthetic.seeded_fill_(nn.Conv2d(128, 16, 3, padding=1, padding_mode="replicate"), seed=4).to(DEV)
+    with torch.inference_mode():
+        y = ops.conv2d(torch.from_numpy(x).to(DEV), conv)
+    ref = oracle.conv2d_replicate(x, _nchw(conv.weight), _nchw(conv.bias))
+    assert_close(y, ref, tol=1e-5, what="replicate-padded conv3x3")
+    zero = oracle.conv2d(x, _nchw(conv.weight), _nchw(conv.bias))
+    assert np.abs(_nchw(y)[:, :, 1:-1, 1:-1] - zero[:, :, 1:-1, 1:-1]).max() < 1e-4  # interior = zero-padded conv
+
+
+def test_batchnorm_fold_matches_unfolded_oracle():
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((1, 64, 12, 20), dtype=np.float32)
+    conv = synthetic.seeded_fill_(nn.Conv2d(64, 64, 3, padding=1, bias=False), seed=6).to(DEV)
+    bn = synthetic.seeded_fill_(nn.BatchNorm2d(64), seed=7).to(DEV).eval()
+    with torch.inference_mode():
+        y = ops.conv2d(torch.from_numpy(x).to(DEV), conv, bn=bn, leaky=0.0)
+        bn.running_mean.add_(0.5)  # the packed-weight cache follows parameter / buffer updates
+        y_shift = ops.conv2d(torch.from_numpy(x).to(DEV), conv, bn=bn, leaky=0.0)
+    sd = {k: _nchw(v) for k, v in bn.state_dict().items()}
+    sd0 = dict(sd, running_mean=sd["running_mean"] - 0.5)
+    ref = np.maximum(oracle.batchnorm_eval(oracle.conv2d(x, _nchw(conv.weight)), sd0, ""), 0)
+    assert_close(y, ref, tol=1e-5, what="conv + folded BatchNorm + ReLU")
+    ref2 = np.maximum(oracle.batchnorm_eval(oracle.conv2d(x, _nchw(conv.weight)), sd, ""), 0)
+    assert_close(y_shift, ref2, tol=1e-5, what="conv + folded BatchNorm after a buffer update")
+
+
+def test_full_size_properties():
+    """640x480 images (BASELINE cfg2/3 size): InstanceNorm'd outputs have zero mean / unit variance per image and
+    channel, and every image is processed independently of its batch neighbours (bitwise)."""
+    enc = synthetic.seeded_fill_(ResnetMatchingEncoder(18, 16), seed=1).to(DEV).eval()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn((3, 3, 480, 640), generator=g).to(DEV)
+    with torch.inference_mode():
+        y = enc(x)
+        y1 = enc(x[1:2])
+    assert tuple(y.shape) == (3, 16, 120, 160)
+    assert torch.equal(y[1:2], y1)
+    m = y.double().mean(dim=(2, 3))
+    v = y.double().var(dim=(2, 3), unbiased=False)
+    assert float(m.abs().max()) < 1e-4 and float((v - 1).abs().max()) < 1e-3, (float(m.abs().max()), float((v - 1).abs().max()))
+
+
+def test_training_mode_and_bad_configs_fail_loudly():
+    enc = ResnetMatchingEncoder(18, 16).to(DEV)
+    with pytest.raises(RuntimeError):
+        enc.train()(torch.zeros(1, 3, 32, 32, device=DEV))
+    with pytest.raises(ValueError):
+        ResnetMatchingEncoder(17, 16)
+    with pytest.raises(ValueError), torch.inference_mode():
+        ops.stem7x7(torch.zeros(1, 4, 32, 32, device=DEV), enc.net[0], enc.net[1])
+    with pytest.raises(NotImplementedError):  # autograd is refused, not silently ignored
+        enc.eval()(torch.zeros(1, 3, 32, 32, device=DEV))

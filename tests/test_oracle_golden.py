@@ -113,3 +113,21 @@ def test_encoder_decoder_oracle(name):
     outs = oracle.depth_decoder_pp([feats[0].numpy()] + cvf, dsd)
     for k, v in outs.items():
         assert_close(v, gold[k], what=f"{name} decoder {k}")
+
+
+@pytest.mark.parametrize("name", list(gc.MATCHING_CASES))
+def test_matching_encoder_oracle(name):
+    """oracle.resnet_matching_encoder vs the reference's ResnetMatchingEncoder (networks.py:149-205) run on
+    refshim's torch.nn restatement of the antialiased ResNet-18 stem."""
+    from simplerecon_amd.networks import ResnetMatchingEncoder
+    case = gc.MATCHING_CASES[name]
+    enc = synthetic.seeded_fill_(ResnetMatchingEncoder(18, 16), seed=case["seed"])
+    sd = {k: v.numpy() for k, v in enc.state_dict().items()}
+    gold = gc.load_golden("matching", name)
+    taps = {}
+    out = oracle.resnet_matching_encoder(gc.matching_input(case).numpy(), sd, taps=taps)
+    for k in ("stem", "pool", "layer1"):
+        assert_close(taps[k], gold[k], what=f"{name} {k}")
+    assert_close(out, gold["out"], what=f"{name} matching features")
+    out64 = oracle.resnet_matching_encoder(gc.matching_input(case).numpy(), sd, precision="f64")
+    assert_close(out64, gold["out"], what=f"{name} matching features (f64 arbitration)")
