@@ -143,22 +143,30 @@ class DotCfg2:
 
 class HeroCfg3:
     """BASELINE.json configs[2]: hero_model.yaml (metadata-MLP matching), batch 8, 7 source views,
-    64 planes, 640x480: the full hot path = FeatureVolumeManager sweep -> CVEncoder -> DepthDecoderPP
-    -> exp, all on hand-written HIP kernels.  Inputs = the encoders' outputs, resident in HBM."""
+    64 planes, 640x480: the hot path = ResnetMatchingEncoder on the B*(1+K) images -> FeatureVolumeManager sweep
+    -> CVEncoder -> DepthDecoderPP -> exp, all on hand-written HIP kernels.  Inputs = the images and the image-prior
+    pyramid (the third-party EfficientNetV2-S encoder is outside the path), resident in HBM.
+    with_encoder=False ("*_core" workloads) starts from synthetic matching features instead."""
     name = "hero_cfg3"
     B, K, Cc, D, h, w = 8, 7, 16, 64, 120, 160
     feature_volume_type = "mlp_feature_volume"
 
-    def __init__(self, dev, rank, B=None, streams=1):
+    def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None):
         from simplerecon_amd import depth_model as dm
         if B is not None:
             self.B = B
+        if name is not None:
+            self.name = name
+        self.with_encoder = with_encoder
         self.streams = streams
         self.dev = dev
         self.frames_per_step = self.B
         opts = dm.default_options(image_width=4 * self.w, image_height=4 * self.h, model_num_views=self.K + 1,
                                   matching_num_depth_bins=self.D, feature_volume_type=self.feature_volume_type)
-        model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(), matching_encoder=dm.StandInMatchingEncoder())
+        model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(),
+                              matching_encoder=None if with_encoder else dm.StandInMatchingEncoder())
+        if with_encoder:
+            synthetic.seeded_fill_(model.matching_model, seed=4)
         synthetic.seeded_fill_(model.cost_volume_net, seed=1)
         synthetic.seeded_fill_(model.depth_decoder, seed=2)
         if hasattr(model.cost_volume, "mlp"):
@@ -169,12 +177,20 @@ class HeroCfg3:
         self.inp = inp
         self.pyramid = [f.contiguous(memory_format=torch.channels_last) for f in
                         synthetic.image_prior_pyramid(self.B, self.h, self.w, seed=rank, device=dev)]
+        if with_encoder:  # ImageNet-normalised images ~ N(0,1)
+            g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+            self.cur_image = torch.randn((self.B, 3, 4 * self.h, 4 * self.w), generator=g).to(dev)
+            self.src_image = torch.randn((self.B, self.K, 3, 4 * self.h, 4 * self.w), generator=g).to(dev)
         self.results = []
         self.last = None
 
     def step(self, i=0):
         inp = self.inp
-        out = self.model.hot_path(self.pyramid, inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"],
+        if self.with_encoder:
+            cur_f, src_f = self.model.compute_matching_feats(self.cur_image, self.src_image, False)
+        else:
+            cur_f, src_f = inp["cur_feats"], inp["src_feats"]
+        out = self.model.hot_path(self.pyramid, cur_f, src_f, inp["src_extrinsics"],
                                   inp["src_poses"], inp["src_Ks"], inp["cur_invK"], return_mask=True)
         self.last = out
 
@@ -187,10 +203,14 @@ class HeroCfg3:
     def config(self, world):
         kind = "FeatureVolumeManager (metadata-MLP matching)" if self.feature_volume_type == "mlp_feature_volume" \
             else "CostVolumeManager (dot-product matching)"
-        return {"workload": f"{self.name}: hot path = {kind} -> CVEncoder -> DepthDecoderPP -> exp, batch "
+        enc = (f"ResnetMatchingEncoder on {self.B}x{self.K + 1} images -> " if self.with_encoder else "")
+        skipped = ("image-prior encoder (third-party EfficientNetV2-S, outside the path) not timed: its pyramid is a "
+                   "synthetic input" if self.with_encoder else
+                   "image-prior and matching encoders not timed: their outputs are synthetic inputs")
+        return {"workload": f"{self.name}: hot path = {enc}{kind} -> CVEncoder -> DepthDecoderPP -> exp, batch "
                             f"{self.B}/GPU, {self.K} source views, {self.D} planes, 640x480 image ({self.h}x{self.w} "
                             f"matching features x {self.Cc} ch, image-prior pyramid 24/48/64/160/256 ch), fp32, "
-                            f"random-init weights; image/matching encoders (third-party, out of scope) not timed",
+                            f"random-init weights; {skipped}",
                 "frames_per_step_per_gpu": self.B, "hip_streams_per_gpu": self.streams,
                 "parallelism": f"replica x{world} (keyframes sharded)"}
 
@@ -206,6 +226,8 @@ class HeroCfg3:
             ops.PROFILE = []
             try:
                 for _ in range(n):
+                    if self.with_encoder:
+                        self.model.compute_matching_feats(self.cur_image, self.src_image, False)
                     feats = self.model.cost_volume_net(vol, self.pyramid[1:])
                     self.model.depth_decoder(self.pyramid[:1] + feats)
                 torch.cuda.synchronize()
@@ -295,12 +317,20 @@ class HeroCfg3:
             mlp = dict(W1=sd["net.0.weight"], b1=sd["net.0.bias"], W2=sd["net.2.weight"], b2=sd["net.2.bias"],
                        W3=sd["net.4.weight"], b3=sd["net.4.bias"])
 
+        if self.with_encoder:
+            msd = {k: v.cpu().numpy() for k, v in m.matching_model.state_dict().items()}
+            images = torch.cat([self.cur_image[:1].unsqueeze(1), self.src_image[:1]], dim=1)[0].cpu().numpy()
+
         def run():
+            cur_f, src_f = inp["cur_feats"], inp["src_feats"]
+            if self.with_encoder:
+                f = oracle.resnet_matching_encoder(images, msd)
+                cur_f, src_f = f[None, 0], f[None, 1:]
             if self.feature_volume_type == "mlp_feature_volume":
-                vol = oracle.mlp_volume(inp["cur_feats"], inp["src_feats"], inp["src_Ks"], inp["src_extrinsics"],
+                vol = oracle.mlp_volume(cur_f, src_f, inp["src_Ks"], inp["src_extrinsics"],
                                         inp["src_poses"], inp["cur_invK"], planes, mlp)[0]
             else:
-                vol = oracle.dot_volume(inp["cur_feats"], inp["src_feats"], inp["src_Ks"], inp["src_extrinsics"],
+                vol = oracle.dot_volume(cur_f, src_f, inp["src_Ks"], inp["src_extrinsics"],
                                         inp["cur_invK"], planes)[0]
             feats = oracle.cv_encoder(vol, pyr[1:], esd)
             return oracle.depth_decoder_pp([pyr[0]] + feats, dsd)
@@ -312,7 +342,9 @@ class HeroCfg3:
             reps += 1
         dt = (time.perf_counter() - t0) / reps
         return {"value": 1.0 / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
-                "sample": f"{reps} repetition(s) of 1 frame of {self.name} (cost volume + CVEncoder + DepthDecoderPP) "
+                "sample": f"{reps} repetition(s) of 1 frame of {self.name} ("
+                          f"{'matching encoder on 8 images + ' if self.with_encoder else ''}"
+                          f"cost volume + CVEncoder + DepthDecoderPP) "
                           f"through oracle/ (plain C + OpenMP restatement, {oracle.num_threads()} threads of "
                           f"{os.cpu_count()} host CPUs)"}
 
@@ -377,7 +409,9 @@ class DotFull(HeroCfg3):
 
 WORKLOADS = {
     "hero_cfg3": lambda dev, rank: HeroCfg3(dev, rank),
-    "hero_b1": lambda dev, rank: HeroCfg3(dev, rank, B=1),
+    "hero_b1": lambda dev, rank: HeroCfg3(dev, rank, B=1, name="hero_b1"),
+    "hero_cfg3_core": lambda dev, rank: HeroCfg3(dev, rank, with_encoder=False, name="hero_cfg3_core"),
+    "hero_b1_core": lambda dev, rank: HeroCfg3(dev, rank, B=1, with_encoder=False, name="hero_b1_core"),
     "hero_cfg3_s2": lambda dev, rank: HeroCfg3(dev, rank, streams=2),
     "hero_cfg3_s4": lambda dev, rank: HeroCfg3(dev, rank, streams=4),
     "dot_full": lambda dev, rank: DotFull(dev, rank),

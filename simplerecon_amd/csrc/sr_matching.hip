@@ -66,19 +66,42 @@ __global__ __launch_bounds__(256, 2) void sr_stem_kernel(SrStemParams p) {
     sh[n] = p.shift ? p.shift[n * 32 + i] : 0.f;
   }
 
+  // The next tile's patch is fetched into registers while the current tile's MFMAs run (one LDS patch buffer:
+  // the stores happen between two barriers after the MFMA loop), so the global-load latency is off the critical path.
+  constexpr int PF = (SR_STEM_PFLOATS + 255) / 256;
+  float pf[PF];
+  auto fetch = [&](int tile) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const float* __restrict__ img = p.in + (int64_t)b * p.sb;
+#pragma unroll
+    for (int it = 0; it < PF; ++it) {
+      const int e = threadIdx.x + it * 256;
+      const int c = e / (SR_STEM_PR * SR_STEM_PW), rem = e - c * (SR_STEM_PR * SR_STEM_PW);
+      const int r = rem / SR_STEM_PW, x = rem - r * SR_STEM_PW;
+      const int gy = 2 * ty * SR_STEM_T - 3 + r, gx = 2 * tx * SR_STEM_T - 3 + x;
+      const bool ok = (e < SR_STEM_PFLOATS) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
+      const int64_t off = ok ? c * p.sc + gy * p.sy + gx * p.sx : 0;
+      const float v = img[off];
+      pf[it] = ok ? v : 0.f;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int it = 0; it < PF; ++it) {
+      const int e = threadIdx.x + it * 256;
+      if (e < SR_STEM_PFLOATS) patch[e] = pf[it];
+    }
+  };
+  if ((int)blockIdx.x < p.total) fetch(blockIdx.x);
+  stash();
+  __syncthreads();  // weights + first patch in place
+
   for (int tile = blockIdx.x; tile < p.total; tile += gridDim.x) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
     const int oy0 = ty * SR_STEM_T, ox0 = tx * SR_STEM_T;
-    const float* __restrict__ img = p.in + (int64_t)b * p.sb;
-    __syncthreads();  // the previous tile's fragment reads are done (and the weights are in place)
-    for (int e = threadIdx.x; e < SR_STEM_PFLOATS; e += 256) {
-      const int c = e / (SR_STEM_PR * SR_STEM_PW), rem = e - c * (SR_STEM_PR * SR_STEM_PW);
-      const int r = rem / SR_STEM_PW, x = rem - r * SR_STEM_PW;
-      const int gy = 2 * oy0 - 3 + r, gx = 2 * ox0 - 3 + x;
-      const bool ok = (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
-      patch[e] = ok ? img[c * p.sc + gy * p.sy + gx * p.sx] : 0.f;
-    }
-    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < p.total) fetch(next);
+    __builtin_amdgcn_sched_barrier(0);
 
     v16f acc[2][2];
 #pragma unroll
@@ -103,6 +126,10 @@ __global__ __launch_bounds__(256, 2) void sr_stem_kernel(SrStemParams p) {
           acc[0][1] = SR_MFMA(a0, w.y, acc[0][1]);
           acc[1][1] = SR_MFMA(a1, w.y, acc[1][1]);
         }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // every wave is done reading this tile's patch
+    if (next < p.total) stash();
+    __syncthreads();
 
     float* __restrict__ ob = p.out + (int64_t)b * p.out_sb;
 #pragma unroll
@@ -138,60 +165,86 @@ __device__ __forceinline__ float4 sr_axpy4(float s, float4 a, float4 acc) {
   return make_float4(acc.x + s * a.x, acc.y + s * a.y, acc.z + s * a.z, acc.w + s * a.w);
 }
 
+__device__ __forceinline__ float4 sr_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// One output pixel through the generic (reflected) path: 16 max-pooled samples, 4 loads each.
+__device__ __forceinline__ float4 sr_maxblur_generic(const float* __restrict__ ib, int in_sp, int W, int Hm, int Wm,
+                                                     int oy, int ox, int c4) {
+  const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < 4; ++i) {
+    const int my = sr_reflect(2 * oy - 1 + i, Hm);
+    float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 4; ++j) {
+      const int mx = sr_reflect(2 * ox - 1 + j, Wm);
+      const float* q = ib + ((int64_t)my * W + mx) * in_sp + 4 * c4;
+      row = sr_axpy4(f[j], sr_max4(sr_max4(sr_ld4(q), sr_ld4(q + in_sp)),
+                                   sr_max4(sr_ld4(q + (int64_t)W * in_sp), sr_ld4(q + (int64_t)W * in_sp + in_sp))), row);
+    }
+    acc = sr_axpy4(f[i], row, acc);
+  }
+  return acc;
+}
+
+// One thread = a 2x2 block of output pixels x 4 channels.  Interior blocks stream their 7x7 input window row by
+// row (49 float4 loads for 4 outputs): vertical max with the previous row, horizontal max, horizontal blur for the
+// two output columns, then the row's contribution to the two output rows.
 __global__ __launch_bounds__(256) void sr_maxblurpool_kernel(const float* __restrict__ in, int64_t in_sb, int in_sp,
                                                              float* __restrict__ out, int64_t out_sb, int out_sp,
                                                              int H, int W, int Ho, int Wo, int C4) {
   const int Hm = H - 1, Wm = W - 1;
-  const int64_t total = (int64_t)Ho * Wo * C4;
+  const int bx = (Wo + 1) / 2, by = (Ho + 1) / 2;
+  const int64_t total = (int64_t)bx * by * C4;
   const float* __restrict__ ib = in + (int64_t)blockIdx.y * in_sb;
   float* __restrict__ ob = out + (int64_t)blockIdx.y * out_sb;
   const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % C4);
-    const int pix = (int)(idx / C4);
-    const int oy = pix / Wo, ox = pix - oy * Wo;
-    const int y0 = 2 * oy - 1, x0 = 2 * ox - 1;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (y0 >= 0 && y0 + 3 < Hm && x0 >= 0 && x0 + 3 < Wm) {
-      float4 vm[4][5];  // vertical max of rows (y0+i, y0+i+1) at the 5 window columns
-      float4 prev[5];
+    const int blk = (int)(idx / C4);
+    const int oy0 = 2 * (blk / bx), ox0 = 2 * (blk % bx);
+    const int y0 = 2 * oy0 - 1, x0 = 2 * ox0 - 1;  // first max-pooled row / column of the window
+    if (y0 >= 0 && y0 + 5 < Hm && x0 >= 0 && x0 + 5 < Wm && oy0 + 1 < Ho && ox0 + 1 < Wo) {
+      const float* q = ib + ((int64_t)y0 * W + x0) * in_sp + 4 * c4;
+      float4 prev[7], acc[2][2];
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
-        prev[j] = *reinterpret_cast<const float4*>(ib + ((int64_t)y0 * W + x0 + j) * in_sp + 4 * c4);
+      for (int j = 0; j < 7; ++j) prev[j] = sr_ld4(q + (int64_t)j * in_sp);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float4 cur[5];
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          cur[j] = *reinterpret_cast<const float4*>(ib + ((int64_t)(y0 + i + 1) * W + x0 + j) * in_sp + 4 * c4);
-          vm[i][j] = sr_max4(prev[j], cur[j]);
-          prev[j] = cur[j];
+        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        q += (int64_t)W * in_sp;
+        float4 vm[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const float4 cur = sr_ld4(q + (int64_t)j * in_sp);
+          vm[j] = sr_max4(prev[j], cur);
+          prev[j] = cur;
         }
-      }
+        float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) row = sr_axpy4(f[j], sr_max4(vm[i][j], vm[i][j + 1]), row);
-        acc = sr_axpy4(f[i], row, acc);
-      }
-    } else {
-      for (int i = 0; i < 4; ++i) {
-        const int my = sr_reflect(y0 + i, Hm);
-        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = 0; j < 4; ++j) {
-          const int mx = sr_reflect(x0 + j, Wm);
-          const float* q = ib + ((int64_t)my * W + mx) * in_sp + 4 * c4;
-          const float4 a = *reinterpret_cast<const float4*>(q);
-          const float4 bq = *reinterpret_cast<const float4*>(q + in_sp);
-          const float4 c = *reinterpret_cast<const float4*>(q + (int64_t)W * in_sp);
-          const float4 d = *reinterpret_cast<const float4*>(q + (int64_t)W * in_sp + in_sp);
-          row = sr_axpy4(f[j], sr_max4(sr_max4(a, bq), sr_max4(c, d)), row);
+          h0 = sr_axpy4(f[j], sr_max4(vm[j], vm[j + 1]), h0);
+          h1 = sr_axpy4(f[j], sr_max4(vm[j + 2], vm[j + 3]), h1);
         }
-        acc = sr_axpy4(f[i], row, acc);
+        if (i < 4) { acc[0][0] = sr_axpy4(f[i], h0, acc[0][0]); acc[0][1] = sr_axpy4(f[i], h1, acc[0][1]); }
+        if (i >= 2) { acc[1][0] = sr_axpy4(f[i - 2], h0, acc[1][0]); acc[1][1] = sr_axpy4(f[i - 2], h1, acc[1][1]); }
       }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+          *reinterpret_cast<float4*>(ob + ((int64_t)(oy0 + a) * Wo + ox0 + b2) * out_sp + 4 * c4) = acc[a][b2];
+    } else {
+      for (int a = 0; a < 2; ++a)
+        for (int b2 = 0; b2 < 2; ++b2) {
+          const int oy = oy0 + a, ox = ox0 + b2;
+          if (oy < Ho && ox < Wo)
+            *reinterpret_cast<float4*>(ob + ((int64_t)oy * Wo + ox) * out_sp + 4 * c4) =
+                sr_maxblur_generic(ib, in_sp, W, Hm, Wm, oy, ox, c4);
+        }
     }
-    *reinterpret_cast<float4*>(ob + (int64_t)pix * out_sp + 4 * c4) = acc;
   }
 }
 
@@ -356,7 +409,7 @@ extern "C" int sr_maxblurpool_nhwc_fwd(const float* in, int64_t in_batch_stride,
       ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
     return SR_ERR_UNSUPPORTED;
   const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
-  const int64_t total = (int64_t)Ho * Wo * (C / 4);
+  const int64_t total = (int64_t)((Ho + 1) / 2) * ((Wo + 1) / 2) * (C / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(sr_maxblurpool_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, in, in_batch_stride,
                      in_pix_stride, out, out_batch_stride, out_pix_stride, H, W, Ho, Wo, C / 4);

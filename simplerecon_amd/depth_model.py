@@ -5,11 +5,11 @@ without the PyTorch-Lightning / losses / training machinery (out of scope, SURVE
     model = DepthModel(opts)                      # opts: reference options.Options or default_options()
     outputs = model("test", cur_data, src_data, unbatched_matching_encoder_forward=True, return_mask=True)
 
-The two image encoders (timm EfficientNetV2-S image prior, antialiased ResNet18 matching encoder,
-reference depth_model.py:110-116, networks.py:149-205) are third-party models that are NOT part of
-this hot path (SURVEY.md §8f "next" #1): they are pluggable.  By default the reference's own
-constructors are used when timm / antialiased_cnns are importable; `hot_path()` -- what bench.py
-times -- starts from their outputs.
+The matching encoder (antialiased ResNet-18 stem + InstanceNorm tail, reference networks.py:149-205,
+SURVEY.md §8 a16) is built natively (networks.ResnetMatchingEncoder, HIP kernels).  The image-prior
+encoder (timm EfficientNetV2-S, reference depth_model.py:110-116) is a third-party model outside this
+path (SURVEY.md §8f "next" #1): it is pluggable, and by default the reference's own constructor is
+used when timm is importable.  `hot_path()` -- what bench.py times -- starts from the encoders' outputs.
 """
 from dataclasses import dataclass
 
@@ -18,7 +18,7 @@ from torch import nn
 
 from .cost_volume import CostVolumeManager, FeatureVolumeManager
 from .layers import TensorFormatter
-from .networks import CVEncoder, DepthDecoderPP
+from .networks import CVEncoder, DepthDecoderPP, ResnetMatchingEncoder
 
 
 @dataclass
@@ -66,15 +66,6 @@ def _reference_image_encoder():
     return enc
 
 
-def _reference_matching_encoder(dims):
-    try:
-        import antialiased_cnns  # noqa: F401
-    except ImportError as e:
-        raise ImportError("the matching encoder needs `antialiased_cnns` (reference networks.py:163-174); pass "
-                          "matching_encoder=... to DepthModel to plug in another /4-resolution encoder") from e
-    raise NotImplementedError("construct reference modules.networks.ResnetMatchingEncoder and pass it in")
-
-
 class DepthModel(nn.Module):
     def __init__(self, opts, image_encoder=None, matching_encoder=None):
         super().__init__()
@@ -113,9 +104,14 @@ class DepthModel(nn.Module):
         self.cost_volume.volume_memory_format = torch.channels_last
 
         if matching_encoder is None:
-            if opts.matching_encoder_type not in ("resnet", "unet_encoder"):
+            if opts.matching_encoder_type == "resnet":
+                # reference depth_model.py:181-182: ResnetMatchingEncoder(18, matching_feature_dims)
+                matching_encoder = ResnetMatchingEncoder(18, opts.matching_feature_dims).eval()
+            elif opts.matching_encoder_type == "unet_encoder":
+                raise NotImplementedError("UNetMatchingEncoder needs timm + torchvision FPN (reference "
+                                          "networks.py:207-251); pass matching_encoder=... to plug one in")
+            else:
                 raise ValueError(f"Unrecognized option {opts.matching_encoder_type} for matching encoder type!")
-            matching_encoder = _reference_matching_encoder(opts.matching_feature_dims)
         self.matching_model = matching_encoder
         self.tensor_formatter = TensorFormatter()
         # Keyframes of a batch are independent: hot_path() can run `num_streams` sub-batches on separate
