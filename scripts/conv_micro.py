@@ -6,6 +6,8 @@ from simplerecon_amd import ops
 dev = "cuda:0"
 shapes = [(8, 64, 240, 320, 64, 3), (8, 192, 240, 320, 64, 3), (8, 64, 120, 160, 64, 3), (8, 192, 240, 320, 64, 1),
           (8, 256, 30, 40, 256, 3), (8, 384, 15, 20, 384, 3), (1, 64, 240, 320, 64, 3)]
+if os.environ.get("SR_MICRO_SHAPES"):
+    shapes = [shapes[int(i)] for i in os.environ["SR_MICRO_SHAPES"].split(",")]
 for (B, ci, H, W, co, k) in shapes:
     conv = torch.nn.Conv2d(ci, co, k, padding=k // 2).to(dev)
     x = torch.randn(B, ci, H, W, device=dev).contiguous(memory_format=torch.channels_last)

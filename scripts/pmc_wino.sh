@@ -1,5 +1,23 @@
 #!/bin/bash
+# LDS / wait counters of the Winograd kernel on the dominant layer shape (one --pmc pass per counter group).
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; cd /tmp; export TMPDIR=/tmp
-export SR_CONV_WINO=2
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_wino -o w -- python $R/scripts/conv_micro.py > $O/pmc_wino.log 2>&1
-ls $O/pmc_wino
+export SR_MICRO_SHAPES=${SR_MICRO_SHAPES:-0}
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT" \
+           "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" \
+           "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $O/pmc_wino$i -o w -- python $R/scripts/conv_micro.py > $O/pmc_wino$i.log 2>&1
+done
+python - <<PY
+import csv, glob, collections
+for d in sorted(glob.glob("$O/pmc_wino?")):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"][:40]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        for k, v in agg.items():
+            if "wino_kernel" in k or "conv_kernel" in k:
+                print(d[-9:], k, {a: f"{b:.3g}" for a, b in v.items()})
+PY

@@ -16,6 +16,7 @@
 // Epilogue: the 16 x 32 x 32 accumulator slab goes through LDS once, each thread applies A^T M A for its
 // (tile, channel) pairs, adds bias / residual, applies LeakyReLU and writes 2 x 2 pixels (32 channels per 128-byte
 // line) straight into the consumer's concat slice.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sr_common.h"
@@ -49,7 +50,22 @@ struct SrWinoParams {
   float slope;
   int vec4;
   int debug;  // ablation bits (env SR_WINO_DEBUG), 0 in production
+#ifdef SR_WINO_TRACE
+  unsigned long long* trace;  // [blocks][SR_TR_REGIONS][SR_TR_EVENTS] shader-clock stamps (debug builds only)
+#endif
 };
+
+#ifdef SR_WINO_TRACE
+#define SR_TR_REGIONS 12
+#define SR_TR_EVENTS 16
+#define SR_TR(ev)                                                                                          \
+  do {                                                                                                     \
+    if (tid == 0 && tr_region < SR_TR_REGIONS)                                                              \
+      p.trace[((size_t)blockIdx.x * SR_TR_REGIONS + tr_region) * SR_TR_EVENTS + (ev)] = clock64();          \
+  } while (0)
+#else
+#define SR_TR(ev) do {} while (0)
+#endif
 
 // U = G g G^T per (co, ci), stored in MFMA B-fragment order: element (xi, g8, kk, co, e) = U_xi[co][8*g8 + 4*kk + e]
 __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wu, int Co, int Ci, int G,
@@ -85,7 +101,7 @@ __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restri
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-template <int NT, bool VEC4>
+template <int NT, bool VEC4, bool VOUT>
 __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* raw = lds;                   // [10*18][20]
@@ -104,6 +120,14 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
   const int ttr = tt >> 3, ttc = tt & 7;
   const int t_base = ((2 * ttr + th) * WN_PW + 2 * ttc) * WN_ROW + 4 * tq;
 
+#ifdef SR_WINO_TRACE
+  int tr_region = -1;
+  if (tid == 0) {  // event 15 of region 0: HW_ID (CU / SE) and XCC_ID, to group co-resident workgroups
+    p.trace[((size_t)blockIdx.x * SR_TR_REGIONS) * SR_TR_EVENTS + 15] =
+        ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |
+        (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+  }
+#endif
   for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
     int wk = work;
     const int cb = wk % p.co_blocks; wk /= p.co_blocks;
@@ -113,6 +137,10 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     const int oy0 = ry * (2 * WN_TR), ox0 = rx * (2 * WN_TC), co0 = cb * (32 * NT);
     const float* in_b = p.in + (int64_t)b * p.in_sb;
     const float4* wu4 = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + co0 + i);
+#ifdef SR_WINO_TRACE
+    ++tr_region;
+#endif
+    SR_TR(0);
 
     int offs[WN_STAGE_PER_THREAD];
 #pragma unroll
@@ -173,6 +201,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #pragma unroll
     for (int s = 0; s < PD; ++s) load_b(0, s, b_f[s]);
     __syncthreads();
+    SR_TR(1);
 
     for (int ch = 0; ch < chunks; ++ch) {
       const bool more = ch + 1 < chunks;
@@ -203,6 +232,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         }
       }
       __syncthreads();
+      if (ch < 5) SR_TR(2 + 2 * ch);
       if (more) stage_store(stg);
 
       // ---- M: this wave's 4 frequencies x 2 channel groups ----
@@ -233,8 +263,10 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
           acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].w, b_f[cbuf][n].w, acc[s >> 1][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (ch < 5) SR_TR(3 + 2 * ch);   // this wave's MFMAs issued (before the barrier)
       __syncthreads();
     }
+    SR_TR(12);
 
     // ---- epilogue: Y = A^T M A, + bias + residual, LeakyReLU, store ----
     const float* __restrict__ resp = p.res ? p.res + (int64_t)b * p.res_sb : nullptr;
@@ -244,292 +276,127 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     // through LDS: O[ur][b][tile][co] (64 KB for both N-tiles -> one pass, two barriers).
     if (!(p.debug & 16)) {
       constexpr int CO = 32 * NT;           // channels per workgroup
-      constexpr int UNITS = 32 * CO / 256;  // (tile, channel) units per thread
-      // (1) residual values first: their latency hides under the LDS exchange (and never sits between stores)
-      float rv[UNITS][4];
-      bool ok[UNITS][4];
-      unsigned opix[UNITS][4];
-      const int co = tid & (CO - 1);
-      const int cog = co0 + co;
-      const bool okc = cog < p.Cout;
+      if (VOUT) {
+        // Vector epilogue (Cout % 4 == 0, 16-byte aligned output / residual rows): a thread owns (tile, 4 consecutive
+        // channels) units -- float4 residual loads, ds_read_b128 of the exchanged slab, float4 stores.
+        constexpr int CG = CO / 4;            // channel groups per workgroup
+        constexpr int UNITS = 32 * CG / 256;  // = NT
+        const int cg = tid % CG;
+        const int cog = co0 + 4 * cg;
+        const bool okc = cog < p.Cout;
+        float4 rv[UNITS][4];
+        bool ok[UNITS][4];
+        unsigned opix[UNITS][4];
 #pragma unroll
-      for (int it = 0; it < UNITS; ++it) {
-        const int tile = tid / CO + (256 / CO) * it;
-        const int tr = tile >> 3, tc = tile & 7;
+        for (int it = 0; it < UNITS; ++it) {
+          const int tile = tid / CG + (256 / CG) * it;
+          const int tr = tile >> 3, tc = tile & 7;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int oy = oy0 + 2 * tr + (q >> 1), ox = ox0 + 2 * tc + (q & 1);
-          ok[it][q] = okc & (oy < p.H) & (ox < p.W);
-          opix[it][q] = (unsigned)(oy * p.W + ox);
-          const bool ld = ok[it][q] & (resp != nullptr);
-          const float v = (resp ? resp : p.in)[ld ? opix[it][q] * (unsigned)p.res_sp + cog : 0u];
-          rv[it][q] = ld ? v : 0.0f;
-        }
-      }
-      // (2) column transform in registers, then LDS
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int tile = (r & 3) + 8 * (r >> 2) + 4 * kk;
-          const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
-          O[((wave * 2 + 0) * 32 + tile) * CO + 32 * n + i] = (m0 + m1) + m2;
-          O[((wave * 2 + 1) * 32 + tile) * CO + 32 * n + i] = (m1 - m2) - m3;
-        }
-      __syncthreads();
-      // (3) row transform, + bias + residual, LeakyReLU, store
-      const float bv = (p.bias && okc) ? p.bias[cog] : 0.0f;
-#pragma unroll
-      for (int it = 0; it < UNITS; ++it) {
-        const int tile = tid / CO + (256 / CO) * it;
-        float t[4][2];
-#pragma unroll
-        for (int ur = 0; ur < 4; ++ur)
-#pragma unroll
-          for (int bb = 0; bb < 2; ++bb) t[ur][bb] = O[((ur * 2 + bb) * 32 + tile) * CO + co];
-        const float y[4] = {(t[0][0] + t[1][0]) + t[2][0], (t[0][1] + t[1][1]) + t[2][1],
-                            (t[1][0] - t[2][0]) - t[3][0], (t[1][1] - t[2][1]) - t[3][1]};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = y[q] + bv + rv[it][q];
-          if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
-          if (ok[it][q] && (!(p.debug & 1) || v == 1.2345e33f)) outp[opix[it][q] * (unsigned)p.out_sp + cog] = v;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// ------------------------------------------------------------------ specialised-wave variant ----
-// Workgroup of 8 waves = 2 per SIMD with different jobs: waves 0-3 ("compute") only issue MFMAs (frequency row
-// ur = wave) and run the epilogue; waves 4-7 ("transform") fetch the next slab's 4x4 patches straight from global
-// memory (L1/L2 hits: patches overlap) and write B^T d B into the OTHER V buffer while the compute waves work --
-// one barrier per slab, the matrix pipe only stops for the epilogue exchange.  LDS: 2 x V (41 KB) + O (64 KB).
-#define WN2_LDS_FLOATS (2 * WN_V_FLOATS + WN_O_FLOATS)
-
-template <int NT, bool VEC4>
-__global__ __launch_bounds__(512, 2) void sr_wino2_kernel(SrWinoParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* O = lds + 2 * WN_V_FLOATS;  // [4 ur][2][32 tiles][32*NT co]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const bool is_compute = wave < 4;  // wave-uniform
-  const int i = lane & 31, kk = lane >> 5;
-  const int S = p.G >> 1;            // slabs per region
-  const int64_t rec = (int64_t)2 * p.Co_pad;
-  constexpr int STEPS = 8, NB = 4, PD = 3;
-
-  auto decode = [&](int wk, int& b, int& oy0, int& ox0, int& co0) {
-    const int cb = wk % p.co_blocks; wk /= p.co_blocks;
-    const int rx = wk % p.regions_x; wk /= p.regions_x;
-    const int ry = wk % p.regions_y;
-    b = wk / p.regions_y;
-    oy0 = ry * (2 * WN_TR); ox0 = rx * (2 * WN_TC); co0 = cb * (32 * NT);
-  };
-
-  if (!is_compute) {
-    // ================================ transform waves ================================
-    const int xt = tid - 256;
-    const int th = xt & 1, tq = (xt >> 1) & 3, tt = xt >> 3;
-    const int ttr = tt >> 3, ttc = tt & 7;
-    float4 d[3][4];
-    int l_work = blockIdx.x, l_s = 0;  // next (region, slab) to LOAD
-    bool loaded = false;               // d holds a slab that is not yet transformed
-    auto issue_loads = [&]() {
-      loaded = l_work < p.total;
-      if (loaded) {
-        int b, oy0, ox0, co0;
-        decode(l_work, b, oy0, ox0, co0);
-        const float* in_b = p.in + (int64_t)b * p.in_sb;
-        const int c = l_s * 16 + 4 * tq;
-        const bool okc = c < p.Cin;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int iy = oy0 - 1 + 2 * ttr + th + r;
-          const bool oky = (iy >= 0) & (iy < p.H) & okc;
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const int ix = ox0 - 1 + 2 * ttc + cc;
-            const bool ok = oky & (ix >= 0) & (ix < p.W);
-            const float* src = in_b + (ok ? (iy * p.W + ix) * p.in_sp + c : 0);
-            if (VEC4) {
-              const float4 v = *reinterpret_cast<const float4*>(src);
-              d[r][cc] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-              float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (ok) {
-                v.x = src[0];
-                if (c + 1 < p.Cin) v.y = src[1];
-                if (c + 2 < p.Cin) v.z = src[2];
-                if (c + 3 < p.Cin) v.w = src[3];
-              }
-              d[r][cc] = v;
-            }
+          for (int q = 0; q < 4; ++q) {
+            const int oy = oy0 + 2 * tr + (q >> 1), ox = ox0 + 2 * tc + (q & 1);
+            ok[it][q] = okc & (oy < p.H) & (ox < p.W);
+            opix[it][q] = (unsigned)(oy * p.W + ox);
+            const bool ld = ok[it][q] & (resp != nullptr);
+            const float4 v = *reinterpret_cast<const float4*>((resp ? resp : p.in) +
+                                                               (ld ? opix[it][q] * (unsigned)p.res_sp + cog : 0u));
+            rv[it][q] = ld ? v : make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
-        if (++l_s == S) { l_s = 0; l_work += gridDim.x; }
-      }
-    };
-    auto transform_into = [&](float* V) {
-      // th = 0: patch rows 0,1,2 -> W0 = d0 - d2, W1 = d1 + d2;  th = 1: patch rows 1,2,3 -> W2 = d2 - d1, W3 = d1 - d3
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        float4 wv[4];
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (th == 0) wv[c] = rr == 0 ? f4sub(d[0][c], d[2][c]) : f4add(d[1][c], d[2][c]);
-          else wv[c] = rr == 0 ? f4sub(d[1][c], d[0][c]) : f4sub(d[0][c], d[2][c]);
+          for (int r = 0; r < 16; ++r) {
+            const int tile = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
+            O[((wave * 2 + 0) * 32 + tile) * CO + 32 * n + i] = (m0 + m1) + m2;
+            O[((wave * 2 + 1) * 32 + tile) * CO + 32 * n + i] = (m1 - m2) - m3;
+          }
+        __syncthreads();
+        SR_TR(13);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && okc) bv = *reinterpret_cast<const float4*>(p.bias + cog);
+#pragma unroll
+        for (int it = 0; it < UNITS; ++it) {
+          const int tile = tid / CG + (256 / CG) * it;
+          float4 t[4][2];
+#pragma unroll
+          for (int ur = 0; ur < 4; ++ur)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+              t[ur][bb] = *reinterpret_cast<const float4*>(&O[((ur * 2 + bb) * 32 + tile) * CO + 4 * cg]);
+          const float4 y[4] = {f4add(f4add(t[0][0], t[1][0]), t[2][0]), f4add(f4add(t[0][1], t[1][1]), t[2][1]),
+                               f4sub(f4sub(t[1][0], t[2][0]), t[3][0]), f4sub(f4sub(t[1][1], t[2][1]), t[3][1])};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = f4add(f4add(y[q], bv), rv[it][q]);
+            if (p.slope >= 0.0f) {
+              v.x = fmaxf(v.x, 0.0f) + p.slope * fminf(v.x, 0.0f);
+              v.y = fmaxf(v.y, 0.0f) + p.slope * fminf(v.y, 0.0f);
+              v.z = fmaxf(v.z, 0.0f) + p.slope * fminf(v.z, 0.0f);
+              v.w = fmaxf(v.w, 0.0f) + p.slope * fminf(v.w, 0.0f);
+            }
+            if (ok[it][q] && (!(p.debug & 1) || v.x == 1.2345e33f))
+              *reinterpret_cast<float4*>(outp + (opix[it][q] * (unsigned)p.out_sp + cog)) = v;
+          }
         }
-        const int ur = 2 * th + rr;
-        float* vrow = V + ((4 * ur) * 32 + tt) * WN_ROW + 4 * tq;
-        *reinterpret_cast<float4*>(vrow + 0 * 32 * WN_ROW) = f4sub(wv[0], wv[2]);
-        *reinterpret_cast<float4*>(vrow + 1 * 32 * WN_ROW) = f4add(wv[1], wv[2]);
-        *reinterpret_cast<float4*>(vrow + 2 * 32 * WN_ROW) = f4sub(wv[2], wv[1]);
-        *reinterpret_cast<float4*>(vrow + 3 * 32 * WN_ROW) = f4sub(wv[1], wv[3]);
-      }
-    };
-    int vb = 0;
-    issue_loads();
-    if (loaded) transform_into(lds);
-    issue_loads();
-    __syncthreads();  // P: V[0] = first slab
-    for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
-      for (int s = 0; s < S; ++s) {
-        if (loaded) transform_into(lds + (vb ^ 1) * WN_V_FLOATS);  // the slab the compute waves need NEXT
-        issue_loads();
-        __syncthreads();  // B_s
-        vb ^= 1;
-      }
-      __syncthreads();  // E1 (compute waves exchange accumulators through O)
-    }
-    return;
-  }
-
-  // ================================ compute waves ================================
-  float4 b_f[NB][NT], a_f[2];
-  auto load_b = [&](const float4* wbase, int ch, int s, float4 (&dst)[NT]) {
-    const int xi = 4 * wave + (s >> 1), g = s & 1;
-    const float4* wrec = wbase + (int64_t)(xi * p.G + 2 * ch + g) * rec;
+        __syncthreads();
+        SR_TR(14);
+      } else {
+        constexpr int UNITS = 32 * CO / 256;  // (tile, channel) units per thread
+        // (1) residual values first: their latency hides under the LDS exchange (and never sits between stores)
+        float rv[UNITS][4];
+        bool ok[UNITS][4];
+        unsigned opix[UNITS][4];
+        const int co = tid & (CO - 1);
+        const int cog = co0 + co;
+        const bool okc = cog < p.Cout;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
-  };
-  int vb = 0;
-  {
-    int b, oy0, ox0, co0;
-    decode(blockIdx.x, b, oy0, ox0, co0);
-    const float4* wu4 = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + co0 + i);
+        for (int it = 0; it < UNITS; ++it) {
+          const int tile = tid / CO + (256 / CO) * it;
+          const int tr = tile >> 3, tc = tile & 7;
 #pragma unroll
-    for (int s = 0; s < PD; ++s) load_b(wu4, 0, s, b_f[s]);
-  }
-  __syncthreads();  // P
-  for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
-    int b, oy0, ox0, co0;
-    decode(work, b, oy0, ox0, co0);
-    const float4* wu4 = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + co0 + i);
-    const bool have_next = work + (int)gridDim.x < p.total;
-    int bn, oyn, oxn, con = co0;
-    if (have_next) decode(work + gridDim.x, bn, oyn, oxn, con);
-    const float4* wu4n = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + con + i);
-
-    f32x16 acc[4][NT];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][n][r] = 0.0f;
-
-    for (int ch = 0; ch < S; ++ch) {
-      const float* V = lds + vb * WN_V_FLOATS;
-      const bool last = ch + 1 == S;
-      const bool more = !last || have_next;
-      const float4* wnext = last ? wu4n : wu4;
-      const int chn = last ? 0 : ch + 1;
-      a_f[0] = *reinterpret_cast<const float4*>(&V[((4 * wave) * 32 + i) * WN_ROW + 4 * kk]);
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
-        const int cbuf = s % NB, ca = s & 1;
-        if (s + PD < STEPS) load_b(wu4, ch, s + PD, b_f[(s + PD) % NB]);
-        else if (more) load_b(wnext, chn, s + PD - STEPS, b_f[(s + PD) % NB]);
-        if (s + 1 < STEPS) {
-          const int xi = 4 * wave + ((s + 1) >> 1), g = (s + 1) & 1;
-          a_f[ca ^ 1] = *reinterpret_cast<const float4*>(&V[(xi * 32 + i) * WN_ROW + 8 * g + 4 * kk]);
+          for (int q = 0; q < 4; ++q) {
+            const int oy = oy0 + 2 * tr + (q >> 1), ox = ox0 + 2 * tc + (q & 1);
+            ok[it][q] = okc & (oy < p.H) & (ox < p.W);
+            opix[it][q] = (unsigned)(oy * p.W + ox);
+            const bool ld = ok[it][q] & (resp != nullptr);
+            const float v = (resp ? resp : p.in)[ld ? opix[it][q] * (unsigned)p.res_sp + cog : 0u];
+            rv[it][q] = ld ? v : 0.0f;
+          }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // k-step outer, N-tile inner: consecutive MFMAs hit different accumulators
+        // (2) column transform in registers, then LDS
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].x, b_f[cbuf][n].x, acc[s >> 1][n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].y, b_f[cbuf][n].y, acc[s >> 1][n], 0, 0, 0);
+          for (int r = 0; r < 16; ++r) {
+            const int tile = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
+            O[((wave * 2 + 0) * 32 + tile) * CO + 32 * n + i] = (m0 + m1) + m2;
+            O[((wave * 2 + 1) * 32 + tile) * CO + 32 * n + i] = (m1 - m2) - m3;
+          }
+        __syncthreads();
+        // (3) row transform, + bias + residual, LeakyReLU, store
+        const float bv = (p.bias && okc) ? p.bias[cog] : 0.0f;
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].z, b_f[cbuf][n].z, acc[s >> 1][n], 0, 0, 0);
+        for (int it = 0; it < UNITS; ++it) {
+          const int tile = tid / CO + (256 / CO) * it;
+          float t[4][2];
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].w, b_f[cbuf][n].w, acc[s >> 1][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();  // B_s
-      vb ^= 1;
-    }
-
-    // ---- epilogue (compute waves only; 256 threads) ----
-    const float* __restrict__ resp = p.res ? p.res + (int64_t)b * p.res_sb : nullptr;
-    float* __restrict__ outp = p.out + (int64_t)b * p.out_sb;
-    constexpr int CO = 32 * NT;
-    constexpr int UNITS = 32 * CO / 256;
-    float rv[UNITS][4];
-    bool ok[UNITS][4];
-    unsigned opix[UNITS][4];
-    const int co = tid & (CO - 1);
-    const int cog = co0 + co;
-    const bool okc = cog < p.Cout;
+          for (int ur = 0; ur < 4; ++ur)
 #pragma unroll
-    for (int it = 0; it < UNITS; ++it) {
-      const int tile = tid / CO + (256 / CO) * it;
-      const int tr = tile >> 3, tc = tile & 7;
+            for (int bb = 0; bb < 2; ++bb) t[ur][bb] = O[((ur * 2 + bb) * 32 + tile) * CO + co];
+          const float y[4] = {(t[0][0] + t[1][0]) + t[2][0], (t[0][1] + t[1][1]) + t[2][1],
+                              (t[1][0] - t[2][0]) - t[3][0], (t[1][1] - t[2][1]) - t[3][1]};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int oy = oy0 + 2 * tr + (q >> 1), ox = ox0 + 2 * tc + (q & 1);
-        ok[it][q] = okc & (oy < p.H) & (ox < p.W);
-        opix[it][q] = (unsigned)(oy * p.W + ox);
-        const bool ld = ok[it][q] & (resp != nullptr);
-        const float v = (resp ? resp : p.in)[ld ? opix[it][q] * (unsigned)p.res_sp + cog : 0u];
-        rv[it][q] = ld ? v : 0.0f;
+          for (int q = 0; q < 4; ++q) {
+            float v = y[q] + bv + rv[it][q];
+            if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
+            if (ok[it][q] && (!(p.debug & 1) || v == 1.2345e33f)) outp[opix[it][q] * (unsigned)p.out_sp + cog] = v;
+          }
+        }
+        __syncthreads();
       }
     }
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int tile = (r & 3) + 8 * (r >> 2) + 4 * kk;
-        const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
-        O[((wave * 2 + 0) * 32 + tile) * CO + 32 * n + i] = (m0 + m1) + m2;
-        O[((wave * 2 + 1) * 32 + tile) * CO + 32 * n + i] = (m1 - m2) - m3;
-      }
-    __syncthreads();  // E1
-    const float bv = (p.bias && okc) ? p.bias[cog] : 0.0f;
-#pragma unroll
-    for (int it = 0; it < UNITS; ++it) {
-      const int tile = tid / CO + (256 / CO) * it;
-      float t[4][2];
-#pragma unroll
-      for (int ur = 0; ur < 4; ++ur)
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) t[ur][bb] = O[((ur * 2 + bb) * 32 + tile) * CO + co];
-      const float y[4] = {(t[0][0] + t[1][0]) + t[2][0], (t[0][1] + t[1][1]) + t[2][1],
-                          (t[1][0] - t[2][0]) - t[3][0], (t[1][1] - t[2][1]) - t[3][1]};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v = y[q] + bv + rv[it][q];
-        if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
-        if (ok[it][q]) outp[opix[it][q] * (unsigned)p.out_sp + cog] = v;
-      }
-    }
-    // (no barrier: the next write of O is S + 1 barriers away, and every compute wave passes them)
   }
 }
 
@@ -602,42 +469,49 @@ extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_WINO_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0) && (Cin % 4 == 0);
   hipStream_t stream = (hipStream_t)stream_;
-  // SR_WINO_VARIANT=2 selects the experimental specialised-wave kernel (measured r01: 21.2 ms vs 18.6 ms for the
-  // conv stack -- one workgroup per CU leaves nothing to cover the compute waves' weight-stream stalls)
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("SR_WINO_VARIANT"); variant = e ? atoi(e) : 1; }
-  if (variant == 2) {
-    int blocks2 = sr_wino_num_cus();
-    if (blocks2 > p.total) blocks2 = p.total;
-    const size_t lds2 = (size_t)WN2_LDS_FLOATS * sizeof(float);
-#define SR_WINO2_LAUNCH(NTV, V4)                                                                                  \
-    {                                                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)sr_wino2_kernel<NTV, V4>,                                   \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                  \
-      if (e != hipSuccess) return sr_hip_rc(e);                                                                   \
-      hipLaunchKernelGGL((sr_wino2_kernel<NTV, V4>), dim3(blocks2), dim3(512), lds2, stream, p);                  \
-    }
-    if (nt == 2 && p.vec4) SR_WINO2_LAUNCH(2, true)
-    else if (nt == 2) SR_WINO2_LAUNCH(2, false)
-    else if (p.vec4) SR_WINO2_LAUNCH(1, true)
-    else SR_WINO2_LAUNCH(1, false)
-#undef SR_WINO2_LAUNCH
-    return sr_hip_rc(hipGetLastError());
-  }
   int blocks = sr_wino_num_cus() * 2;
   if (blocks > p.total) blocks = p.total;
   const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
-#define SR_WINO_LAUNCH(NTV, V4)                                                                                   \
+#ifdef SR_WINO_TRACE
+  static unsigned long long* trace_buf = nullptr;
+  static int launches = 0;
+  const size_t trace_n = (size_t)blocks * SR_TR_REGIONS * SR_TR_EVENTS;
+  if (!trace_buf) (void)hipMalloc((void**)&trace_buf, (size_t)1024 * SR_TR_REGIONS * SR_TR_EVENTS * 8);
+  (void)hipMemsetAsync(trace_buf, 0, trace_n * 8, stream);
+  p.trace = trace_buf;
+#endif
+#define SR_WINO_LAUNCH(NTV, V4, VO)                                                                               \
   {                                                                                                               \
-    hipError_t e = hipFuncSetAttribute((const void*)sr_wino_kernel<NTV, V4>,                                      \
+    hipError_t e = hipFuncSetAttribute((const void*)sr_wino_kernel<NTV, V4, VO>,                                  \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
     if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
-    hipLaunchKernelGGL((sr_wino_kernel<NTV, V4>), dim3(blocks), dim3(256), lds, stream, p);                       \
+    hipLaunchKernelGGL((sr_wino_kernel<NTV, V4, VO>), dim3(blocks), dim3(256), lds, stream, p);                   \
   }
-  if (nt == 2 && p.vec4) SR_WINO_LAUNCH(2, true)
-  else if (nt == 2) SR_WINO_LAUNCH(2, false)
-  else if (p.vec4) SR_WINO_LAUNCH(1, true)
-  else SR_WINO_LAUNCH(1, false)
+  // vector epilogue: whole float4 channel groups, 16-byte aligned output / residual / bias rows
+  const bool vout = p.vec4 && (Cout % 4 == 0) && (((uintptr_t)out & 15) == 0) && (out_pix_stride % 4 == 0) &&
+                    (out_batch_stride % 4 == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                    (!residual || ((((uintptr_t)residual & 15) == 0) && (res_pix_stride % 4 == 0) &&
+                                   (res_batch_stride % 4 == 0)));
+  if (nt == 2 && vout) SR_WINO_LAUNCH(2, true, true)
+  else if (nt == 2 && p.vec4) SR_WINO_LAUNCH(2, true, false)
+  else if (nt == 2) SR_WINO_LAUNCH(2, false, false)
+  else if (vout) SR_WINO_LAUNCH(1, true, true)
+  else if (p.vec4) SR_WINO_LAUNCH(1, true, false)
+  else SR_WINO_LAUNCH(1, false, false)
 #undef SR_WINO_LAUNCH
+#ifdef SR_WINO_TRACE
+  {
+    const char* path = getenv("SR_WINO_TRACE_FILE");
+    const char* at = getenv("SR_WINO_TRACE_LAUNCH");
+    if (path && ++launches == (at ? atoi(at) : 10)) {
+      (void)hipStreamSynchronize(stream);
+      unsigned long long* host = (unsigned long long*)malloc(trace_n * 8);
+      (void)hipMemcpy(host, trace_buf, trace_n * 8, hipMemcpyDeviceToHost);
+      FILE* f = fopen(path, "wb");
+      if (f) { int hdr[4] = {blocks, SR_TR_REGIONS, SR_TR_EVENTS, p.G / 2}; fwrite(hdr, 4, 4, f); fwrite(host, 8, trace_n, f); fclose(f); }
+      free(host);
+    }
+  }
+#endif
   return sr_hip_rc(hipGetLastError());
 }
