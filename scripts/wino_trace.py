@@ -30,6 +30,8 @@ last = 3 + 2 * (min(chunks, 5) - 1)
 print("  last M -> loop end    ", dur(last, 12))
 print("  loop end -> O exchanged", dur(12, 13))
 print("  O exchanged -> stores issued + barrier", dur(13, 14))
+print("  epilogue detail: loopend->rv loads issued", dur(12, 10), " ->O writes issued", dur(10, 11), " ->barrier", dur(11, 13),
+      " ->transform+stores issued", dur(13, 15), " ->final barrier", dur(15, 14))
 print("  region total           ", dur(0, 14))
 per = (valid[:, 1:, 0] - valid[:, :-1, 0]).ravel()
 print("  region period          ", per[per > 0].mean())

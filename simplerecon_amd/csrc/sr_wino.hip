@@ -27,6 +27,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SR_WINO_WAVES 2  // waves per SIMD the register allocation must allow (2 = two workgroups per CU)
 #endif
 
+#ifndef SR_WINO_NB
+#define SR_WINO_NB 3
+#define SR_WINO_PD 2
+#endif
+
 #define WN_TR 4
 #define WN_TC 8
 #define WN_PH (2 * WN_TR + 2)  // 10 patch rows
@@ -35,7 +40,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WN_RAW_FLOATS (WN_PH * WN_PW * WN_ROW)
 #define WN_V_FLOATS (16 * 32 * WN_ROW)
 #define WN_O_FLOATS (8 * 32 * 64)
-#define WN_LDS_FLOATS (WN_RAW_FLOATS + WN_V_FLOATS > WN_O_FLOATS ? WN_RAW_FLOATS + WN_V_FLOATS : WN_O_FLOATS)
+// V and the epilogue slab O share the first 64 KB; the raw patch lives behind them so that the NEXT region's first
+// slab can be staged while the current region finishes (its last MFMA phase and its epilogue): 78 KB, 2 per CU.
+#define WN_VO_FLOATS (WN_V_FLOATS > WN_O_FLOATS ? WN_V_FLOATS : WN_O_FLOATS)
+#define WN_LDS_FLOATS (WN_VO_FLOATS + WN_RAW_FLOATS)
 #define WN_STAGE_ELEMS (WN_PH * WN_PW * 4)  // float4 elements per slab (720)
 #define WN_STAGE_PER_THREAD 3
 
@@ -104,16 +112,16 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 template <int NT, bool VEC4, bool VOUT>
 __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* raw = lds;                   // [10*18][20]
-  float* V = lds + WN_RAW_FLOATS;     // [16][32][20]
-  float* O = lds;                     // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases raw + V)
+  float* V = lds;                     // [16][32][20]
+  float* O = lds;                     // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases V)
+  float* raw = lds + WN_VO_FLOATS;    // [10*18][20]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, kk = lane >> 5;
   const int chunks = p.G >> 1;
   const int64_t rec = (int64_t)2 * p.Co_pad;
   constexpr int STEPS = 8;            // (frequency, 8-channel group) steps per slab and wave
-  constexpr int NB = 4, PD = 3;       // weight prefetch: 3 steps ahead through 4 rotating register sets
+  constexpr int NB = SR_WINO_NB, PD = SR_WINO_PD;  // weight prefetch: PD steps ahead through NB rotating register sets
 
   // transform-phase role of this thread: tile t, 4-channel group q, row pair h
   const int th = tid & 1, tq = (tid >> 1) & 3, tt = tid >> 3;
@@ -128,30 +136,31 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
   }
 #endif
-  for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
-    int wk = work;
+  // Region coordinates of a work item and the per-thread staging offsets of its 10x18 input patch.
+  struct Region { int b, oy0, ox0, co0; };
+  auto decode = [&](int wk) {
+    Region r;
     const int cb = wk % p.co_blocks; wk /= p.co_blocks;
     const int rx = wk % p.regions_x; wk /= p.regions_x;
     const int ry = wk % p.regions_y;
-    const int b = wk / p.regions_y;
-    const int oy0 = ry * (2 * WN_TR), ox0 = rx * (2 * WN_TC), co0 = cb * (32 * NT);
-    const float* in_b = p.in + (int64_t)b * p.in_sb;
-    const float4* wu4 = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + co0 + i);
-#ifdef SR_WINO_TRACE
-    ++tr_region;
-#endif
-    SR_TR(0);
-
-    int offs[WN_STAGE_PER_THREAD];
+    r.b = wk / p.regions_y;
+    r.oy0 = ry * (2 * WN_TR); r.ox0 = rx * (2 * WN_TC); r.co0 = cb * (32 * NT);
+    return r;
+  };
+  int offs[WN_STAGE_PER_THREAD];
+  const float* in_b = p.in;
+  auto aim = [&](const Region& r) {  // point the staging loads at region r
+    in_b = p.in + (int64_t)r.b * p.in_sb;
 #pragma unroll
     for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
       const int e = tid + it * 256;
       const int px = e >> 2, q = e & 3;
       const int py = px / WN_PW, pxx = px - py * WN_PW;
-      const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
+      const int iy = r.oy0 - 1 + py, ix = r.ox0 - 1 + pxx;
       const bool ok = (e < WN_STAGE_ELEMS) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
       offs[it] = ok ? (iy * p.W + ix) * p.in_sp + 4 * q : -1;
     }
+  };
     auto stage_load = [&](int c0, float4 (&stg)[WN_STAGE_PER_THREAD]) {
 #pragma unroll
       for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
@@ -180,12 +189,33 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         if (e < WN_STAGE_ELEMS) *reinterpret_cast<float4*>(&raw[(e >> 2) * WN_ROW + 4 * (e & 3)]) = stg[it];
       }
     };
+    const float4* wu4 = nullptr;
     auto load_b = [&](int ch, int s, float4 (&dst)[NT]) {
       const int xi = 4 * wave + (s >> 1), g = s & 1;
-      const float4* wrec = wu4 + (int64_t)(xi * p.G + 2 * ch + g) * rec;
+      const float4* wrec = wu4 + ((p.debug & 32) ? (int64_t)0 : (int64_t)(xi * p.G + 2 * ch + g) * rec);
 #pragma unroll
       for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
     };
+
+  // Software pipeline over regions: a region's first slab is staged while the previous region runs its last MFMA
+  // phase and its epilogue, issued in front of that epilogue's stores (VMEM returns in order, so waiting for the
+  // slab does not wait for the stores).
+  float4 stg[WN_STAGE_PER_THREAD];
+  if ((int)blockIdx.x < p.total) {
+    aim(decode(blockIdx.x));
+    stage_load(0, stg);
+    stage_store(stg);
+  }
+  __syncthreads();
+  for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
+    const Region reg = decode(work);
+    const int b = reg.b, oy0 = reg.oy0, ox0 = reg.ox0, co0 = reg.co0;
+    wu4 = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + co0 + i);
+    const bool has_next = work + (int)gridDim.x < p.total;
+#ifdef SR_WINO_TRACE
+    ++tr_region;
+#endif
+    SR_TR(0);
 
     f32x16 acc[4][NT];
 #pragma unroll
@@ -195,45 +225,46 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][n][r] = 0.0f;
 
-    float4 stg[WN_STAGE_PER_THREAD], b_f[NB][NT], a_f[2];
-    stage_load(0, stg);
-    stage_store(stg);
+    float4 b_f[NB][NT], a_f[2];
 #pragma unroll
     for (int s = 0; s < PD; ++s) load_b(0, s, b_f[s]);
-    __syncthreads();
     SR_TR(1);
 
     for (int ch = 0; ch < chunks; ++ch) {
       const bool more = ch + 1 < chunks;
       if (more) stage_load((ch + 1) * 16, stg);
+      else if (has_next) {
+        aim(decode(work + gridDim.x));
+        stage_load(0, stg);
+      }
 
       // ---- T: V = B^T d B for (tile tt, channels 4*tq.., rows {2*th, 2*th+1} of the 4x4 frequency grid) ----
       if (!(p.debug & 2)) {
-        float4 d[3][4];
+        // th = 0: patch rows 0,1,2 -> W0 = d0 - d2, W1 = d1 + d2;  th = 1: patch rows 1,2,3 -> W2 = d2 - d1, W3 = d1 - d3.
+        // Column by column (3 loads -> 2 row-transformed values) to keep the live set small: the accumulators, the
+        // weight prefetch and the staged slab already fill most of the register file.
+        float4 wv[2][4];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) d[r][c] = *reinterpret_cast<const float4*>(&raw[t_base + (r * WN_PW + c) * WN_ROW]);
-        // th = 0: patch rows 0,1,2 -> W0 = d0 - d2, W1 = d1 + d2;  th = 1: patch rows 1,2,3 -> W2 = d2 - d1, W3 = d1 - d3
+        for (int c = 0; c < 4; ++c) {
+          const float4 d0 = *reinterpret_cast<const float4*>(&raw[t_base + (0 * WN_PW + c) * WN_ROW]);
+          const float4 d1 = *reinterpret_cast<const float4*>(&raw[t_base + (1 * WN_PW + c) * WN_ROW]);
+          const float4 d2 = *reinterpret_cast<const float4*>(&raw[t_base + (2 * WN_PW + c) * WN_ROW]);
+          wv[0][c] = th == 0 ? f4sub(d0, d2) : f4sub(d1, d0);
+          wv[1][c] = th == 0 ? f4add(d1, d2) : f4sub(d0, d2);
+        }
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-          float4 wv[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (th == 0) wv[c] = rr == 0 ? f4sub(d[0][c], d[2][c]) : f4add(d[1][c], d[2][c]);
-            else wv[c] = rr == 0 ? f4sub(d[1][c], d[0][c]) : f4sub(d[0][c], d[2][c]);
-          }
           const int ur = 2 * th + rr;
           float* vrow = V + ((4 * ur) * 32 + tt) * WN_ROW + 4 * tq;
-          *reinterpret_cast<float4*>(vrow + 0 * 32 * WN_ROW) = f4sub(wv[0], wv[2]);
-          *reinterpret_cast<float4*>(vrow + 1 * 32 * WN_ROW) = f4add(wv[1], wv[2]);
-          *reinterpret_cast<float4*>(vrow + 2 * 32 * WN_ROW) = f4sub(wv[2], wv[1]);
-          *reinterpret_cast<float4*>(vrow + 3 * 32 * WN_ROW) = f4sub(wv[1], wv[3]);
+          *reinterpret_cast<float4*>(vrow + 0 * 32 * WN_ROW) = f4sub(wv[rr][0], wv[rr][2]);
+          *reinterpret_cast<float4*>(vrow + 1 * 32 * WN_ROW) = f4add(wv[rr][1], wv[rr][2]);
+          *reinterpret_cast<float4*>(vrow + 2 * 32 * WN_ROW) = f4sub(wv[rr][2], wv[rr][1]);
+          *reinterpret_cast<float4*>(vrow + 3 * 32 * WN_ROW) = f4sub(wv[rr][1], wv[rr][3]);
         }
       }
       __syncthreads();
       if (ch < 5) SR_TR(2 + 2 * ch);
-      if (more) stage_store(stg);
+      if (more || has_next) stage_store(stg);
 
       // ---- M: this wave's 4 frequencies x 2 channel groups ----
       a_f[0] = *reinterpret_cast<const float4*>(&V[((4 * wave) * 32 + i) * WN_ROW + 4 * kk]);
@@ -302,6 +333,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
             rv[it][q] = ld ? v : make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
+        SR_TR(10);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -311,6 +343,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
             O[((wave * 2 + 0) * 32 + tile) * CO + 32 * n + i] = (m0 + m1) + m2;
             O[((wave * 2 + 1) * 32 + tile) * CO + 32 * n + i] = (m1 - m2) - m3;
           }
+        SR_TR(11);
         __syncthreads();
         SR_TR(13);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -339,6 +372,9 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
               *reinterpret_cast<float4*>(outp + (opix[it][q] * (unsigned)p.out_sp + cog)) = v;
           }
         }
+#ifdef SR_WINO_TRACE
+        if (tr_region > 0) SR_TR(15);
+#endif
         __syncthreads();
         SR_TR(14);
       } else {
