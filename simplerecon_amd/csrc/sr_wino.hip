@@ -28,8 +28,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 
 #ifndef SR_WINO_NB
-#define SR_WINO_NB 3
-#define SR_WINO_PD 2
+#define SR_WINO_NB 4   // rotating weight-fragment register sets; must divide the 8 steps of a slab
+#define SR_WINO_PD 3   // prefetch distance in steps (< NB)
 #endif
 
 #define WN_TR 4
@@ -42,7 +42,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WN_O_FLOATS (8 * 32 * 64)
 // V and the epilogue slab O share the first 64 KB; the raw patch lives behind them so that the NEXT region's first
 // slab can be staged while the current region finishes (its last MFMA phase and its epilogue): 78 KB, 2 per CU.
-#define WN_VO_FLOATS (WN_V_FLOATS > WN_O_FLOATS ? WN_V_FLOATS : WN_O_FLOATS)
+#define WN_VO_FLOATS (WN_V_FLOATS + WN_RAW_FLOATS > WN_O_FLOATS ? WN_V_FLOATS + WN_RAW_FLOATS : WN_O_FLOATS)
 #define WN_LDS_FLOATS (WN_VO_FLOATS + WN_RAW_FLOATS)
 #define WN_STAGE_ELEMS (WN_PH * WN_PW * 4)  // float4 elements per slab (720)
 #define WN_STAGE_PER_THREAD 3
@@ -113,20 +113,24 @@ template <int NT, bool VEC4, bool VOUT>
 __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* V = lds;                     // [16][32][20]
-  float* O = lds;                     // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases V)
-  float* raw = lds + WN_VO_FLOATS;    // [10*18][20]
+  float* O = lds;                     // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases V and raw A)
+  float* rawA = lds + WN_V_FLOATS;    // [10*18][20]  odd slabs  (inside the V/O area: dead by the epilogue)
+  float* rawB = lds + WN_VO_FLOATS;   // [10*18][20]  even slabs (behind it: survives the epilogue)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, kk = lane >> 5;
   const int chunks = p.G >> 1;
   const int64_t rec = (int64_t)2 * p.Co_pad;
   constexpr int STEPS = 8;            // (frequency, 8-channel group) steps per slab and wave
+  static_assert(8 % SR_WINO_NB == 0 && SR_WINO_PD < SR_WINO_NB, "the register rotation must line up across slabs");
   constexpr int NB = SR_WINO_NB, PD = SR_WINO_PD;  // weight prefetch: PD steps ahead through NB rotating register sets
 
-  // transform-phase role of this thread: tile t, 4-channel group q, row pair h
-  const int th = tid & 1, tq = (tid >> 1) & 3, tt = tid >> 3;
-  const int ttr = tt >> 3, ttc = tt & 7;
-  const int t_base = ((2 * ttr + th) * WN_PW + 2 * ttc) * WN_ROW + 4 * tq;
+  // Transform-phase role: wave w produces the frequency ROW ur = w of V (the rows it alone multiplies), so V is
+  // wave-private and no barrier separates a wave's transform from its MFMAs.  Lane -> 4-channel group tq and tiles
+  // tt0, tt0 + 16.  Row ur of B^T d needs two patch rows: (0,2) d0-d2, (1,2) d1+d2, (2,1) d2-d1, (1,3) d1-d3.
+  const int tq = lane & 3, tt0 = lane >> 2;
+  const int t_ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1), t_rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+  const float t_sign = wave == 1 ? 1.0f : -1.0f;
 
 #ifdef SR_WINO_TRACE
   int tr_region = -1;
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         }
       }
     };
-    auto stage_store = [&](const float4 (&stg)[WN_STAGE_PER_THREAD]) {
+    auto stage_store = [&](const float4 (&stg)[WN_STAGE_PER_THREAD], float* raw) {
 #pragma unroll
       for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
         const int e = tid + it * 256;
@@ -197,25 +201,29 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
       for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
     };
 
-  // Software pipeline over regions: a region's first slab is staged while the previous region runs its last MFMA
-  // phase and its epilogue, issued in front of that epilogue's stores (VMEM returns in order, so waiting for the
-  // slab does not wait for the stores).
+  // Software pipeline: slab c of a region sits in raw buffer (c odd ? A : B); slab c+1 is fetched into registers at
+  // the top of chunk c and stored at its end (one barrier per chunk).  With an even slab count the NEXT region's
+  // slab 0 follows the same way during the last chunk -- it lands in B, which the epilogue leaves alone, and is
+  // issued in front of the epilogue's stores (VMEM returns in order: waiting for it does not wait for them).
   float4 stg[WN_STAGE_PER_THREAD];
-  if ((int)blockIdx.x < p.total) {
-    aim(decode(blockIdx.x));
-    stage_load(0, stg);
-    stage_store(stg);
-  }
-  __syncthreads();
+  const bool chain = !(chunks & 1);
+  bool staged = false;
   for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
     const Region reg = decode(work);
     const int b = reg.b, oy0 = reg.oy0, ox0 = reg.ox0, co0 = reg.co0;
     wu4 = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + co0 + i);
-    const bool has_next = work + (int)gridDim.x < p.total;
+    const bool has_next = chain && (work + (int)gridDim.x < p.total);
 #ifdef SR_WINO_TRACE
     ++tr_region;
 #endif
     SR_TR(0);
+    if (!staged) {
+      aim(reg);
+      stage_load(0, stg);
+      stage_store(stg, rawB);
+      __syncthreads();
+    }
+    staged = has_next;
 
     f32x16 acc[4][NT];
 #pragma unroll
@@ -238,33 +246,28 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         stage_load(0, stg);
       }
 
-      // ---- T: V = B^T d B for (tile tt, channels 4*tq.., rows {2*th, 2*th+1} of the 4x4 frequency grid) ----
+      // ---- T: this wave's row of V = B^T d B, all 32 tiles x 16 channels ----
       if (!(p.debug & 2)) {
-        // th = 0: patch rows 0,1,2 -> W0 = d0 - d2, W1 = d1 + d2;  th = 1: patch rows 1,2,3 -> W2 = d2 - d1, W3 = d1 - d3.
-        // Column by column (3 loads -> 2 row-transformed values) to keep the live set small: the accumulators, the
-        // weight prefetch and the staged slab already fill most of the register file.
-        float4 wv[2][4];
+        const float* raw = (ch & 1) ? rawA : rawB;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float4 d0 = *reinterpret_cast<const float4*>(&raw[t_base + (0 * WN_PW + c) * WN_ROW]);
-          const float4 d1 = *reinterpret_cast<const float4*>(&raw[t_base + (1 * WN_PW + c) * WN_ROW]);
-          const float4 d2 = *reinterpret_cast<const float4*>(&raw[t_base + (2 * WN_PW + c) * WN_ROW]);
-          wv[0][c] = th == 0 ? f4sub(d0, d2) : f4sub(d1, d0);
-          wv[1][c] = th == 0 ? f4add(d1, d2) : f4sub(d0, d2);
-        }
+        for (int j = 0; j < 2; ++j) {
+          const int tt = tt0 + 16 * j;
+          const int base = ((2 * (tt >> 3)) * WN_PW + 2 * (tt & 7)) * WN_ROW + 4 * tq;
+          float4 wv[4];
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int ur = 2 * th + rr;
-          float* vrow = V + ((4 * ur) * 32 + tt) * WN_ROW + 4 * tq;
-          *reinterpret_cast<float4*>(vrow + 0 * 32 * WN_ROW) = f4sub(wv[rr][0], wv[rr][2]);
-          *reinterpret_cast<float4*>(vrow + 1 * 32 * WN_ROW) = f4add(wv[rr][1], wv[rr][2]);
-          *reinterpret_cast<float4*>(vrow + 2 * 32 * WN_ROW) = f4sub(wv[rr][2], wv[rr][1]);
-          *reinterpret_cast<float4*>(vrow + 3 * 32 * WN_ROW) = f4sub(wv[rr][1], wv[rr][3]);
+          for (int c = 0; c < 4; ++c) {
+            const float4 da = *reinterpret_cast<const float4*>(&raw[base + (t_ra * WN_PW + c) * WN_ROW]);
+            const float4 db = *reinterpret_cast<const float4*>(&raw[base + (t_rb * WN_PW + c) * WN_ROW]);
+            wv[c] = make_float4(da.x + t_sign * db.x, da.y + t_sign * db.y, da.z + t_sign * db.z, da.w + t_sign * db.w);
+          }
+          float* vrow = V + ((4 * wave) * 32 + tt) * WN_ROW + 4 * tq;
+          *reinterpret_cast<float4*>(vrow + 0 * 32 * WN_ROW) = f4sub(wv[0], wv[2]);
+          *reinterpret_cast<float4*>(vrow + 1 * 32 * WN_ROW) = f4add(wv[1], wv[2]);
+          *reinterpret_cast<float4*>(vrow + 2 * 32 * WN_ROW) = f4sub(wv[2], wv[1]);
+          *reinterpret_cast<float4*>(vrow + 3 * 32 * WN_ROW) = f4sub(wv[1], wv[3]);
         }
       }
-      __syncthreads();
       if (ch < 5) SR_TR(2 + 2 * ch);
-      if (more || has_next) stage_store(stg);
 
       // ---- M: this wave's 4 frequencies x 2 channel groups ----
       a_f[0] = *reinterpret_cast<const float4*>(&V[((4 * wave) * 32 + i) * WN_ROW + 4 * kk]);
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         __builtin_amdgcn_sched_barrier(0);
       }
       if (ch < 5) SR_TR(3 + 2 * ch);   // this wave's MFMAs issued (before the barrier)
+      if (more || has_next) stage_store(stg, (ch & 1) ? rawB : rawA);
       __syncthreads();
     }
     SR_TR(12);
