@@ -194,6 +194,11 @@ int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pi
                              int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
                              int Cout, float leaky_slope, void* stream);
 
+/* Name of the kernel instantiation sr_conv3x3_wino_nhwc_fwd launches for these arguments (the output-channel block
+ * is chosen per launch); aligned_in / aligned_out = input / output+residual+bias rows are 16-byte aligned with
+ * channel counts that are multiples of 4.  For profilers. */
+const char* sr_wino_kernel_name(int B, int H, int W, int Cin, int Cout, int aligned_in, int aligned_out);
+
 /* Name of the kernel instantiation sr_conv2d_nhwc_fwd launches for these arguments (tile shape is
  * chosen per launch); `aligned16` = input pointer / strides are 16-byte aligned.  For profilers. */
 const char* sr_conv_kernel_name(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int aligned16);

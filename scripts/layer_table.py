@@ -6,7 +6,7 @@ import bench_workloads as bw
 from simplerecon_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-wl = bw.HeroCfg3(torch.device("cuda", 0), 0, B=B)
+wl = bw.HeroCfg3(torch.device("cuda", 0), 0, B=B, with_encoder=False)
 inp = wl.inp
 with torch.inference_mode():
     vol = wl.model.cost_volume(cur_feats=inp["cur_feats"], src_feats=inp["src_feats"], src_extrinsics=inp["src_extrinsics"],

@@ -484,6 +484,39 @@ extern "C" int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int 
   return (util >= 0.4 && Cin >= 16) ? 1 : 0;
 }
 
+// Output channels per workgroup: 64 (NT = 2) shares one transformed input slab between two N-tiles; 32 (NT = 1) makes
+// twice as many, roughly 0.58x as long work items, which fills the chip better when there are few regions
+// (batch 1, low-resolution pyramid levels).  Launch time ~ rounds over the 2-per-CU slots x item length.
+static int sr_wino_pick_nt(int B, int H, int W, int Cout) {
+  const int co_pad = ((Cout + 31) / 32) * 32;
+  if (co_pad % 64 != 0) return 1;
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("SR_WINO_NT"); forced = e ? atoi(e) : 0; }
+  if (forced == 1 || forced == 2) return forced;
+  const long regions = (long)((H + 2 * WN_TR - 1) / (2 * WN_TR)) * ((W + 2 * WN_TC - 1) / (2 * WN_TC)) * B;
+  const long cus = sr_wino_num_cus(), slots = 2 * cus;
+  const long items2 = regions * (co_pad / 64), items1 = regions * (co_pad / 32);
+  // cost = max(latency bound: rounds x item length when a workgroup has its CU to itself,
+  //            throughput bound: items per CU x item length under sharing), in units of an NT = 2 item (r01 fit)
+  auto cost = [&](long items, double t_lat, double t_thr) {
+    const double lat = (double)((items + slots - 1) / slots) * t_lat, thr = (double)items / (double)cus * t_thr;
+    return lat > thr ? lat : thr;
+  };
+  const double cost2 = cost(items2, 1.0, 0.8), cost1 = cost(items1, 0.62, 0.5);
+  return cost1 < 0.92 * cost2 ? 1 : 2;
+}
+
+// Symbol of the kernel instantiation sr_conv3x3_wino_nhwc_fwd launches (for profilers / bench): `aligned_in` = input
+// rows 16-byte aligned and Cin % 4 == 0, `aligned_out` = output / residual / bias rows 16-byte aligned and Cout % 4 == 0.
+extern "C" const char* sr_wino_kernel_name(int B, int H, int W, int Cin, int Cout, int aligned_in, int aligned_out) {
+  static thread_local char buf[64];
+  (void)Cin;
+  const int vin = aligned_in != 0, vout = vin && aligned_out;
+  snprintf(buf, sizeof(buf), "sr_wino_kernel<%d, %s, %s>", sr_wino_pick_nt(B, H, W, Cout), vin ? "true" : "false",
+           vout ? "true" : "false");
+  return buf;
+}
+
 extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
                                         const float* packed_u, const float* bias, const float* residual,
                                         int64_t res_batch_stride, int res_pix_stride, float* out,
@@ -502,7 +535,7 @@ extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride
   p.G = ((Cin + 15) / 16) * 2;
   p.regions_x = (W + 2 * WN_TC - 1) / (2 * WN_TC);
   p.regions_y = (H + 2 * WN_TR - 1) / (2 * WN_TR);
-  const int nt = (p.Co_pad % 64 == 0) ? 2 : 1;
+  const int nt = sr_wino_pick_nt(B, H, W, Cout);
   p.co_blocks = p.Co_pad / (32 * nt);
   p.total = p.regions_x * p.regions_y * p.co_blocks * B;
   p.slope = leaky_slope;

@@ -223,12 +223,11 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None):
             ev1.record()
             v4 = int(x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0)
             if use_wino:
-                nt = 2 if ((co + 31) // 32 * 32) % 64 == 0 else 1
                 vin = bool(v4 and ci % 4 == 0)
                 al = lambda t, sb_, sp_: t is None or (t.data_ptr() % 16 == 0 and sp_ % 4 == 0 and sb_ % 4 == 0)
                 vout = vin and co % 4 == 0 and al(out, osb, osp) and al(residual, rsb, rsp) and \
                     (bias is None or bias.data_ptr() % 16 == 0)
-                name = f"sr_wino_kernel<{nt}, {'true' if vin else 'false'}, {'true' if vout else 'false'}>"
+                name = lib.sr_wino_kernel_name(b, h, w, ci, co, int(vin), int(vout)).decode()
             else:
                 name = lib.sr_conv_kernel_name(b, h, w, ci, co, k, s, v4).decode()
             executed = None
