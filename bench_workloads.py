@@ -151,13 +151,15 @@ class HeroCfg3:
     B, K, Cc, D, h, w = 8, 7, 16, 64, 120, 160
     feature_volume_type = "mlp_feature_volume"
 
-    def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None):
+    def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None, graph=False):
         from simplerecon_amd import depth_model as dm
         if B is not None:
             self.B = B
         if name is not None:
             self.name = name
         self.with_encoder = with_encoder
+        self.use_graph = graph
+        self._graphed = None
         self.streams = streams
         self.dev = dev
         self.frames_per_step = self.B
@@ -184,15 +186,25 @@ class HeroCfg3:
         self.results = []
         self.last = None
 
+    def _eager(self, feats_or_images, pyramid, ext, poses, Ks, invK):
+        if self.with_encoder:
+            cur_f, src_f = self.model.compute_matching_feats(feats_or_images[0], feats_or_images[1], False)
+        else:
+            cur_f, src_f = feats_or_images
+        return self.model.hot_path(pyramid, cur_f, src_f, ext, poses, Ks, invK, return_mask=True)
+
     def step(self, i=0):
         inp = self.inp
-        if self.with_encoder:
-            cur_f, src_f = self.model.compute_matching_feats(self.cur_image, self.src_image, False)
+        first = [self.cur_image, self.src_image] if self.with_encoder else [inp["cur_feats"], inp["src_feats"]]
+        args = (first, self.pyramid, inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"], inp["cur_invK"])
+        if self.use_graph:
+            if self._graphed is None:  # capture once (warm-up steps): the ~230 launches of a step become one HIP graph
+                from simplerecon_amd.graph import GraphedCallable
+                self._graphed = GraphedCallable(self._eager, *args)
+                self._static = self._graphed.static_inputs   # inputs live in the graph's buffers: no copies per step
+            self.last = self._graphed(*self._static)
         else:
-            cur_f, src_f = inp["cur_feats"], inp["src_feats"]
-        out = self.model.hot_path(self.pyramid, cur_f, src_f, inp["src_extrinsics"],
-                                  inp["src_poses"], inp["src_Ks"], inp["cur_invK"], return_mask=True)
-        self.last = out
+            self.last = self._eager(*args)
 
     def finish(self, world):
         if world > 1:
@@ -212,6 +224,7 @@ class HeroCfg3:
                             f"matching features x {self.Cc} ch, image-prior pyramid 24/48/64/160/256 ch), fp32, "
                             f"random-init weights; {skipped}",
                 "frames_per_step_per_gpu": self.B, "hip_streams_per_gpu": self.streams,
+                "submission": "one HIP graph replay per step" if self.use_graph else "eager (one launch per kernel)",
                 "parallelism": f"replica x{world} (keyframes sharded)"}
 
     def _profile_convs(self, n):
@@ -412,6 +425,10 @@ WORKLOADS = {
     "hero_b1": lambda dev, rank: HeroCfg3(dev, rank, B=1, name="hero_b1"),
     "hero_cfg3_core": lambda dev, rank: HeroCfg3(dev, rank, with_encoder=False, name="hero_cfg3_core"),
     "hero_b1_core": lambda dev, rank: HeroCfg3(dev, rank, B=1, with_encoder=False, name="hero_b1_core"),
+    "hero_cfg3_graph": lambda dev, rank: HeroCfg3(dev, rank, graph=True, name="hero_cfg3_graph"),
+    "hero_b1_graph": lambda dev, rank: HeroCfg3(dev, rank, B=1, graph=True, name="hero_b1_graph"),
+    "hero_b1_core_graph": lambda dev, rank: HeroCfg3(dev, rank, B=1, with_encoder=False, graph=True,
+                                                     name="hero_b1_core_graph"),
     "hero_cfg3_s2": lambda dev, rank: HeroCfg3(dev, rank, streams=2),
     "hero_cfg3_s4": lambda dev, rank: HeroCfg3(dev, rank, streams=4),
     "dot_full": lambda dev, rank: DotFull(dev, rank),

@@ -118,6 +118,7 @@ class DepthModel(nn.Module):
         # HIP streams so that one sub-batch's kernel tails / launch gaps are filled by the other's work.
         self.num_streams = 1
         self._streams = {}
+        self._range_cache = {}
 
     # ---- reference depth_model.py:191-245 ----------------------------------------------------
     def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward):
@@ -170,11 +171,37 @@ class DepthModel(nn.Module):
                 out[k] = torch.cat(vals, 0)
         return out
 
+    def _depth_range(self, like):
+        """min / max matching depth as [1,1,1,1] device tensors (reference depth_model.py:358-359), created once per
+        device and dtype so that the hot path issues no host-to-device copy (and can be captured in a HIP graph)."""
+        key = (like.device, like.dtype)
+        hit = self._range_cache.get(key)
+        o = self.run_opts
+        if hit is None or hit[0] != (o.min_matching_depth, o.max_matching_depth):
+            mn = torch.tensor(o.min_matching_depth).type_as(like).view(1, 1, 1, 1)
+            mx = torch.tensor(o.max_matching_depth).type_as(like).view(1, 1, 1, 1)
+            hit = ((o.min_matching_depth, o.max_matching_depth), mn, mx)
+            self._range_cache[key] = hit
+        return hit[1], hit[2]
+
+    def graphed(self, cur_image, src_image, cur_feats, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK,
+                return_mask=False):
+        """HIP-graph version of `matching encoder -> hot_path` for fixed shapes: returns a
+        `graph.GraphedCallable` taking (cur_image, src_image, cur_feats (pyramid list), src_cam_T_cur_cam,
+        cur_cam_T_src_cam, src_K, cur_invK).  One submission per keyframe batch instead of ~230 launches."""
+        from .graph import GraphedCallable
+
+        def step(cur_image, src_image, cur_feats, src_T_cur, cur_T_src, src_K, cur_invK):
+            mc, ms = self.compute_matching_feats(cur_image, src_image, False)
+            return self.hot_path(list(cur_feats), mc, ms, src_T_cur, cur_T_src, src_K, cur_invK,
+                                 return_mask=return_mask)
+        return GraphedCallable(step, cur_image, src_image, list(cur_feats), src_cam_T_cur_cam, cur_cam_T_src_cam,
+                               src_K, cur_invK)
+
     def _hot_path_one(self, cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam, cur_cam_T_src_cam,
                       src_K, cur_invK, return_mask=False, flip=False):
         o = self.run_opts
-        min_depth = torch.tensor(o.min_matching_depth).type_as(src_K).view(1, 1, 1, 1)
-        max_depth = torch.tensor(o.max_matching_depth).type_as(src_K).view(1, 1, 1, 1)
+        min_depth, max_depth = self._depth_range(src_K)
         cost_volume, lowest_cost, _, overall_mask_bhw = self.cost_volume(
             cur_feats=matching_cur_feats, src_feats=matching_src_feats, src_extrinsics=src_cam_T_cur_cam,
             src_poses=cur_cam_T_src_cam, src_Ks=src_K, cur_invK=cur_invK, min_depth=min_depth,
