@@ -245,6 +245,27 @@ int sr_instance_norm_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_p
                               int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C, float eps,
                               float leaky_slope, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------- TSDF fusion -----------
+ *
+ * TSDFFuser.integrate_depth (reference tools/tsdf.py:238-320; project_to_camera :218-236; voxel coordinates of
+ * TSDF.from_bounds / generate_voxel_coords :69-111): fuses a batch of B depth maps, in order, into the fp16 TSDF volume.
+ * All tensors are fp16 as the reference feeds them (OurFuser.fuse_frames, tools/fusers_helper.py:62-68); results are
+ * bit-identical to the reference executed on CPU.
+ *
+ *  tsdf_values, tsdf_weights : [X,Y,Z] fp16, contiguous (z fastest), updated in place; Z % 8 == 0 (the reference rounds
+ *                              volume dimensions to multiples of 8, tsdf.py:16,80-85), 16-byte aligned
+ *  voxel_coords              : [3,X,Y,Z] fp16 explicit world coordinates, or NULL: origin + index * voxel_size
+ *                              (fp32, rounded to fp16) as TSDF.from_bounds generates them -- saves 6 of 10 bytes/voxel
+ *  depth [B,H,W] fp16, depth_mask [B,H,W] bool or NULL, K / T [B,4,4] fp16 row-major (intrinsics, cam_T_world)
+ *  min_depth, max_depth, truncation (= truncation_size * voxel_size), maxW: the fuser's python scalars as fp32;
+ *  depth_range = max_depth - min_depth evaluated in double, as fp32.
+ */
+int sr_tsdf_integrate_fwd(void* tsdf_values, void* tsdf_weights, const void* voxel_coords, int X, int Y, int Z,
+                          float origin_x, float origin_y, float origin_z, float voxel_size, const void* depth,
+                          const uint8_t* depth_mask, const void* K, const void* T, int B, int H, int W,
+                          float min_depth, float max_depth, float depth_range, float truncation, float maxW,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -313,3 +313,95 @@ def resnet_matching_encoder(img, sd, precision="f32", taps=None):
     x = instance_norm(x, leaky=0.2)
     x = conv2d_replicate(x, sd["net.8.weight"], sd["net.8.bias"], precision=precision)
     return instance_norm(x)
+
+
+# ---------------------------------------------------------------- TSDF fusion (§8f "next" #2) --
+# Restates tools/tsdf.py (TSDF.from_bounds :69-97, generate_voxel_coords :99-111, TSDFFuser.project_to_camera
+# :218-236, integrate_depth :238-320) as the reference executes it: EVERY tensor is fp16 (OurFuser.fuse_frames
+# passes depth / K / cam_T_world through .half(), fusers_helper.py:62-68) and every torch op on fp16 tensors
+# computes in fp32 and rounds its result to fp16.  numpy's float16 ufuncs do exactly that, so the restatement is
+# written op for op on float16 arrays; the two matmuls round once after an fp32 dot product (products of two
+# halves are exact in fp32).  Checked bit-for-bit against the reference class run on CPU (tests/golden).
+
+_F16 = np.float16
+
+
+def _hs(s):
+    """python scalar -> fp16 the way torch converts it (c10::Half(float(double)): through fp32)."""
+    return np.float16(np.float32(s))
+
+
+def tsdf_from_bounds(bounds, voxel_size, vox_mod=8):
+    """TSDF.from_bounds: (origin float32 [3], dims (X, Y, Z), voxel_coords float16 [3,X,Y,Z], values, weights)."""
+    dims = tuple(int(np.ceil((bounds[a + "max"] - bounds[a + "min"]) / voxel_size / vox_mod)) * vox_mod for a in "xyz")
+    origin = np.array([bounds["xmin"], bounds["ymin"], bounds["zmin"]], np.float32)
+    grid = np.stack(np.meshgrid(*[np.arange(d) for d in dims], indexing="ij"), 0)
+    # int64 grid * python float -> float32 tensor product with the scalar cast to float32 (generate_voxel_coords :108)
+    coords = (origin.reshape(3, 1, 1, 1) + grid.astype(np.float32) * np.float32(voxel_size)).astype(_F16)
+    values = -np.ones(dims, _F16)
+    weights = np.zeros(dims, _F16)
+    return origin, dims, coords, values, weights
+
+
+def _half_matmul(a, b):
+    """torch.matmul on fp16 operands: exact fp32 products, fp32 accumulation in index order, one rounding to fp16."""
+    a32, b32 = a.astype(np.float32), b.astype(np.float32)
+    acc = a32[:, 0:1] * b32[0:1]
+    for k in range(1, a32.shape[1]):
+        acc = acc + a32[:, k:k + 1] * b32[k:k + 1]
+    return acc.astype(_F16)
+
+
+def _half_div_scalar(a, s):
+    """fp16 tensor / python scalar on torch's CPU path: fp32 division by the scalar AS FLOAT32 (not rounded to fp16),
+    one rounding of the quotient to fp16 (probed on torch 2.10; tensor +- scalar and comparisons DO round the scalar
+    to fp16 first)."""
+    return (a.astype(np.float32) / np.float32(s)).astype(_F16)
+
+
+def tsdf_integrate(values, weights, coords, depth_b1hw, cam_T_world_b44, K_b44, min_depth=0.5, max_depth=5.0,
+                   voxel_size=0.04, truncation_size=3.0, maxW=100.0, depth_mask_b1hw=None):
+    """TSDFFuser.integrate_depth: updates `values` / `weights` ([X,Y,Z] float16) in place, frame after frame."""
+    depth_b1hw = np.asarray(depth_b1hw, _F16)
+    T, K = np.asarray(cam_T_world_b44, _F16), np.asarray(K_b44, _F16)
+    B, _, H, W = depth_b1hw.shape
+    trunc = truncation_size * voxel_size                       # python float (tsdf.py:214-216)
+    X = coords.reshape(3, -1)
+    hom = np.concatenate([X, np.ones((1, X.shape[1]), _F16)], 0)
+    vals, wts = values.reshape(-1), weights.reshape(-1)
+    for b in range(B):
+        depth = depth_b1hw[b, 0]
+        if depth_mask_b1hw is not None:
+            depth = depth.copy()
+            depth[~np.asarray(depth_mask_b1hw[b, 0], bool)] = _F16(-1)
+        P = _half_matmul(K[b], T[b])[:3]                       # world_to_pix_P_b34 (:226)
+        cam = _half_matmul(P, hom)                             # cam_points_b3N (:232)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            z = cam[2]
+            px, py = cam[0] / z, cam[1] / z                    # (:233)
+            gx = _F16(2) * px / _F16(W) - _F16(1)              # 2 * pix / img_size - 1 (:268)
+            gy = _F16(2) * py / _F16(H) - _F16(1)
+            # F.grid_sample(mode="nearest", padding_mode="zeros", align_corners=False) on Half: ATen's
+            # grid_sampler_compute_source_index in Half arithmetic, then nearbyint (:275-279)
+            ix = ((gx + _F16(1)) * _F16(W) - _F16(1)) / _F16(2)
+            iy = ((gy + _F16(1)) * _F16(H) - _F16(1)) / _F16(2)
+            # a non-finite Half coordinate (|pix| overflows fp16 for voxels next to the camera plane) indexes
+            # texel 0 on ATen's CPU path (probed: inf / -inf / nan -> column or row 0), it is not "out of bounds"
+            ixn = np.where(np.isfinite(ix), np.rint(ix.astype(np.float32)), np.float32(0))
+            iyn = np.where(np.isfinite(iy), np.rint(iy.astype(np.float32)), np.float32(0))
+            inb = (ixn >= 0) & (ixn < W) & (iyn >= 0) & (iyn < H)
+            sd = np.zeros(X.shape[1], _F16)
+            sd[inb] = depth[iyn[inb].astype(np.int64), ixn[inb].astype(np.int64)]
+            conf = np.clip(_F16(1.0) - _half_div_scalar(sd - _hs(min_depth), max_depth - min_depth), _F16(0), _F16(1))
+            conf = (conf * conf).astype(_F16)                  # ** 2 (:283-285)
+            dist = sd - z
+            tv = np.clip(_half_div_scalar(dist, trunc), _F16(-1), _F16(1))
+            valid = (z > 0) & (dist > _hs(-trunc)) & (sd > 0) & (z < _hs(max_depth)) & (conf > 0)
+        ov, ow = vals[valid], wts[valid]
+        nv, cf = tv[valid], conf[valid]
+        rate = np.where(cf < ow, _F16(2), _F16(5)).astype(_F16)
+        nw = _half_div_scalar(cf * rate, maxW)
+        tw = ow + nw
+        vals[valid] = (ov * ow + nv * nw) / tw
+        wts[valid] = np.minimum(tw, _F16(1))
+    return values, weights

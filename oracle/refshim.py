@@ -135,6 +135,22 @@ def install_stubs():
         pass  # DepthModel itself is not importable; not needed for the hot path
 
 
+def import_tsdf():
+    """The reference's tools/tsdf.py (TSDF, TSDFFuser) with stubs for its mesh-export imports (trimesh, skimage),
+    which integrate_depth never touches."""
+    if not os.path.isdir(REFERENCE_ROOT):
+        raise RuntimeError(f"reference not present at {REFERENCE_ROOT}")
+    for name in ("trimesh", "skimage", "skimage.measure"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["skimage"].measure = sys.modules["skimage.measure"]
+    if not hasattr(sys.modules["trimesh"], "Trimesh"):
+        sys.modules["trimesh"].Trimesh = object
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    return importlib.import_module("tools.tsdf")
+
+
 def import_reference():
     """Returns the reference's (cost_volume, networks, layers, geometry_utils,
     generic_utils) modules imported unmodified from REFERENCE_ROOT."""

@@ -108,6 +108,21 @@ def main():
                             pool=pool.numpy(), layer1=layer1.numpy())
         print(name, y.shape, float(y.abs().max()))
 
+    # ---- TSDF fusion: the reference's TSDF / TSDFFuser (tools/tsdf.py) on CPU, fp16 as OurFuser.fuse_frames feeds it
+    tsdf_mod = refshim.import_tsdf()
+    for name, case in gc.TSDF_CASES.items():
+        vol = tsdf_mod.TSDF.from_bounds(dict(case["bounds"]), voxel_size=case["voxel_size"])
+        fuser = tsdf_mod.TSDFFuser(vol, max_depth=case["max_depth"], use_gpu=False)
+        depth, K, T, mask = gc.tsdf_inputs(case)
+        n1 = (case["frames"] + 1) // 2
+        fuser.integrate_depth(depth[:n1].half(), T[:n1].half(), K[:n1].half())
+        mid_v, mid_w = fuser.tsdf_values.clone(), fuser.tsdf_weights.clone()
+        fuser.integrate_depth(depth[n1:].half(), T[n1:].half(), K[n1:].half(), depth_mask_b1hw=mask[n1:])
+        np.savez_compressed(os.path.join(OUT, f"tsdf_{name}.npz"), values=fuser.tsdf_values.numpy(),
+                            weights=fuser.tsdf_weights.numpy(), values_mid=mid_v.numpy(), weights_mid=mid_w.numpy(),
+                            voxel_coords=vol.voxel_coords.numpy(), origin=vol.origin.float().numpy())
+        print(name, tuple(fuser.shape), "touched voxels", int((fuser.tsdf_weights > 0).sum()))
+
 
 if __name__ == "__main__":
     main()

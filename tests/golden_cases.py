@@ -112,3 +112,38 @@ def matching_input(case, device="cpu"):
     rng = np.random.default_rng(case["seed"])
     x = rng.standard_normal((case["B"], 3, case["H"], case["W"]), dtype=np.float32)
     return torch.from_numpy(x).to(device)
+
+
+# ------------------------------------------------------------ TSDF fusion (§8f "next" #2)
+
+TSDF_CASES = {
+    # a room-sized slab of voxels seen by 5 frames (two integrate_depth calls: batch of 3, then 2 with a depth mask)
+    "room": dict(bounds=dict(xmin=-1.0, xmax=1.0, ymin=-0.8, ymax=0.8, zmin=0.2, zmax=2.2), voxel_size=0.04,
+                 H=48, W=64, frames=5, max_depth=3.0, seed=51),
+    # coarse voxels, frames looking partly away from the volume / from inside it (z <= 0 voxels, out-of-image pixels)
+    "skew": dict(bounds=dict(xmin=-0.5, xmax=0.9, ymin=-0.7, ymax=0.4, zmin=-0.4, zmax=1.1), voxel_size=0.05,
+                 H=30, W=44, frames=4, max_depth=2.0, seed=52),
+}
+
+
+def tsdf_inputs(case):
+    """Depth maps [F,1,H,W], intrinsics and extrinsics [F,4,4] (float32; the fuser receives them through .half())
+    and a boolean depth mask for the second half of the frames."""
+    rng = np.random.default_rng(case["seed"])
+    F_, H, W = case["frames"], case["H"], case["W"]
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    depth = np.stack([1.1 + 0.25 * np.sin(0.13 * xx + i) * np.cos(0.11 * yy - i) +
+                      0.05 * rng.standard_normal((H, W)).astype(np.float32) for i in range(F_)])[:, None]
+    depth[:, :, :2, :3] = 0.0                                  # invalid (zero) depths
+    K = np.tile(np.eye(4, dtype=np.float32), (F_, 1, 1))
+    K[:, 0, 0] = K[:, 1, 1] = 0.95 * W
+    K[:, 0, 2], K[:, 1, 2] = W / 2, H / 2
+    T = np.tile(np.eye(4, dtype=np.float32), (F_, 1, 1))
+    for i in range(F_):
+        a, b2 = 0.12 * i - 0.1, 0.07 * i
+        Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        Rx = np.array([[1, 0, 0], [0, np.cos(b2), -np.sin(b2)], [0, np.sin(b2), np.cos(b2)]], np.float32)
+        T[i, :3, :3] = Ry @ Rx
+        T[i, :3, 3] = [0.06 * i - 0.1, 0.03 * i, 0.08 * i - 0.05]
+    mask = rng.random((F_, 1, H, W)) > 0.2
+    return torch.from_numpy(depth.astype(np.float32)), torch.from_numpy(K), torch.from_numpy(T), torch.from_numpy(mask)

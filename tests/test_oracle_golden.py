@@ -131,3 +131,24 @@ def test_matching_encoder_oracle(name):
     assert_close(out, gold["out"], what=f"{name} matching features")
     out64 = oracle.resnet_matching_encoder(gc.matching_input(case).numpy(), sd, precision="f64")
     assert_close(out64, gold["out"], what=f"{name} matching features (f64 arbitration)")
+
+
+@pytest.mark.parametrize("name", list(gc.TSDF_CASES))
+def test_tsdf_oracle_bit_exact(name):
+    """oracle.tsdf_from_bounds / tsdf_integrate vs the reference's TSDF + TSDFFuser (tools/tsdf.py) run on CPU:
+    voxel coordinates, TSDF values and weights are fp16 and must agree bit for bit."""
+    case = gc.TSDF_CASES[name]
+    gold = gc.load_golden("tsdf", name)
+    origin, dims, coords, values, weights = oracle.tsdf_from_bounds(case["bounds"], case["voxel_size"])
+    assert dims == gold["values"].shape
+    assert np.array_equal(coords.view(np.uint16), gold["voxel_coords"].view(np.uint16))
+    depth, K, T, mask = (t.numpy() for t in gc.tsdf_inputs(case))
+    n1 = (case["frames"] + 1) // 2
+    kw = dict(max_depth=case["max_depth"], voxel_size=case["voxel_size"])
+    oracle.tsdf_integrate(values, weights, coords, depth[:n1], T[:n1], K[:n1], **kw)
+    assert np.array_equal(values.view(np.uint16), gold["values_mid"].view(np.uint16))
+    assert np.array_equal(weights.view(np.uint16), gold["weights_mid"].view(np.uint16))
+    oracle.tsdf_integrate(values, weights, coords, depth[n1:], T[n1:], K[n1:], depth_mask_b1hw=mask[n1:], **kw)
+    assert np.array_equal(values.view(np.uint16), gold["values"].view(np.uint16))
+    assert np.array_equal(weights.view(np.uint16), gold["weights"].view(np.uint16))
+    assert int((weights > 0).sum()) > 1000  # the case actually fuses something
