@@ -6,6 +6,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -414,6 +415,68 @@ class HeroVolumeOnly:
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "not run for this workload"}
 
 
+class TsdfFuse:
+    """TSDF fusion of predicted depth maps ("next" component after the hot path, reference tools/tsdf.py +
+    fusers_helper.OurFuser): batches of 8 640x480 fp16 depth maps into the reference's default +-10 m cube at 4 cm
+    (504^3 = 128 M voxels, fp16 values + weights = 512 MB), camera moving through the volume."""
+    name = "tsdf_fuse"
+
+    def __init__(self, dev, rank, B=8, bounds=None):
+        from simplerecon_amd.tsdf import OurFuser
+        self.dev, self.B = dev, B
+        self.frames_per_step = B
+        self.fuser = OurFuser(bounds=bounds, max_fusion_depth=3.0, device=dev)
+        g = torch.Generator(device="cpu").manual_seed(2000 + rank)
+        self.depth = (1.0 + 1.5 * torch.rand((B, 1, 480, 640), generator=g)).to(dev).half()
+        K = torch.eye(4).repeat(B, 1, 1)
+        K[:, 0, 0] = K[:, 1, 1] = 577.87
+        K[:, 0, 2], K[:, 1, 2] = 320.0, 240.0
+        self.K = K.to(dev).half()
+        self.step_i = 0
+
+    def _poses(self, i):
+        T = torch.eye(4).repeat(self.B, 1, 1)
+        for k in range(self.B):   # a slow sweep: 5 cm per frame along x, small yaw
+            t = 0.05 * (i * self.B + k)
+            a = 0.02 * (i * self.B + k)
+            T[k, 0, 0], T[k, 0, 2], T[k, 2, 0], T[k, 2, 2] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+            T[k, 0, 3] = -t % 4.0
+        return T.to(self.dev).half()
+
+    def step(self, i=0):
+        self.step_i += 1
+        self.fuser.tsdf_fuser_pred.integrate_depth(self.depth, self._poses(self.step_i), self.K)
+
+    def finish(self, world):
+        pass  # each rank fuses its own scene (scenes are independent; a volume is never split across GPUs)
+
+    def config(self, world):
+        f = self.fuser.tsdf_fuser_pred
+        return {"workload": f"{self.name}: TSDFFuser.integrate_depth, batch of {self.B} 640x480 fp16 depth maps into a "
+                            f"{'x'.join(str(int(d)) for d in f.shape)} fp16 volume at {f.voxel_size} m "
+                            f"(reference default +-10 m bounds), max depth 3 m",
+                "frames_per_step_per_gpu": self.B, "parallelism": f"replica x{world} (one scene per GPU)"}
+
+    def roofline(self, n):
+        f = self.fuser.tsdf_fuser_pred
+        T = self._poses(1)
+        t = _time_launches(lambda: f.integrate_depth(self.depth, T, self.K), max(5, n))
+        vox = f.tsdf_values.numel()
+        nbytes = 4.0 * vox + 2.0 * self.depth.numel()
+        return {"kernel": "sr_tsdf_integrate_kernel", "bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": _pmc_traffic(self.name),
+                "avg_launch_us": t * 1e6, "algorithmic_bytes_per_launch": nbytes,
+                "note": "algorithmic bytes = one read of the fp16 values + weights of every voxel + the depth maps; the "
+                        "kernel rejects tiles / segments outside the view frusta on their corners WITHOUT reading them, "
+                        "so it is bound by that rejection arithmetic (VALU), not by HBM: real traffic is far below"}
+
+    def extra_kernels(self, n):
+        return None
+
+    def cpu_baseline(self):
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "not run for this workload"}
+
+
 class DotFull(HeroCfg3):
     """dot_product_model.yaml through the full hot path (cost volume + conv stack), batch 8."""
     name = "dot_full"
@@ -434,6 +497,7 @@ WORKLOADS = {
     "dot_full": lambda dev, rank: DotFull(dev, rank),
     "hero_cfg5_volume": lambda dev, rank: HeroVolumeOnly(dev, rank),
     "hero_cfg3_volume": lambda dev, rank: HeroVolumeOnly(dev, rank, B=8, K=7, D=64, h=120, w=160),
+    "tsdf_fuse": lambda dev, rank: TsdfFuse(dev, rank),
     "dot_cfg2": lambda dev, rank: DotCfg2(dev, rank),
     "dot_b8": lambda dev, rank: DotCfg2(dev, rank, B=8),
 }
