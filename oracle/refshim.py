@@ -135,6 +135,15 @@ def install_stubs():
         pass  # DepthModel itself is not importable; not needed for the hot path
 
 
+def import_keyframe_buffer():
+    """The reference's tools/keyframe_buffer.py (numpy only)."""
+    if not os.path.isdir(REFERENCE_ROOT):
+        raise RuntimeError(f"reference not present at {REFERENCE_ROOT}")
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    return importlib.import_module("tools.keyframe_buffer")
+
+
 def import_tsdf():
     """The reference's tools/tsdf.py (TSDF, TSDFFuser) with stubs for its mesh-export imports (trimesh, skimage),
     which integrate_depth never touches."""

@@ -123,6 +123,22 @@ def main():
                             voxel_coords=vol.voxel_coords.numpy(), origin=vol.origin.float().numpy())
         print(name, tuple(fuser.shape), "touched voxels", int((fuser.tsdf_weights > 0).sum()))
 
+    # ---- keyframe selection: the reference's KeyframeBuffer on a synthetic pose stream
+    kb = refshim.import_keyframe_buffer()
+    cfg = kb.DVMVS_Config
+    buf = kb.KeyframeBuffer(cfg.test_keyframe_buffer_size, cfg.test_keyframe_pose_distance, cfg.test_optimal_t_measure,
+                            cfg.test_optimal_R_measure, store_return_indices=True)
+    poses, dist = gc.keyframe_stream()
+    codes, tuples = [], []
+    for i, (pose, d) in enumerate(zip(poses, dist)):
+        code = buf.try_new_keyframe(pose, None, dist_to_last_valid=d, index=i)
+        codes.append(code)
+        if code == 1:
+            tuples.append([i] + [f[2] for f in buf.get_best_measurement_frames(7)] + [-1] * 7)
+    np.savez_compressed(os.path.join(OUT, "keyframes.npz"), codes=np.array(codes, np.int8),
+                        tuples=np.array([t[:8] for t in tuples], np.int32))
+    print("keyframes", np.bincount(codes), len(tuples))
+
 
 if __name__ == "__main__":
     main()

@@ -147,3 +147,29 @@ def tsdf_inputs(case):
         T[i, :3, 3] = [0.06 * i - 0.1, 0.03 * i, 0.08 * i - 0.05]
     mask = rng.random((F_, 1, H, W)) > 0.2
     return torch.from_numpy(depth.astype(np.float32)), torch.from_numpy(K), torch.from_numpy(T), torch.from_numpy(mask)
+
+
+# ------------------------------------------------------------ keyframe selection (§8f "next" #4)
+
+def keyframe_stream(seed=61, n=400):
+    """A hand-held style camera trajectory (camera-to-world poses) with pauses, fast segments, tracking drop-outs (NaN
+    poses, one longer than the 30-frame 'lost' threshold) and a gap in the valid-frame distances."""
+    rng = np.random.default_rng(seed)
+    poses, dist = [], []
+    T = np.eye(4)
+    for i in range(n):
+        speed = 0.0 if 120 <= i < 150 else (0.06 if 200 <= i < 230 else 0.012)
+        w = rng.standard_normal(3) * 0.01 + np.array([0.0, 0.004, 0.0])
+        th = np.linalg.norm(w)
+        kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        dR = np.eye(3) + np.sin(th) / th * kx + (1 - np.cos(th)) / th ** 2 * kx @ kx
+        step = np.eye(4)
+        step[:3, :3] = dR
+        step[:3, 3] = speed * (np.array([1.0, 0.1, 0.3]) + 0.3 * rng.standard_normal(3))
+        T = T @ step
+        pose = T.copy()
+        if 60 <= i < 70 or 260 <= i < 300:
+            pose[:] = np.nan
+        poses.append(pose)
+        dist.append(45 if i == 330 else 1)
+    return poses, dist

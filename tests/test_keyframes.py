@@ -1,0 +1,52 @@
+"""Keyframe / source-view selection (simplerecon_amd.keyframes) vs the reference's KeyframeBuffer
+(tools/keyframe_buffer.py) on a synthetic pose stream, and the dataset's source ordering."""
+import numpy as np
+import torch
+
+import golden_cases as gc
+from simplerecon_amd import keyframes as kf
+from simplerecon_amd.geometry import pose_distance
+
+
+def test_keyframe_buffer_matches_reference_stream():
+    gold = dict(np.load(gc.GOLDEN_DIR + "/keyframes.npz"))
+    cfg = kf.DVMVS_Config
+    buf = kf.KeyframeBuffer(cfg.test_keyframe_buffer_size, cfg.test_keyframe_pose_distance, cfg.test_optimal_t_measure,
+                            cfg.test_optimal_R_measure, store_return_indices=True)
+    poses, dist = gc.keyframe_stream()
+    codes, tuples = [], []
+    for i, (pose, d) in enumerate(zip(poses, dist)):
+        code = buf.try_new_keyframe(pose, None, dist_to_last_valid=d, index=i)
+        codes.append(code)
+        if code == kf.KeyframeBuffer.ADDED:
+            tuples.append(([i] + [f[2] for f in buf.get_best_measurement_frames(7)] + [-1] * 7)[:8])
+        assert len(buf.buffer) <= cfg.test_keyframe_buffer_size
+    assert np.array_equal(np.array(codes, np.int8), gold["codes"])
+    assert np.array_equal(np.array(tuples, np.int32), gold["tuples"])
+    assert set(np.unique(gold["codes"])) == {0, 1, 2, 3, 4, 5}   # the stream exercises every branch
+
+
+def test_pose_distance_and_pair_validity():
+    a = np.eye(4)
+    b = np.eye(4)
+    b[:3, 3] = [0.3, 0.0, 0.4]
+    combined, r_m, t_m = kf.pose_distance(a, b)
+    assert abs(t_m - 0.5) < 1e-12 and r_m == 0.0 and abs(combined - 0.5) < 1e-12
+    assert kf.is_valid_pair(a, b, 0.125, 0.6) and not kf.is_valid_pair(a, b, 0.125, 0.325)
+    assert not kf.is_pose_available(np.full((4, 4), np.nan)) and kf.is_pose_available(a)
+    buf = kf.KeyframeBuffer(4, 0.1, 0.15, 0.0, store_return_indices=True)
+    try:
+        buf.try_new_keyframe(a, None)
+        assert False, "index=None must be refused"
+    except ValueError:
+        pass
+
+
+def test_sort_sources_by_pose_penalty():
+    rng = np.random.default_rng(3)
+    cur_cam_T_world = np.eye(4, dtype=np.float32)
+    src = np.tile(np.eye(4, dtype=np.float32), (7, 1, 1))
+    src[:, :3, 3] = rng.standard_normal((7, 3)).astype(np.float32) * 0.2
+    order = kf.sort_sources_by_pose_penalty(cur_cam_T_world, src)
+    pen = pose_distance(torch.from_numpy(cur_cam_T_world)[None] @ torch.from_numpy(src))[0].numpy()
+    assert sorted(order) == list(range(7)) and np.all(np.diff(pen[order]) >= 0)
