@@ -245,6 +245,23 @@ int sr_instance_norm_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_p
                               int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C, float eps,
                               float leaky_slope, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Statistics only: stats[b][0][c] = mean, stats[b][1][c] = 1 / sqrt(var + eps) ([B,2,C] floats, 16-byte aligned) -- for
+ * consumers that normalise on the fly (sr_conv3x3_c16_nhwc_fwd).  Same workspace as sr_instance_norm_nhwc_fwd. */
+int sr_instance_norm_stats_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, int B, int H, int W, int C,
+                                float eps, float* stats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* nn.Conv2d(Cin, Cout <= 16, 3, padding=1, padding_mode = replicate ? "replicate" : "zeros") + bias [+ LeakyReLU] on
+ * channels-last data, with an optional InstanceNorm (+ LeakyReLU(in_leaky_slope)) applied to the INPUT on the fly from
+ * `in_stats` (sr_instance_norm_stats_nhwc; NULL = input used as is): the InstanceNorm -> LeakyReLU -> Conv2d(128, 16,
+ * replicate) end of the matching encoder (reference modules/networks.py:188-197) without materialising the
+ * normalised tensor.  Cin % 32 == 0; fp32 MFMA 16x16x4 (no padded output channels). */
+size_t sr_conv3x3_c16_packed_weight_floats(int Cout, int Cin);
+int sr_conv3x3_c16_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream);
+int sr_conv3x3_c16_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* in_stats,
+                            float in_leaky_slope, const float* packed_weight, const float* bias, float* out,
+                            int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin, int Cout,
+                            int replicate, float leaky_slope, void* stream);
+
 /* ------------------------------------------------------------- TSDF fusion -----------
  *
  * TSDFFuser.integrate_depth (reference tools/tsdf.py:238-320; project_to_camera :218-236; voxel coordinates of

@@ -34,6 +34,7 @@ def main():
         t = ops.conv2d(pool, blk.conv1, bn=blk.bn1, leaky=0.0)
         c1 = ops.conv2d(pool, net[5])
         c2 = ops.conv2d(c1, net[8])
+        st = ops.instance_norm_stats(c1)
         rows = [
             ("stem 7x7 s2 + bn + relu", lambda: ops.stem7x7(x, net[0], net[1]), 2.0 * nimg * 240 * 320 * 64 * 147),
             ("maxpool + blurpool", lambda: ops.maxblurpool(stem), None),
@@ -44,6 +45,9 @@ def main():
             ("conv1x1 64->128", lambda: ops.conv2d(pool, net[5]), 2.0 * nimg * 120 * 160 * 64 * 128),
             ("instance norm 128 + lrelu", lambda: ops.instance_norm(c1, leaky=0.2, inplace=True), None),
             ("conv3x3 128->16 replicate", lambda: ops.conv2d(c1, net[8]), 2.0 * nimg * 120 * 160 * 128 * 16 * 9),
+            ("instance norm stats 128", lambda: ops.instance_norm_stats(c1), None),
+            ("norm+lrelu+conv3x3 128->16 fused", lambda: ops.conv3x3_c16(c1, net[8], in_stats=st, in_leaky=0.2),
+             2.0 * nimg * 120 * 160 * 128 * 16 * 9),
             ("instance norm 16", lambda: ops.instance_norm(c2, inplace=True), None),
             ("whole encoder", lambda: enc(x), 8.1e9 * nimg),
         ]

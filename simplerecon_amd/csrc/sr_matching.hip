@@ -355,6 +355,158 @@ __global__ __launch_bounds__(256) void sr_inorm_apply_kernel(SrInormParams p) {
   }
 }
 
+// ------------------------------------------------------------------ conv 3x3, few output channels ----------------
+//
+// nn.Conv2d(Cin, Cout <= 16, 3, padding=1 [, padding_mode="replicate"]) with an optional InstanceNorm + LeakyReLU
+// applied to its INPUT on the fly -- the 128 -> 16 conv that ends the matching encoder (networks.py:189-197), whose
+// normalised 128-channel input would otherwise make an extra HBM round trip (1.26 GB per 64 images).  The 32-wide
+// N-tiles of sr_conv_kernel waste half the matrix work on 16 channels, so this kernel uses v_mfma_f32_16x16x4_f32:
+// M = 16 pixels of one output row, N = 16 channels, K = 4 input channels.  A workgroup (4 waves) owns 8 x 16 output
+// pixels (wave w: rows 2w, 2w+1); per 32-channel slab the 10 x 18 halo is staged global -> registers (normalise,
+// LeakyReLU, padding) -> LDS (36-float pixel rows: conflict-free ds_read_b128), double-buffered, one barrier per slab;
+// a lane's float4 holds channels 16g + 4(l>>4) + s, s = 0..3 = its K-slot in 4 consecutive MFMAs (the packed weight
+// uses the same order); weights stream from L2, 2 steps ahead.
+#define SR_T16_ROW 36
+#define SR_T16_HW 18
+#define SR_T16_HH 10
+#define SR_T16_TILE (SR_T16_HH * SR_T16_HW * SR_T16_ROW)
+#define SR_T16_STAGE 6  // float4 per thread and slab (10*18*8 = 1440 <= 6*256)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SrT16Params {
+  const float* in; int64_t in_sb; int in_sp;
+  const float* stats;                 // [B][2][Cin] (mean, rstd) or null
+  float in_slope;                     // LeakyReLU on the normalised input, < 0: none
+  const float* wp;                    // packed [Cin/32][9 taps][2 g][64 lanes][4]
+  const float* bias;
+  float* out; int64_t out_sb; int out_sp;
+  int H, W, Cin, Cout, replicate;
+  int tiles_x, tiles_y, total;
+  float out_slope;
+};
+
+__global__ void sr_t16_pack_kernel(const float* __restrict__ w /*[Cout,Cin,3,3]*/, float* __restrict__ packed, int Cout,
+                                   int Cin) {
+  const int total = (Cin / 32) * 9 * 2 * 64 * 4;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int s = e & 3, lane = (e >> 2) & 63, g = (e >> 8) & 1, tap = (e >> 9) % 9, slab = (e >> 9) / 9;
+    const int co = lane & 15, ci = 32 * slab + 16 * g + 4 * (lane >> 4) + s;
+    packed[e] = co < Cout ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void sr_t16_kernel(SrT16Params p) {
+  __shared__ __attribute__((aligned(16))) float tiles[2][SR_T16_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int slabs = p.Cin >> 5;
+  const int cq = tid & 7;  // this thread stages channels 4*cq .. 4*cq+3 of every slab
+  const float4* wl = reinterpret_cast<const float4*>(p.wp) + lane;
+
+  for (int tile = blockIdx.x; tile < p.total; tile += gridDim.x) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const int oy0 = 8 * ty, ox0 = 16 * tx;
+    const float* __restrict__ in_b = p.in + (int64_t)b * p.in_sb;
+    const float* st = p.stats ? p.stats + (int64_t)b * 2 * p.Cin : nullptr;
+
+    int offs[SR_T16_STAGE];
+#pragma unroll
+    for (int it = 0; it < SR_T16_STAGE; ++it) {
+      const int e = tid + it * 256, px = e >> 3;
+      const int hy = px / SR_T16_HW, hx = px - hy * SR_T16_HW;
+      int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      if (p.replicate) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }
+      const bool ok = (px < SR_T16_HH * SR_T16_HW) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+      offs[it] = ok ? (iy * p.W + ix) * p.in_sp + 4 * cq : -1;
+    }
+    float4 stg[SR_T16_STAGE];
+    auto stage_load = [&](int slab) {
+#pragma unroll
+      for (int it = 0; it < SR_T16_STAGE; ++it) {
+        const float4 v = *reinterpret_cast<const float4*>(in_b + (offs[it] >= 0 ? offs[it] + 32 * slab : 0));
+        stg[it] = v;
+      }
+    };
+    auto stage_store = [&](int slab, float* tl) {
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f), r = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (st) {
+        m = *reinterpret_cast<const float4*>(st + 32 * slab + 4 * cq);
+        r = *reinterpret_cast<const float4*>(st + p.Cin + 32 * slab + 4 * cq);
+      }
+#pragma unroll
+      for (int it = 0; it < SR_T16_STAGE; ++it) {
+        const int e = tid + it * 256, px = e >> 3;
+        if (px < SR_T16_HH * SR_T16_HW) {
+          float4 v = stg[it];
+          v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w;
+          if (p.in_slope >= 0.f) {
+            v.x = v.x >= 0.f ? v.x : v.x * p.in_slope; v.y = v.y >= 0.f ? v.y : v.y * p.in_slope;
+            v.z = v.z >= 0.f ? v.z : v.z * p.in_slope; v.w = v.w >= 0.f ? v.w : v.w * p.in_slope;
+          }
+          if (offs[it] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding pads the NORMALISED tensor
+          *reinterpret_cast<float4*>(&tl[px * SR_T16_ROW + 4 * cq]) = v;
+        }
+      }
+    };
+
+    f32x4 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+
+    __syncthreads();  // the previous tile's reads of buffer 0 are done
+    stage_load(0);
+    stage_store(0, tiles[0]);
+    __syncthreads();
+    for (int slab = 0; slab < slabs; ++slab) {
+      const float* tl = tiles[slab & 1];
+      const bool more = slab + 1 < slabs;
+      if (more) stage_load(slab + 1);
+      const float4* ws = wl + (size_t)slab * 9 * 2 * 64;
+      float4 wA = ws[0], wB = ws[64];
+#pragma unroll
+      for (int step = 0; step < 18; ++step) {  // (tap, g)
+        const int tap = step >> 1, g = step & 1, ky = tap / 3, kx = tap % 3;
+        const float4 w = wA;
+        wA = wB;
+        if (step + 2 < 18) wB = ws[(step + 2) * 64];
+        float4 a[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          a[m] = *reinterpret_cast<const float4*>(&tl[((2 * wave + m + ky) * SR_T16_HW + li + kx) * SR_T16_ROW + 16 * g + 4 * lk]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, w.x, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, w.y, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, w.z, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, w.w, acc[m], 0, 0, 0);
+        }
+      }
+      if (more) stage_store(slab + 1, tiles[(slab + 1) & 1]);
+      __syncthreads();
+    }
+
+    // D[i = 4*(l>>4) + r][j = l&15]: pixel i of the row, channel j
+    float* __restrict__ ob = p.out + (int64_t)b * p.out_sb;
+    const float bv = (p.bias && li < p.Cout) ? p.bias[li] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int oy = oy0 + 2 * wave + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ox = ox0 + 4 * lk + r;
+        if (oy < p.H && ox < p.W && li < p.Cout) {
+          float v = acc[m][r] + bv;
+          if (p.out_slope >= 0.f) v = v >= 0.f ? v : v * p.out_slope;
+          ob[((int64_t)oy * p.W + ox) * p.out_sp + li] = v;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ C ABI -------------
 
 static int sr_cus() {
@@ -366,6 +518,44 @@ static int sr_cus() {
     else cus = 256;
   }
   return cus;
+}
+
+extern "C" size_t sr_conv3x3_c16_packed_weight_floats(int Cout, int Cin) {
+  if (Cout <= 0 || Cout > 16 || Cin <= 0 || (Cin % 32)) return 0;
+  return (size_t)(Cin / 32) * 9 * 2 * 64 * 4;
+}
+
+extern "C" int sr_conv3x3_c16_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream_) {
+  if (!weight || !packed) return SR_ERR_INVALID_ARGUMENT;
+  if (Cout <= 0 || Cout > 16 || Cin <= 0 || (Cin % 32)) return SR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sr_t16_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream_, weight, packed, Cout, Cin);
+  return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" int sr_conv3x3_c16_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                       const float* in_stats, float in_leaky_slope, const float* packed_weight,
+                                       const float* bias, float* out, int64_t out_batch_stride, int out_pix_stride,
+                                       int B, int H, int W, int Cin, int Cout, int replicate, float leaky_slope,
+                                       void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!in || !packed_weight || !out) return SR_ERR_INVALID_ARGUMENT;
+  if (Cout > 16 || (Cin % 32) || (in_pix_stride % 4) || (in_batch_stride % 4) || ((uintptr_t)in & 15) ||
+      (in_stats && ((uintptr_t)in_stats & 15)))
+    return SR_ERR_UNSUPPORTED;
+  SrT16Params p;
+  p.in = in; p.in_sb = in_batch_stride; p.in_sp = in_pix_stride;
+  p.stats = in_stats; p.in_slope = in_leaky_slope;
+  p.wp = packed_weight; p.bias = bias;
+  p.out = out; p.out_sb = out_batch_stride; p.out_sp = out_pix_stride;
+  p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.replicate = replicate;
+  p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
+  p.total = p.tiles_x * p.tiles_y * B;
+  p.out_slope = leaky_slope;
+  int blocks = 2 * sr_cus();
+  if (blocks > p.total) blocks = p.total;
+  hipLaunchKernelGGL(sr_t16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
+  return sr_hip_rc(hipGetLastError());
 }
 
 extern "C" size_t sr_stem_packed_weight_floats(int Cout) { return Cout == 64 ? (size_t)SR_STEM_WFLOATS : 0; }
@@ -430,6 +620,30 @@ extern "C" size_t sr_instance_norm_workspace_bytes(int B, int H, int W, int C) {
   int chunks, chunk_pix;
   sr_inorm_chunks(B, H * W, &chunks, &chunk_pix);
   return ((size_t)B * chunks * 2 * C + (size_t)B * 2 * C) * sizeof(float);
+}
+
+extern "C" int sr_instance_norm_stats_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, int B, int H,
+                                           int W, int C, float eps, float* stats, void* workspace,
+                                           size_t workspace_bytes, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!in || !stats || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if ((C % 4) || C > 256 || (in_pix_stride % 4) || (in_batch_stride % 4) || ((uintptr_t)in & 15) ||
+      ((uintptr_t)workspace & 15))
+    return SR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sr_instance_norm_workspace_bytes(B, H, W, C)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  SrInormParams p;
+  p.in = in; p.in_sb = in_batch_stride; p.in_sp = in_pix_stride;
+  p.out = nullptr; p.out_sb = 0; p.out_sp = 0;
+  p.HW = H * W; p.C = C; p.C4 = C / 4;
+  sr_inorm_chunks(B, p.HW, &p.chunks, &p.chunk_pix);
+  p.partial = (float*)workspace;
+  p.stats = stats;
+  p.eps = eps; p.slope = -1.0f;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(sr_inorm_partial_kernel, dim3(p.chunks, B), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(sr_inorm_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, p, B);
+  return sr_hip_rc(hipGetLastError());
 }
 
 extern "C" int sr_instance_norm_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out,

@@ -222,6 +222,12 @@ class ResnetMatchingEncoder(nn.Module):
             t = ops.conv2d(x, blk.conv1, bn=blk.bn1, leaky=0.0)
             x = ops.conv2d(t, blk.conv2, bn=blk.bn2, residual=x, leaky=0.0)
         x = ops.conv2d(x, net[5])
-        x = ops.instance_norm(x, eps=net[6].eps, leaky=net[7].negative_slope, inplace=True)
-        x = ops.conv2d(x, net[8])
+        if net[8].out_channels <= 16 and net[8].in_channels % 32 == 0:
+            # InstanceNorm + LeakyReLU of the 128-channel map are applied inside the last conv's input staging:
+            # the normalised tensor never goes to HBM
+            stats = ops.instance_norm_stats(x, eps=net[6].eps)
+            x = ops.conv3x3_c16(x, net[8], in_stats=stats, in_leaky=net[7].negative_slope)
+        else:
+            x = ops.instance_norm(x, eps=net[6].eps, leaky=net[7].negative_slope, inplace=True)
+            x = ops.conv2d(x, net[8])
         return ops.instance_norm(x, eps=net[9].eps, inplace=True)

@@ -382,3 +382,70 @@ def instance_norm(x, eps=1e-5, leaky=None, inplace=False):
                                            _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr(x.device))
     _lib.check(rc, "sr_instance_norm_nhwc_fwd")
     return out
+
+
+_PACKED_C16 = weakref.WeakKeyDictionary()  # nn.Conv2d -> (state key, packed weight, bias)
+
+
+def instance_norm_stats(x, eps=1e-5):
+    """Per-(image, channel) InstanceNorm statistics of a channels-last tensor: [B,2,C] = (mean, 1/sqrt(var + eps))."""
+    x = as_nhwc(x, "instance_norm_stats input")
+    b, c, h, w = x.shape
+    stats = torch.empty((b, 2, c), dtype=torch.float32, device=x.device)
+    if b == 0:
+        return stats
+    lib = _lib.lib()
+    ws = _workspace(x.device, "inorm", lib.sr_instance_norm_workspace_bytes(b, h, w, c))
+    isb, isp = _strides(x)
+    with torch.cuda.device(x.device):
+        rc = lib.sr_instance_norm_stats_nhwc(_lib.ptr(x), isb, isp, b, h, w, c, C.c_float(eps), _lib.ptr(stats),
+                                             _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_instance_norm_stats_nhwc")
+    return stats
+
+
+def conv3x3_c16(x, conv: nn.Conv2d, in_stats=None, in_leaky=None, leaky=None):
+    """conv3x3 (<= 16 output channels, zero or replicate padding) of act(InstanceNorm(x)) where the normalisation
+    (statistics `in_stats` from instance_norm_stats) and its LeakyReLU are applied while the input is staged."""
+    _lib.refuse_autograd(x, conv.weight)
+    x = as_nhwc(x, "conv input")
+    b, ci, h, w = x.shape
+    co = conv.out_channels
+    if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or tuple(conv.padding) != (1, 1) or conv.groups != 1 \
+            or conv.dilation != (1, 1) or conv.padding_mode not in ("zeros", "replicate") or co > 16 or ci % 32 \
+            or ci != conv.in_channels:
+        raise _lib.HipLibraryError(f"conv3x3_c16 needs Conv2d(32k, <=16, 3, padding=1), got {conv} for {ci} channels")
+    lib = _lib.lib()
+    key = _state_key(conv, None)
+    hit = _PACKED_C16.get(conv)
+    if hit is None or hit[0] != key:
+        wp = torch.empty(lib.sr_conv3x3_c16_packed_weight_floats(co, ci), dtype=torch.float32, device=conv.weight.device)
+        with torch.cuda.device(conv.weight.device):
+            _lib.check(lib.sr_conv3x3_c16_pack_weights(_lib.ptr(conv.weight.detach().contiguous()), co, ci, _lib.ptr(wp),
+                                                       _lib.stream_ptr(conv.weight.device)), "sr_conv3x3_c16_pack_weights")
+        hit = (key, wp, conv.bias.detach() if conv.bias is not None else None)
+        _PACKED_C16[conv] = hit
+    _, wp, bias = hit
+    if in_stats is not None and (tuple(in_stats.shape) != (b, 2, ci) or not in_stats.is_contiguous()):
+        raise ValueError(f"in_stats must be a contiguous [{b}, 2, {ci}] tensor")
+    out = empty_nhwc(b, co, h, w, x.device)
+    if b == 0:
+        return out
+    isb, isp = _strides(x)
+    osb, osp = _strides(out)
+    prof = PROFILE
+    with torch.cuda.device(x.device):
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        rc = lib.sr_conv3x3_c16_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(in_stats),
+                                         C.c_float(-1.0 if in_leaky is None else float(in_leaky)), _lib.ptr(wp),
+                                         _lib.ptr(bias), _lib.ptr(out), osb, osp, b, h, w, ci, co,
+                                         int(conv.padding_mode == "replicate"),
+                                         C.c_float(-1.0 if leaky is None else float(leaky)), _lib.stream_ptr(x.device))
+        if prof is not None:
+            ev1.record()
+            prof.append(("sr_t16_kernel", 2.0 * b * h * w * co * ci * 9, ev0, ev1, (b, ci, h, w, co, 3, 1),
+                         2.0 * b * ((h + 7) // 8) * ((w + 15) // 16) * 128 * 16 * ci * 9))
+    _lib.check(rc, "sr_conv3x3_c16_nhwc_fwd")
+    return out

@@ -100,6 +100,26 @@ def test_replicate_padded_conv():
     assert np.abs(_nchw(y)[:, :, 1:-1, 1:-1] - zero[:, :, 1:-1, 1:-1]).max() < 1e-4  # interior = zero-padded conv
 
 
+@pytest.mark.parametrize("mode,with_norm", [("replicate", True), ("zeros", True), ("replicate", False)])
+def test_conv3x3_c16_with_fused_input_norm(mode, with_norm):
+    """sr_conv3x3_c16_nhwc_fwd = conv3x3(LeakyReLU(InstanceNorm(x))) without materialising the normalised tensor."""
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((2, 64, 11, 19), dtype=np.float32) * 1.7 + 0.4).astype(np.float32)
+    conv = synthetic.seeded_fill_(nn.Conv2d(64, 12, 3, padding=1, padding_mode=mode), seed=8).to(DEV)
+    xt = torch.from_numpy(x).to(DEV)
+    with torch.inference_mode():
+        stats = ops.instance_norm_stats(xt) if with_norm else None
+        y = ops.conv3x3_c16(xt, conv, in_stats=stats, in_leaky=0.2 if with_norm else None)
+    xin = oracle.instance_norm(x, leaky=0.2) if with_norm else x
+    wgt, bias = _nchw(conv.weight), _nchw(conv.bias)
+    ref = oracle.conv2d_replicate(xin, wgt, bias) if mode == "replicate" else oracle.conv2d(xin, wgt, bias)
+    assert tuple(y.shape) == ref.shape
+    assert_close(y, ref, tol=1e-5, what=f"conv3x3_c16 {mode} norm={with_norm}")
+    if with_norm:
+        m = x.astype(np.float64).mean(axis=(2, 3))
+        assert_close(stats[:, 0], m, tol=1e-5, what="instance_norm_stats mean")
+
+
 def test_batchnorm_fold_matches_unfolded_oracle():
     rng = np.random.default_rng(12)
     x = rng.standard_normal((1, 64, 12, 20), dtype=np.float32)
