@@ -209,6 +209,9 @@ int sr_upsample2x_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_
                            int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C,
                            void* stream);
 
+/* out[i] = exp(in[i]) over n contiguous floats: depth_pred = exp(log_depth_pred) (reference depth_model.py:392-400). */
+int sr_exp_fwd(const float* in, float* out, int64_t n, void* stream);
+
 /* ------------------------------------------------------ matching-feature encoder -------
  *
  * ResnetMatchingEncoder (reference modules/networks.py:149-205): antialiased ResNet-18 stem + layer1, then

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sr_conv3x3_wino_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _p]),
     "sr_conv_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "sr_upsample2x_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "sr_exp_fwd": (_i, [_p, _p, _i64, _p]),
     "sr_stem_packed_weight_floats": (_sz, [_i]),
     "sr_stem_pack_weights": (_i, [_p, _i, _p, _p]),
     "sr_stem7x7_fwd": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _f, _p, _i64, _i, _i, _i, _i, _i, _p]),

@@ -409,7 +409,22 @@ __global__ void sr_upsample2x_kernel(const float* __restrict__ in, int64_t in_sb
   }
 }
 
+// depth = exp(log_depth) (reference depth_model.py:392-400), elementwise
+__global__ __launch_bounds__(256) void sr_exp_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = expf(in[i]);
+}
+
 // ------------------------------------------------------------------ C ABI -------------
+
+extern "C" int sr_exp_fwd(const float* in, float* out, int64_t n, void* stream_) {
+  if (n < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (n == 0) return SR_OK;
+  if (!in || !out) return SR_ERR_INVALID_ARGUMENT;
+  const int64_t blocks = (n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048;
+  hipLaunchKernelGGL(sr_exp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, in, out, n);
+  return sr_hip_rc(hipGetLastError());
+}
 
 extern "C" size_t sr_conv_packed_weight_floats(int Cout, int Cin, int ksize) {
   if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;

@@ -18,6 +18,7 @@ from torch import nn
 
 from .cost_volume import CostVolumeManager, FeatureVolumeManager
 from .layers import TensorFormatter
+from . import ops
 from .networks import CVEncoder, DepthDecoderPP, ResnetMatchingEncoder
 
 
@@ -216,7 +217,7 @@ class DepthModel(nn.Module):
             if flip:
                 log_depth = torch.flip(log_depth, (-1,))
             depth_outputs[k] = log_depth
-            depth_outputs[k.replace("log_", "")] = torch.exp(log_depth)
+            depth_outputs[k.replace("log_", "")] = ops.exp(log_depth)
         depth_outputs["lowest_cost_bhw"] = lowest_cost
         depth_outputs["overall_mask_bhw"] = overall_mask_bhw
         return depth_outputs

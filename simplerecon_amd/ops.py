@@ -270,6 +270,18 @@ def upsample2x(x, out=None):
     return out
 
 
+def exp(x):
+    """Elementwise exp on a dense fp32 device tensor (any memory format; the result has the same strides)."""
+    _lib.require_device_f32("exp input", x)
+    if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
+        x = x.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().sr_exp_fwd(_lib.ptr(x), _lib.ptr(out), x.numel(), _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_exp_fwd")
+    return out
+
+
 def copy_into(dst_view, src):
     """Copies a [B,C,H,W] tensor (any layout) into a channels-last slice (device-side strided copy)."""
     _lib.require_device_f32("copy source", src)
