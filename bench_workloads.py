@@ -113,7 +113,7 @@ class DotCfg2:
         nbytes = self.algorithmic_bytes()
         achieved = nbytes / t / 1e9
         N = h * w
-        return {"kernel": "sr_dot_volume_kernel<16>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        return {"kernel": "sr_dot_volume_kernel16q", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(self.name),
                 "avg_launch_us": t * 1e6, "algorithmic_bytes_per_launch": nbytes,
                 "onchip_gather_GBps": B * D * K * N * 4 * Cc * 4 / t / 1e9}

@@ -19,7 +19,7 @@ def main(tag_round):
     out, lines = {}, []
     for wl, kern, fp, wp in (
             ("hero_cfg3", "sr_wino_kernel<2, true, true>", "pmc_fetch/hero_counter_collection.csv", "pmc_write/hero_counter_collection.csv"),
-            ("dot_cfg2", "sr_dot_volume_kernel<16>", "pmc_fetch_dot/dot_counter_collection.csv", "pmc_write_dot/dot_counter_collection.csv")):
+            ("dot_cfg2", "sr_dot_volume_kernel16q", "pmc_fetch_dot/dot_counter_collection.csv", "pmc_write_dot/dot_counter_collection.csv")):
         f = agg(os.path.join(R, "gpurun_out", fp), "FETCH_SIZE")
         w = agg(os.path.join(R, "gpurun_out", wp), "WRITE_SIZE")
         lines.append(f"## {wl}\n\n| kernel | launches | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM-side bytes/launch (2F+W)*1024 |\n|---|---|---|---|---|")

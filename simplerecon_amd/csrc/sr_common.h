@@ -93,5 +93,7 @@ static inline float* sr_ws_src_nhwc(void* workspace, int B, int K) {
 // internal launchers shared between translation units
 int sr_launch_geom(const float* K_src, const float* T_src_cur, const float* T_cur_src, float* geom,
                    int n, hipStream_t stream);
+int sr_launch_argmax_planes(const float* cv, int64_t sb, int64_t sd, int64_t sp, SrPlanes planes, int B, int h, int w,
+                            int D, float* lowest, hipStream_t stream);
 int sr_launch_pack_nhwc(const float* src_nchw, float* dst_nhwc, int images, int C, int npix,
                         hipStream_t stream);

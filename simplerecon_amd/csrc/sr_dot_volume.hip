@@ -8,6 +8,8 @@
 // neighbouring texels); the reference feature vector stays in VGPRs over all planes; the
 // over-views reduction and the running argmax stay in registers; planes are split over the
 // waves of a workgroup (more bytes in flight for the L1/TA-bound gather) and merged in LDS.
+#include <stdlib.h>
+
 #include "sr_common.h"
 
 // ------------------------------------------------------------------------ prologue ----
@@ -117,8 +119,10 @@ template <int C>
 __global__ __launch_bounds__(1024) void sr_dot_volume_kernel(SrDotParams p) {
   extern __shared__ float smem[];  // [S][64] best cost, [S][64] best depth, [S][64] valid flag
   const int lane = threadIdx.x & 63;
-  const int grp = threadIdx.x >> 6;
-  const int S = blockDim.x >> 6;
+  // plane groups: waves of one workgroup (LDS argmax merge below), or -- when there are too few pixel tiles to
+  // balance 256 CUs -- separate single-wave workgroups along grid z (lowest cost then comes from sr_argmax_planes)
+  const int grp = gridDim.z > 1 ? (int)blockIdx.z : (int)(threadIdx.x >> 6);
+  const int S = gridDim.z > 1 ? (int)gridDim.z : (int)(blockDim.x >> 6);
   const int b = blockIdx.y;
   const int N = p.h * p.w;
   // XCD-aware tile order: workgroup id % 8 selects the XCD (observed dispatch order; speed only, never
@@ -191,7 +195,148 @@ __global__ __launch_bounds__(1024) void sr_dot_volume_kernel(SrDotParams p) {
   }
 
   if (p.out.lowest) {
-    if (S == 1) {
+    if (gridDim.z > 1) {
+      // merged by the caller (separate launch)
+    } else if (S == 1) {
+      if (active) p.out.lowest[(size_t)b * N + pix] = best_d;
+    } else {
+      float* s_best = smem;
+      float* s_d = smem + S * 64;
+      float* s_have = smem + 2 * S * 64;
+      s_best[grp * 64 + lane] = best;
+      s_d[grp * 64 + lane] = best_d;
+      s_have[grp * 64 + lane] = have ? 1.0f : 0.0f;
+      __syncthreads();
+      if (grp == 0 && active) {
+        float bb = best, bd = best_d;  // group 0 always owns plane 0
+        for (int g = 1; g < S; ++g)
+          if (s_have[g * 64 + lane] != 0.0f && s_best[g * 64 + lane] > bb) {
+            bb = s_best[g * 64 + lane];
+            bd = s_d[g * 64 + lane];
+          }
+        p.out.lowest[(size_t)b * N + pix] = bd;
+      }
+    }
+  }
+}
+
+// 16-channel variant (what SimpleRecon uses) with texel-coalesced taps.  In the generic kernel a lane owns a pixel and
+// pulls its four 64-byte texels with 16 float4 loads, so one load instruction touches 64 different texel records
+// (32+ cache lines for 1 KB of data): the L1 tag rate, not its bandwidth, bounds the sweep.  Here the projection is
+// still computed with lane = pixel (bit-identical geometry), but the taps are fetched in 4 rounds of 16 pixels with
+// lane = (pixel, channel quad): the 4 lanes of a pixel read the 64 contiguous bytes of a texel (one float4 each), each
+// forms its 4-channel partial dot, and two DPP quad exchanges finish the reduction.  Sample parameters travel from the
+// owning lane with ds_bpermute; per-round reference features are loaded once per tile.
+__device__ __forceinline__ float sr_quad_sum(float v) {
+  // sum over the 4 lanes of a quad: quad_perm [1,0,3,2] then [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void sr_dot_volume_kernel16q(SrDotParams p) {
+  constexpr int C = 16;
+  extern __shared__ float smem[];  // [S][64] best cost, [S][64] best depth, [S][64] valid flag
+  const int lane = threadIdx.x & 63;
+  // plane groups: waves of one workgroup (LDS argmax merge below), or -- when there are too few pixel tiles to
+  // balance 256 CUs -- separate single-wave workgroups along grid z (lowest cost then comes from sr_argmax_planes)
+  const int grp = gridDim.z > 1 ? (int)blockIdx.z : (int)(threadIdx.x >> 6);
+  const int S = gridDim.z > 1 ? (int)gridDim.z : (int)(blockDim.x >> 6);
+  const int b = blockIdx.y;
+  const int N = p.h * p.w;
+  int tile = blockIdx.x;  // XCD-aware tile order, see sr_dot_volume_kernel
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int pix = tile * 64 + lane;
+  const bool active = pix < N;
+  const int pc = active ? pix : N - 1;
+  const int y = pc / p.w, x = pc - y * p.w;
+  const int per = (p.D + S - 1) / S;
+  const int j0 = grp * per, j1 = min(p.D, j0 + per);
+
+  // reference features of the pixel this lane serves in round r (pixel 16r + lane/4), channels 4*(lane%4)..+3
+  const int quad = lane & 3, slot = lane >> 2;
+  float4 curq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pr = min(tile * 64 + 16 * r + slot, N - 1);
+    const float* cp = p.cur + ((size_t)b * C + 4 * quad) * N + pr;
+    curq[r] = make_float4(cp[0], cp[(size_t)N], cp[2 * (size_t)N], cp[3 * (size_t)N]);
+  }
+
+  float r0, r1, r2;
+  {
+#pragma clang fp contract(off)
+    const float* iK = p.invK + 16 * (size_t)b;
+    const float px = (float)x + 0.5f, py = (float)y + 0.5f;  // geometry_utils.py:34-44
+    r0 = iK[0] * px + iK[1] * py + iK[2];
+    r1 = iK[4] * px + iK[5] * py + iK[6];
+    r2 = iK[8] * px + iK[9] * py + iK[10];
+  }
+  const float* geom_b = p.geom + (size_t)b * p.K * SR_GEOM_STRIDE;
+  const float* src_b = p.src_nhwc + (size_t)b * p.K * N * C;
+  const float* planes = p.planes.ptr + b * p.planes.sb + y * p.planes.sy + x * p.planes.sx;
+  float* out = p.out.cv + b * p.out.sb + (int64_t)pc * p.out.sp;
+  const int gather_lane = 4 * (lane & 15);  // where this lane's own pixel sits inside its round
+
+  float best = 0.0f, best_d = 0.0f;
+  bool have = false;
+  for (int j = j0; j < j1; ++j) {
+    const float d = planes[j * p.planes.sd];
+    float X0, X1, X2;
+    {
+#pragma clang fp contract(off)
+      X0 = d * r0; X1 = d * r1; X2 = d * r2;  // geometry_utils.py:56-57
+    }
+    float costr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    bool any_depth = false, any_bounds = false;
+#pragma unroll 1
+    for (int k = 0; k < p.K; ++k) {
+      SrSample s;
+      sr_project_sample(geom_b + k * SR_GEOM_STRIDE, X0, X1, X2, p.h, p.w, p.inv_w, p.inv_h, s);
+      const bool front = s.zp > 0.0f;  // cost_volume.py:231-232: the mask multiplies the view's dot product
+      any_depth |= front;
+      any_bounds |= sr_in_bounds(s, p.h, p.w);
+      const float w_nw = front ? s.w_nw : 0.0f, w_ne = front ? s.w_ne : 0.0f;
+      const float w_sw = front ? s.w_sw : 0.0f, w_se = front ? s.w_se : 0.0f;
+      const float* img = src_b + (size_t)k * N * C + 4 * quad;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int sl = 16 * r + slot;
+        const int o_nw = __shfl(s.o_nw, sl), o_ne = __shfl(s.o_ne, sl), o_sw = __shfl(s.o_sw, sl), o_se = __shfl(s.o_se, sl);
+        const float a_nw = __shfl(w_nw, sl), a_ne = __shfl(w_ne, sl), a_sw = __shfl(w_sw, sl), a_se = __shfl(w_se, sl);
+        const float4 t_nw = *reinterpret_cast<const float4*>(img + (size_t)o_nw * C);
+        const float4 t_ne = *reinterpret_cast<const float4*>(img + (size_t)o_ne * C);
+        const float4 t_sw = *reinterpret_cast<const float4*>(img + (size_t)o_sw * C);
+        const float4 t_se = *reinterpret_cast<const float4*>(img + (size_t)o_se * C);
+        const float4 c = curq[r];
+        const float d_nw = fmaf(t_nw.w, c.w, fmaf(t_nw.z, c.z, fmaf(t_nw.y, c.y, t_nw.x * c.x)));
+        const float d_ne = fmaf(t_ne.w, c.w, fmaf(t_ne.z, c.z, fmaf(t_ne.y, c.y, t_ne.x * c.x)));
+        const float d_sw = fmaf(t_sw.w, c.w, fmaf(t_sw.z, c.z, fmaf(t_sw.y, c.y, t_sw.x * c.x)));
+        const float d_se = fmaf(t_se.w, c.w, fmaf(t_se.z, c.z, fmaf(t_se.y, c.y, t_se.x * c.x)));
+        // sum_c (sum_taps w_t * tap_c) * cur_c == sum_taps w_t * (tap . cur)   (cost_volume.py:322-326)
+        costr[r] += fmaf(a_se, d_se, fmaf(a_sw, d_sw, fmaf(a_ne, d_ne, a_nw * d_nw)));
+      }
+    }
+    // quad partial sums -> per-pixel cost, back to lane = pixel
+    float cost = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = __shfl(sr_quad_sum(costr[r]), gather_lane);
+      cost = (lane >> 4) == r ? v : cost;
+    }
+    if (active) out[j * p.out.sd] = cost;
+    if (!have || cost > best) { best = cost; best_d = d; have = true; }  // first max wins
+    if (j == p.D - 1 && p.out.mask && active)
+      p.out.mask[(size_t)b * N + pix] = (uint8_t)(any_depth && any_bounds);
+  }
+
+  if (p.out.lowest) {
+    if (gridDim.z > 1) {
+      // merged by the caller (separate launch)
+    } else if (S == 1) {
       if (active) p.out.lowest[(size_t)b * N + pix] = best_d;
     } else {
       float* s_best = smem;
@@ -271,18 +416,30 @@ extern "C" int sr_dot_volume_sweep(const float* cur, const float* invK_cur, cons
   p.inv_h = (float)(1.0 / (double)h);
 
   const int S = sr_pick_plane_split(B, N, D);
-  dim3 grid((N + 63) / 64, B), block(64 * S);
-  const size_t lds = (size_t)3 * S * 64 * sizeof(float);
+  // With few pixel tiles (batch 1: 300 workgroups of 16 waves on 256 CUs) whole-workgroup granularity leaves CUs
+  // idle: spread the plane groups over grid z as single-wave workgroups and take the lowest cost in a second launch.
+  const bool spread = S > 1 && (long)B * ((N + 63) / 64) < 4L * 256;
+  dim3 grid((N + 63) / 64, B, spread ? S : 1), block(spread ? 64 : 64 * S);
+  const size_t lds = spread ? 0 : (size_t)3 * S * 64 * sizeof(float);
   switch (C) {
     case 4: hipLaunchKernelGGL(sr_dot_volume_kernel<4>, grid, block, lds, stream, p); break;
     case 8: hipLaunchKernelGGL(sr_dot_volume_kernel<8>, grid, block, lds, stream, p); break;
     case 12: hipLaunchKernelGGL(sr_dot_volume_kernel<12>, grid, block, lds, stream, p); break;
-    case 16: hipLaunchKernelGGL(sr_dot_volume_kernel<16>, grid, block, lds, stream, p); break;
+    case 16: {
+      static int quad = -1;  // SR_DOT_QUAD=0 selects the generic lane-per-pixel kernel (ablation)
+      if (quad < 0) { const char* e = getenv("SR_DOT_QUAD"); quad = e ? atoi(e) : 1; }
+      if (quad) hipLaunchKernelGGL(sr_dot_volume_kernel16q, grid, block, lds, stream, p);
+      else hipLaunchKernelGGL(sr_dot_volume_kernel<16>, grid, block, lds, stream, p);
+      break;
+    }
     case 24: hipLaunchKernelGGL(sr_dot_volume_kernel<24>, grid, block, lds, stream, p); break;
     case 32: hipLaunchKernelGGL(sr_dot_volume_kernel<32>, grid, block, lds, stream, p); break;
     default: return SR_ERR_UNSUPPORTED;
   }
-  return sr_hip_rc(hipGetLastError());
+  int rc = sr_hip_rc(hipGetLastError());
+  if (rc == SR_OK && spread && out_lowest)
+    rc = sr_launch_argmax_planes(out_cv, cv_sb, cv_sd, cv_sp, p.planes, B, h, w, D, out_lowest, stream);
+  return rc;
 }
 
 extern "C" int sr_dot_volume_fwd(const float* cur, const float* src, const float* K_src,

@@ -541,12 +541,15 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
 #undef SR_MLP_LAUNCH
   int rc = sr_hip_rc(hipGetLastError());
   if (rc) return rc;
-  if (out_lowest) {
-    hipLaunchKernelGGL(sr_argmax_planes_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, out_cv, cv_sb,
-                       cv_sd, cv_sp, p.planes, h, w, D, out_lowest);
-    rc = sr_hip_rc(hipGetLastError());
-  }
+  if (out_lowest) rc = sr_launch_argmax_planes(out_cv, cv_sb, cv_sd, cv_sp, p.planes, B, h, w, D, out_lowest, stream);
   return rc;
+}
+
+int sr_launch_argmax_planes(const float* cv, int64_t sb, int64_t sd, int64_t sp, SrPlanes planes, int B, int h, int w,
+                            int D, float* lowest, hipStream_t stream) {
+  hipLaunchKernelGGL(sr_argmax_planes_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, stream, cv, sb, sd, sp,
+                     planes, h, w, D, lowest);
+  return sr_hip_rc(hipGetLastError());
 }
 
 extern "C" int sr_mlp_pack_weights(const float* W1, const float* b1, const float* W2, const float* b2,
