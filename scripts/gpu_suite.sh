@@ -1,5 +1,6 @@
 #!/bin/bash
-# full GPU suite + headline bench + kernel-trace profile + PMC traffic pass
+# full GPU suite + headline benches + kernel-trace profiles + PMC passes (HBM traffic, MFMA utilisation);
+# afterwards, in the build container: python scripts/pmc_traffic.py r01; python scripts/pmc_mfma.py r01; copy bench_*.json / *_kernel_stats.csv to profiles/
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; export TMPDIR=/tmp; O=$R/gpurun_out; mkdir -p $O
 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
@@ -14,4 +15,5 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o he
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o hero -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_dot -o dot -- python $R/bench.py --workload dot_cfg2 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch_dot.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_dot -o dot -- python $R/bench.py --workload dot_cfg2 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write_dot.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma -o hero -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_mfma.log 2>&1
 cd $R; tail -2 $O/smoke.log; tail -3 $O/pytest_gpu.log; cat $O/bench_hero_cfg3.json; ls $O/pmc_fetch $O/pmc_write | head
