@@ -457,8 +457,17 @@ __global__ void sr_argmax_planes_kernel(const float* __restrict__ cv, int64_t sb
   const float* c = cv + b * sb + (int64_t)pix * sp;
   float best = c[0];
   int bj = 0;
-  for (int j = 1; j < D; ++j) {
-    const float v = c[j * sd];
+  int j = 1;
+  for (; j + 8 <= D; j += 8) {  // 8 loads in flight per thread (the launch has few threads: latency-bound otherwise)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = c[(int64_t)(j + u) * sd];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (v[u] > best) { best = v[u]; bj = j + u; }
+  }
+  for (; j < D; ++j) {
+    const float v = c[(int64_t)j * sd];
     if (v > best) { best = v; bj = j; }
   }
   lowest[(size_t)b * N + pix] = planes.ptr[b * planes.sb + bj * planes.sd + y * planes.sy + x * planes.sx];
@@ -547,7 +556,7 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
 
 int sr_launch_argmax_planes(const float* cv, int64_t sb, int64_t sd, int64_t sp, SrPlanes planes, int B, int h, int w,
                             int D, float* lowest, hipStream_t stream) {
-  hipLaunchKernelGGL(sr_argmax_planes_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, stream, cv, sb, sd, sp,
+  hipLaunchKernelGGL(sr_argmax_planes_kernel, dim3((h * w + 63) / 64, B), dim3(64), 0, stream, cv, sb, sd, sp,
                      planes, h, w, D, lowest);
   return sr_hip_rc(hipGetLastError());
 }
