@@ -6,16 +6,20 @@
 // the transforms use only +, - and exact scalings by 1/2, and the fp32 error vs an fp64 reference is the
 // same as the direct algorithm's (3.1e-7 vs 2.7e-7 on a 64-channel layer, tests/).
 //
-// A workgroup (4 waves) owns a region of 4 x 8 Winograd tiles (= 8 x 16 output pixels = the 32 rows of one MFMA
-// M-tile) x 32*NT output channels.  Per 16-channel slab of the input:
-//   S  the 10 x 18 pixel input patch is staged once into LDS (register-staged, next slab's loads in flight),
-//   T  all 256 threads apply B^T d B to their (tile, 4-channel group, row pair) -> V[16][32 tiles][16 ch] in LDS,
+// A workgroup (4 waves, 2 workgroups per CU) owns a region of 4 x 8 Winograd tiles (= 8 x 16 output pixels = the 32
+// rows of one MFMA M-tile) x 32*NT output channels.  Per 16-channel slab of the input:
+//   S  the 10 x 18 pixel input patch is staged global -> registers -> LDS, double-buffered: slab c+1 is fetched at the
+//      top of slab c and stored at its end; with an even slab count the NEXT region's first slab follows the same way
+//      (it lands behind the V/O area, which the epilogue leaves alone),
+//   T  wave w applies B^T d B for frequency row ur = w -- exactly the rows it multiplies -- to all 32 tiles x 16
+//      channels -> its private quarter of V[16][32 tiles][16 ch]; no barrier between T and M, one per slab overall,
 //   M  wave w multiplies the 4 "frequencies" xi = 4w..4w+3:  M_xi[tile, co] += V_xi[tile, ci] . U_xi[ci, co]
 //      (A fragments: conflict-free ds_read_b128 on 20-float rows; U streams from L2 in B-fragment order,
-//      prefetched 3 steps ahead).
-// Epilogue: the 16 x 32 x 32 accumulator slab goes through LDS once, each thread applies A^T M A for its
-// (tile, channel) pairs, adds bias / residual, applies LeakyReLU and writes 2 x 2 pixels (32 channels per 128-byte
-// line) straight into the consumer's concat slice.
+//      prefetched 3 steps ahead through 4 rotating register sets).
+// Epilogue: the output transform is separable -- wave w holds a whole frequency row, so the column half (M A) happens
+// in registers and 2 of 4 values per (tile, channel) cross LDS (one 64-KB pass); a thread then owns (tile, 4 channels)
+// units: float4 residual loads, bias, LeakyReLU, float4 stores straight into the consumer's concat slice.
+// The live set (128 accumulator + 32 weight + 12 staging registers ...) fits 256 VGPRs without scratch spills.
 #include <stdio.h>
 #include <stdlib.h>
 
