@@ -194,6 +194,20 @@ int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pi
                              int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
                              int Cout, float leaky_slope, void* stream);
 
+/* Split-K variant for layers with few output regions and a long chain of input slabs (deep low-resolution levels,
+ * batch 1): work items cover Cin / ks input channels each and store raw partial outputs to `workspace`
+ * ([ks][B, H*W, Cout] floats, 16-byte aligned); a second kernel adds them in index order (deterministic) and applies
+ * bias + residual + LeakyReLU.  sr_wino_splitk_factor() = ks the launch plan picks for a shape (1: no split, no
+ * workspace needed); with a NULL / too small workspace the call runs unsplit. */
+int sr_wino_splitk_factor(int B, int H, int W, int Cin, int Cout);
+size_t sr_wino_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int sr_conv3x3_wino_splitk_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                    const float* packed_u, const float* bias, const float* residual,
+                                    int64_t res_batch_stride, int res_pix_stride, float* out,
+                                    int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                                    int Cout, float leaky_slope, void* workspace, size_t workspace_bytes,
+                                    void* stream);
+
 /* Name of the kernel instantiation sr_conv3x3_wino_nhwc_fwd launches for these arguments (the output-channel block
  * is chosen per launch); aligned_in / aligned_out = input / output+residual+bias rows are 16-byte aligned with
  * channel counts that are multiples of 4.  For profilers. */

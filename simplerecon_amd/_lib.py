@@ -45,6 +45,10 @@ SIGNATURES = {
     "sr_wino_packed_weight_floats": (_sz, [_i, _i]),
     "sr_wino_pack_weights": (_i, [_p, _i, _i, _p, _p]),
     "sr_conv_prefers_wino": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "sr_wino_splitk_factor": (_i, [_i, _i, _i, _i, _i]),
+    "sr_wino_splitk_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sr_conv3x3_wino_splitk_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f,
+                                             _p, _sz, _p]),
     "sr_wino_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_conv3x3_wino_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _p]),
     "sr_conv_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),

@@ -62,6 +62,9 @@ struct SrWinoParams {
   float slope;
   int vec4;
   int debug;  // ablation bits (env SR_WINO_DEBUG), 0 in production
+  // split-K: a work item covers 1/ksplit of the input slabs and stores its raw partial output (no bias / residual /
+  // activation) to part + ks * part_stride (dense channels-last [B, H*W, Cout]); sr_wino_reduce_kernel finishes.
+  int ksplit; float* part; int64_t part_stride;
 #ifdef SR_WINO_TRACE
   unsigned long long* trace;  // [blocks][SR_TR_REGIONS][SR_TR_EVENTS] shader-clock stamps (debug builds only)
 #endif
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, kk = lane >> 5;
-  const int chunks = p.G >> 1;
+  const int chunks = (p.G >> 1) / p.ksplit;  // input slabs per work item
   const int64_t rec = (int64_t)2 * p.Co_pad;
   constexpr int STEPS = 8;            // (frequency, 8-channel group) steps per slab and wave
   static_assert(8 % SR_WINO_NB == 0 && SR_WINO_PD < SR_WINO_NB, "the register rotation must line up across slabs");
@@ -145,9 +148,10 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
   }
 #endif
   // Region coordinates of a work item and the per-thread staging offsets of its 10x18 input patch.
-  struct Region { int b, oy0, ox0, co0; };
+  struct Region { int b, oy0, ox0, co0, ks; };
   auto decode = [&](int wk) {
     Region r;
+    r.ks = wk % p.ksplit; wk /= p.ksplit;
     const int cb = wk % p.co_blocks; wk /= p.co_blocks;
     const int rx = wk % p.regions_x; wk /= p.regions_x;
     const int ry = wk % p.regions_y;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
   bool staged = false;
   for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
     const Region reg = decode(work);
-    const int b = reg.b, oy0 = reg.oy0, ox0 = reg.ox0, co0 = reg.co0;
+    const int b = reg.b, oy0 = reg.oy0, ox0 = reg.ox0, co0 = reg.co0, sl0 = reg.ks * chunks;
     wu4 = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + co0 + i);
     const bool has_next = chain && (work + (int)gridDim.x < p.total);
 #ifdef SR_WINO_TRACE
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     SR_TR(0);
     if (!staged) {
       aim(reg);
-      stage_load(0, stg);
+      stage_load(sl0 * 16, stg);
       stage_store(stg, rawB);
       __syncthreads();
     }
@@ -239,15 +243,16 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 
     float4 b_f[NB][NT], a_f[2];
 #pragma unroll
-    for (int s = 0; s < PD; ++s) load_b(0, s, b_f[s]);
+    for (int s = 0; s < PD; ++s) load_b(sl0, s, b_f[s]);
     SR_TR(1);
 
     for (int ch = 0; ch < chunks; ++ch) {
       const bool more = ch + 1 < chunks;
-      if (more) stage_load((ch + 1) * 16, stg);
+      if (more) stage_load((sl0 + ch + 1) * 16, stg);
       else if (has_next) {
-        aim(decode(work + gridDim.x));
-        stage_load(0, stg);
+        const Region nxt = decode(work + gridDim.x);
+        aim(nxt);
+        stage_load(nxt.ks * chunks * 16, stg);
       }
 
       // ---- T: this wave's row of V = B^T d B, all 32 tiles x 16 channels ----
@@ -279,8 +284,8 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const int cbuf = s % NB, ca = s & 1;
-        if (s + PD < STEPS) load_b(ch, s + PD, b_f[(s + PD) % NB]);
-        else if (more) load_b(ch + 1, s + PD - STEPS, b_f[(s + PD) % NB]);
+        if (s + PD < STEPS) load_b(sl0 + ch, s + PD, b_f[(s + PD) % NB]);
+        else if (more) load_b(sl0 + ch + 1, s + PD - STEPS, b_f[(s + PD) % NB]);
         if (s + 1 < STEPS) {
           const int xi = 4 * wave + ((s + 1) >> 1), g = (s + 1) & 1;
           a_f[ca ^ 1] = *reinterpret_cast<const float4*>(&V[(xi * 32 + i) * WN_ROW + 8 * g + 4 * kk]);
@@ -308,8 +313,13 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     SR_TR(12);
 
     // ---- epilogue: Y = A^T M A, + bias + residual, LeakyReLU, store ----
-    const float* __restrict__ resp = p.res ? p.res + (int64_t)b * p.res_sb : nullptr;
-    float* __restrict__ outp = p.out + (int64_t)b * p.out_sb;
+    const bool partial = p.ksplit > 1;
+    const float* __restrict__ resp = (p.res && !partial) ? p.res + (int64_t)b * p.res_sb : nullptr;
+    float* __restrict__ outp = partial ? p.part + reg.ks * p.part_stride + (int64_t)b * p.H * p.W * p.Cout
+                                       : p.out + (int64_t)b * p.out_sb;
+    const unsigned out_sp = partial ? (unsigned)p.Cout : (unsigned)p.out_sp;
+    const float* bias_p = partial ? nullptr : p.bias;
+    const float slope = partial ? -1.0f : p.slope;
     // Y = A^T M A is separable: wave w holds the whole frequency ROW ur = w (its 4 accumulators are the columns
     // uc = 0..3), so the column half (M A) is done in registers and only 2 of 4 values per (tile, channel) go
     // through LDS: O[ur][b][tile][co] (64 KB for both N-tiles -> one pass, two barriers).
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         __syncthreads();
         SR_TR(13);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && okc) bv = *reinterpret_cast<const float4*>(p.bias + cog);
+        if (bias_p && okc) bv = *reinterpret_cast<const float4*>(bias_p + cog);
 #pragma unroll
         for (int it = 0; it < UNITS; ++it) {
           const int tile = tid / CG + (256 / CG) * it;
@@ -370,14 +380,14 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float4 v = f4add(f4add(y[q], bv), rv[it][q]);
-            if (p.slope >= 0.0f) {
-              v.x = fmaxf(v.x, 0.0f) + p.slope * fminf(v.x, 0.0f);
-              v.y = fmaxf(v.y, 0.0f) + p.slope * fminf(v.y, 0.0f);
-              v.z = fmaxf(v.z, 0.0f) + p.slope * fminf(v.z, 0.0f);
-              v.w = fmaxf(v.w, 0.0f) + p.slope * fminf(v.w, 0.0f);
+            if (slope >= 0.0f) {
+              v.x = fmaxf(v.x, 0.0f) + slope * fminf(v.x, 0.0f);
+              v.y = fmaxf(v.y, 0.0f) + slope * fminf(v.y, 0.0f);
+              v.z = fmaxf(v.z, 0.0f) + slope * fminf(v.z, 0.0f);
+              v.w = fmaxf(v.w, 0.0f) + slope * fminf(v.w, 0.0f);
             }
             if (ok[it][q] && (!(p.debug & 1) || v.x == 1.2345e33f))
-              *reinterpret_cast<float4*>(outp + (opix[it][q] * (unsigned)p.out_sp + cog)) = v;
+              *reinterpret_cast<float4*>(outp + (opix[it][q] * out_sp + cog)) = v;
           }
         }
 #ifdef SR_WINO_TRACE
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
           }
         __syncthreads();
         // (3) row transform, + bias + residual, LeakyReLU, store
-        const float bv = (p.bias && okc) ? p.bias[cog] : 0.0f;
+        const float bv = (bias_p && okc) ? bias_p[cog] : 0.0f;
 #pragma unroll
         for (int it = 0; it < UNITS; ++it) {
           const int tile = tid / CO + (256 / CO) * it;
@@ -434,13 +444,39 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float v = y[q] + bv + rv[it][q];
-            if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
-            if (ok[it][q] && (!(p.debug & 1) || v == 1.2345e33f)) outp[opix[it][q] * (unsigned)p.out_sp + cog] = v;
+            if (slope >= 0.0f) v = fmaxf(v, 0.0f) + slope * fminf(v, 0.0f);
+            if (ok[it][q] && (!(p.debug & 1) || v == 1.2345e33f)) outp[opix[it][q] * out_sp + cog] = v;
           }
         }
         __syncthreads();
       }
     }
+  }
+}
+
+// split-K finish: out = act(sum_ks partial[ks] + bias + residual), partials added in index order (deterministic)
+__global__ __launch_bounds__(256) void sr_wino_reduce_kernel(const float* __restrict__ part, int ksplit,
+                                                             int64_t part_stride, const float* __restrict__ bias,
+                                                             const float* __restrict__ res, int64_t res_sb, int res_sp,
+                                                             float* __restrict__ out, int64_t out_sb, int out_sp,
+                                                             int HW, int C4, float slope) {
+  const int b = blockIdx.y;
+  const int64_t total = (int64_t)HW * C4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    const int64_t px = idx / C4;
+    const float* q = part + ((int64_t)b * HW + px) * (4 * C4) + 4 * c4;
+    float4 v = *reinterpret_cast<const float4*>(q);
+    for (int k = 1; k < ksplit; ++k) v = f4add(v, *reinterpret_cast<const float4*>(q + k * part_stride));
+    if (bias) v = f4add(v, *reinterpret_cast<const float4*>(bias + 4 * c4));
+    if (res) v = f4add(v, *reinterpret_cast<const float4*>(res + (int64_t)b * res_sb + px * res_sp + 4 * c4));
+    if (slope >= 0.0f) {
+      v.x = fmaxf(v.x, 0.0f) + slope * fminf(v.x, 0.0f);
+      v.y = fmaxf(v.y, 0.0f) + slope * fminf(v.y, 0.0f);
+      v.z = fmaxf(v.z, 0.0f) + slope * fminf(v.z, 0.0f);
+      v.w = fmaxf(v.w, 0.0f) + slope * fminf(v.w, 0.0f);
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)b * out_sb + px * out_sp + 4 * c4) = v;
   }
 }
 
@@ -488,26 +524,50 @@ extern "C" int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int 
   return (util >= 0.4 && Cin >= 16) ? 1 : 0;
 }
 
-// Output channels per workgroup: 64 (NT = 2) shares one transformed input slab between two N-tiles; 32 (NT = 1) makes
-// twice as many, roughly 0.58x as long work items, which fills the chip better when there are few regions
-// (batch 1, low-resolution pyramid levels).  Launch time ~ rounds over the 2-per-CU slots x item length.
-static int sr_wino_pick_nt(int B, int H, int W, int Cout) {
+// Launch plan.  Output channels per workgroup: 64 (NT = 2) shares one transformed input slab between two N-tiles; 32
+// (NT = 1) makes twice as many, roughly 0.58x as long work items.  Split-K (ks > 1) cuts a work item's chain of input
+// slabs into ks independent items whose raw partial outputs a second kernel adds up -- for the deep low-resolution
+// layers (e.g. 384 channels at 15x20: 24 slabs in a row on a handful of workgroups).  Launch time ~
+//   max(rounds over the 2-per-CU slots x item length alone on a CU, items per CU x item length under sharing) (+ reduce),
+// item length ~ slabs + 2 (prologue / epilogue); constants fitted on r01 measurements, in units of a full NT = 2 item.
+struct SrWinoPlan { int nt, ks; };
+static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allow_split) {
   const int co_pad = ((Cout + 31) / 32) * 32;
-  if (co_pad % 64 != 0) return 1;
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("SR_WINO_NT"); forced = e ? atoi(e) : 0; }
-  if (forced == 1 || forced == 2) return forced;
+  const int slabs = (Cin + 15) / 16;
+  static int forced_nt = -1, forced_ks = -1;
+  if (forced_nt < 0) { const char* e = getenv("SR_WINO_NT"); forced_nt = e ? atoi(e) : 0; }
+  if (forced_ks < 0) { const char* e = getenv("SR_WINO_KSPLIT"); forced_ks = e ? atoi(e) : 0; }
   const long regions = (long)((H + 2 * WN_TR - 1) / (2 * WN_TR)) * ((W + 2 * WN_TC - 1) / (2 * WN_TC)) * B;
   const long cus = sr_wino_num_cus(), slots = 2 * cus;
-  const long items2 = regions * (co_pad / 64), items1 = regions * (co_pad / 32);
-  // cost = max(latency bound: rounds x item length when a workgroup has its CU to itself,
-  //            throughput bound: items per CU x item length under sharing), in units of an NT = 2 item (r01 fit)
-  auto cost = [&](long items, double t_lat, double t_thr) {
-    const double lat = (double)((items + slots - 1) / slots) * t_lat, thr = (double)items / (double)cus * t_thr;
-    return lat > thr ? lat : thr;
-  };
-  const double cost2 = cost(items2, 1.0, 0.8), cost1 = cost(items1, 0.62, 0.5);
-  return cost1 < 0.92 * cost2 ? 1 : 2;
+  SrWinoPlan best = {co_pad % 64 == 0 ? 2 : 1, 1};
+  double best_cost = -1.0;
+  for (int nt = 2; nt >= 1; --nt) {
+    if (nt == 2 && co_pad % 64 != 0) continue;
+    if ((forced_nt == 1 || forced_nt == 2) && nt != forced_nt && !(forced_nt == 2 && co_pad % 64 != 0)) continue;
+    for (int ks = 1; ks <= 8; ks *= 2) {
+      if (ks > 1 && (!allow_split || slabs % ks != 0 || slabs / ks < 4 || Cout % 4 != 0)) continue;
+      if (forced_ks > 0 && ks != forced_ks && allow_split && slabs % forced_ks == 0 && slabs / forced_ks >= 1) continue;
+      const long items = regions * (co_pad / (32 * nt)) * ks;
+      const double f = ((double)slabs / ks + 2.0) / ((double)slabs + 2.0);
+      const double t_lat = nt == 2 ? 1.0 : 0.62, t_thr = nt == 2 ? 0.8 : 0.5;
+      const double lat = (double)((items + slots - 1) / slots) * t_lat * f, thr = (double)items / (double)cus * t_thr * f;
+      double cost = lat > thr ? lat : thr;
+      if (ks > 1) cost += 2.7 / ((double)slabs + 2.0);            // the reduce launch
+      if (nt == 1 || ks > 1) cost *= 1.08;                         // deviate from the default only for a clear gain
+      if (best_cost < 0 || cost < best_cost) { best = {nt, ks}; best_cost = cost; }
+    }
+  }
+  return best;
+}
+
+extern "C" int sr_wino_splitk_factor(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 1;
+  return sr_wino_plan(B, H, W, Cin, Cout, true).ks;
+}
+
+extern "C" size_t sr_wino_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  const int ks = sr_wino_splitk_factor(B, H, W, Cin, Cout);
+  return ks > 1 ? (size_t)ks * B * H * W * Cout * sizeof(float) : 0;
 }
 
 // Symbol of the kernel instantiation sr_conv3x3_wino_nhwc_fwd launches (for profilers / bench): `aligned_in` = input
@@ -516,16 +576,15 @@ extern "C" const char* sr_wino_kernel_name(int B, int H, int W, int Cin, int Cou
   static thread_local char buf[64];
   (void)Cin;
   const int vin = aligned_in != 0, vout = vin && aligned_out;
-  snprintf(buf, sizeof(buf), "sr_wino_kernel<%d, %s, %s>", sr_wino_pick_nt(B, H, W, Cout), vin ? "true" : "false",
-           vout ? "true" : "false");
+  snprintf(buf, sizeof(buf), "sr_wino_kernel<%d, %s, %s>", sr_wino_plan(B, H, W, Cin, Cout, vout != 0).nt,
+           vin ? "true" : "false", vout ? "true" : "false");
   return buf;
 }
 
-extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
-                                        const float* packed_u, const float* bias, const float* residual,
-                                        int64_t res_batch_stride, int res_pix_stride, float* out,
-                                        int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
-                                        int Cout, float leaky_slope, void* stream_) {
+static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u,
+                       const float* bias, const float* residual, int64_t res_batch_stride, int res_pix_stride,
+                       float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin, int Cout,
+                       float leaky_slope, void* workspace, size_t workspace_bytes, void* stream_) {
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (B == 0) return SR_OK;
   if (!in || !packed_u || !out) return SR_ERR_INVALID_ARGUMENT;
@@ -539,12 +598,24 @@ extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride
   p.G = ((Cin + 15) / 16) * 2;
   p.regions_x = (W + 2 * WN_TC - 1) / (2 * WN_TC);
   p.regions_y = (H + 2 * WN_TR - 1) / (2 * WN_TR);
-  const int nt = sr_wino_pick_nt(B, H, W, Cout);
-  p.co_blocks = p.Co_pad / (32 * nt);
-  p.total = p.regions_x * p.regions_y * p.co_blocks * B;
   p.slope = leaky_slope;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_WINO_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0) && (Cin % 4 == 0);
+  // vector epilogue: whole float4 channel groups, 16-byte aligned output / residual / bias rows
+  const bool vout = p.vec4 && (Cout % 4 == 0) && (((uintptr_t)out & 15) == 0) && (out_pix_stride % 4 == 0) &&
+                    (out_batch_stride % 4 == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                    (!residual || ((((uintptr_t)residual & 15) == 0) && (res_pix_stride % 4 == 0) &&
+                                   (res_batch_stride % 4 == 0)));
+  const bool can_split = vout && workspace && (((uintptr_t)workspace & 15) == 0);
+  SrWinoPlan plan = sr_wino_plan(B, H, W, Cin, Cout, can_split);
+  if (plan.ks > 1 && workspace_bytes < (size_t)plan.ks * B * H * W * Cout * sizeof(float))
+    plan = sr_wino_plan(B, H, W, Cin, Cout, false);
+  const int nt = plan.nt;
+  p.ksplit = plan.ks;
+  p.part = (float*)workspace;
+  p.part_stride = (int64_t)B * H * W * Cout;
+  p.co_blocks = p.Co_pad / (32 * nt);
+  p.total = p.regions_x * p.regions_y * p.co_blocks * B * p.ksplit;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_WINO_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   hipStream_t stream = (hipStream_t)stream_;
   int blocks = sr_wino_num_cus() * 2;
   if (blocks > p.total) blocks = p.total;
@@ -564,11 +635,6 @@ extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride
     if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
     hipLaunchKernelGGL((sr_wino_kernel<NTV, V4, VO>), dim3(blocks), dim3(256), lds, stream, p);                   \
   }
-  // vector epilogue: whole float4 channel groups, 16-byte aligned output / residual / bias rows
-  const bool vout = p.vec4 && (Cout % 4 == 0) && (((uintptr_t)out & 15) == 0) && (out_pix_stride % 4 == 0) &&
-                    (out_batch_stride % 4 == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
-                    (!residual || ((((uintptr_t)residual & 15) == 0) && (res_pix_stride % 4 == 0) &&
-                                   (res_batch_stride % 4 == 0)));
   if (nt == 2 && vout) SR_WINO_LAUNCH(2, true, true)
   else if (nt == 2 && p.vec4) SR_WINO_LAUNCH(2, true, false)
   else if (nt == 2) SR_WINO_LAUNCH(2, false, false)
@@ -590,5 +656,34 @@ extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride
     }
   }
 #endif
-  return sr_hip_rc(hipGetLastError());
+  int rc = sr_hip_rc(hipGetLastError());
+  if (rc == SR_OK && p.ksplit > 1) {
+    const int64_t total = (int64_t)H * W * (Cout / 4);
+    const int rblocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sr_wino_reduce_kernel, dim3(rblocks, B), dim3(256), 0, stream, p.part, p.ksplit, p.part_stride,
+                       bias, residual, res_batch_stride, res_pix_stride, out, out_batch_stride, out_pix_stride, H * W,
+                       Cout / 4, leaky_slope);
+    rc = sr_hip_rc(hipGetLastError());
+  }
+  return rc;
+}
+
+extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                        const float* packed_u, const float* bias, const float* residual,
+                                        int64_t res_batch_stride, int res_pix_stride, float* out,
+                                        int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                                        int Cout, float leaky_slope, void* stream_) {
+  return sr_wino_run(in, in_batch_stride, in_pix_stride, packed_u, bias, residual, res_batch_stride, res_pix_stride, out,
+                     out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, leaky_slope, nullptr, 0, stream_);
+}
+
+extern "C" int sr_conv3x3_wino_splitk_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                               const float* packed_u, const float* bias, const float* residual,
+                                               int64_t res_batch_stride, int res_pix_stride, float* out,
+                                               int64_t out_batch_stride, int out_pix_stride, int B, int H, int W,
+                                               int Cin, int Cout, float leaky_slope, void* workspace,
+                                               size_t workspace_bytes, void* stream_) {
+  return sr_wino_run(in, in_batch_stride, in_pix_stride, packed_u, bias, residual, res_batch_stride, res_pix_stride, out,
+                     out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, leaky_slope, workspace, workspace_bytes,
+                     stream_);
 }

@@ -212,9 +212,11 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         if use_wino:
-            rc = lib.sr_conv3x3_wino_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
-                                              rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, slope,
-                                              _lib.stream_ptr(x.device))
+            nbytes = lib.sr_wino_splitk_workspace_bytes(b, h, w, ci, co)   # 0 unless the launch plan splits K
+            ws = _workspace(x.device, "wino_splitk", nbytes) if nbytes else None
+            rc = lib.sr_conv3x3_wino_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
+                                                     _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
+                                                     co, slope, _lib.ptr(ws), nbytes, _lib.stream_ptr(x.device))
         else:
             fwd = lib.sr_conv2d_replicate_nhwc_fwd if replicate else lib.sr_conv2d_nhwc_fwd
             rc = fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb, rsp, _lib.ptr(out),
@@ -296,7 +298,8 @@ _WORKSPACES = {}                            # (device, tag) -> scratch tensor (g
 
 
 def _workspace(device, tag, nbytes):
-    key = (device, tag)
+    # one scratch buffer per (device, purpose, stream): launches on a stream are ordered, different streams must not share
+    key = (device, tag, torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)

@@ -92,3 +92,23 @@ def test_conv_properties_at_full_resolution():
     sd = {k: v.cpu().numpy() for k, v in blk.state_dict().items()}
     y_o = oracle.basic_block(crop.numpy(), sd, "")
     assert_close(y[:, :, :20, :36], y_o[:, :, :20, :36], tol=1e-5, what="240x320 block crop vs oracle")
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 15, 20, 128), (2, 384, 15, 20, 64), (1, 256, 30, 40, 256)])
+def test_winograd_split_k(shape):
+    """Deep low-resolution layers run split-K (partial outputs + deterministic reduce): same result as the oracle,
+    bias / residual / LeakyReLU applied once, bit-reproducible."""
+    from simplerecon_amd import _lib
+    b, ci, h, w, co = shape
+    assert _lib.lib().sr_wino_splitk_factor(b, h, w, ci, co) > 1, "the launch plan should split this shape"
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal((b, ci, h, w), dtype=np.float32)
+    res = rng.standard_normal((b, co, h, w), dtype=np.float32)
+    conv = synthetic.seeded_fill_(torch.nn.Conv2d(ci, co, 3, padding=1), seed=5).to(DEV)
+    xt, rt = torch.from_numpy(x).to(DEV), torch.from_numpy(res).to(DEV)
+    with torch.inference_mode():
+        y = ops.conv2d(xt, conv, residual=rt, leaky=0.2)
+        y2 = ops.conv2d(xt, conv, residual=rt, leaky=0.2)
+    assert torch.equal(y, y2)
+    ref = oracle.conv2d(x, conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(), residual=res, leaky=0.2)
+    assert_close(y, ref, tol=1e-5, what=f"split-K Winograd conv {shape}")

@@ -108,6 +108,8 @@ def test_full_size_hot_path_properties():
         assert torch.isfinite(a[k]).all() and bool((a[k] > 0).all())
         assert torch.equal(a[k], b[k]), "hot path is not deterministic"
         assert torch.equal(a[k], torch.exp(a[k.replace("depth_", "log_depth_")]))
-        assert torch.equal(one[k][0], a[k][1]), "frames of a batch are not independent"
+        # the cost volume is bitwise batch-independent (tests/test_gpu_mlp_volume.py); in the conv stack the launch
+        # plan (split-K of the deep layers) depends on the batch size, hence the summation order: agreement, not identity
+        assert_close(one[k][0], a[k][1], tol=1e-5, what=f"frame 1 alone vs inside the batch, {k}")
     assert torch.equal(a["lowest_cost_bhw"], b["lowest_cost_bhw"]) and a["overall_mask_bhw"].dtype == torch.bool
     assert 0.5 < float(a["overall_mask_bhw"].float().mean()) <= 1.0
