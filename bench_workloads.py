@@ -223,7 +223,9 @@ class HeroCfg3:
         return {"workload": f"{self.name}: hot path = {enc}{kind} -> CVEncoder -> DepthDecoderPP -> exp, batch "
                             f"{self.B}/GPU, {self.K} source views, {self.D} planes, 640x480 image ({self.h}x{self.w} "
                             f"matching features x {self.Cc} ch, image-prior pyramid 24/48/64/160/256 ch), fp32, "
-                            f"random-init weights; {skipped}",
+                            f"random-init weights; {skipped}"
+                            + (" (BASELINE.json configs[2]: hero_model.yaml, batch 8)" if self.B == 8 and
+                               self.feature_volume_type == "mlp_feature_volume" else ""),
                 "frames_per_step_per_gpu": self.B, "hip_streams_per_gpu": self.streams,
                 "submission": "one HIP graph replay per step" if self.use_graph else "eager (one launch per kernel)",
                 "parallelism": f"replica x{world} (keyframes sharded)"}
