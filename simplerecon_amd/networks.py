@@ -119,11 +119,28 @@ class DepthDecoderPP(nn.Module):
                     nn.Conv2d(num_ch_out, self.num_output_channels, 1),
                 )
 
+    # The three inputs of a node (right / diagonal / up branch) are independent BasicBlocks writing disjoint channel
+    # slices of the node's concat buffer.  At small batch a single conv launch leaves CUs idle (150-600 work items for
+    # 512 slots), so for batches <= `branch_stream_max_batch` the diagonal and up branches run on two side HIP
+    # streams and join before `in_conv`.  (At batch 8 every launch fills the chip and the fork/join only costs.)
+    branch_stream_max_batch = 2
+
+    def _side_streams(self, device):
+        cache = self.__dict__.setdefault("_streams", {})
+        if device not in cache:
+            cache[device] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return cache[device]
+
     def forward(self, input_features):
         from . import ops
         prev_outputs = list(input_features)
         outputs = []
         depth_outputs = {}
+        dev = prev_outputs[0].device
+        fork = dev.type == "cuda" and prev_outputs[0].shape[0] <= self.branch_stream_max_batch
+        if fork:
+            main = torch.cuda.current_stream(dev)
+            s1, s2 = self._side_streams(dev)
         for j in range(1, 5):
             max_i = 4 - j
             for i in range(max_i, -1, -1):
@@ -133,11 +150,24 @@ class DepthDecoderPP(nn.Module):
                 x_i = prev_outputs[i]
                 n_parts = 3 if i + j != 4 else 2
                 buf = ops.empty_nhwc(x_i.shape[0], c * n_parts, x_i.shape[2], x_i.shape[3], x_i.device)
-                right(x_i, out=buf[:, :c])
-                ops.upsample2x(diag(prev_outputs[i + 1]), out=buf[:, c:2 * c])
-                if i + j != 4:
-                    up = self.convs[f"up_conv_{i + 1}{j}"]
-                    ops.upsample2x(up(outputs[-1]), out=buf[:, 2 * c:3 * c])
+                if fork:
+                    s1.wait_stream(main)
+                    with torch.cuda.stream(s1):
+                        ops.upsample2x(diag(prev_outputs[i + 1]), out=buf[:, c:2 * c])
+                    if i + j != 4:
+                        s2.wait_stream(main)
+                        with torch.cuda.stream(s2):
+                            ops.upsample2x(self.convs[f"up_conv_{i + 1}{j}"](outputs[-1]), out=buf[:, 2 * c:3 * c])
+                    right(x_i, out=buf[:, :c])
+                    main.wait_stream(s1)
+                    if i + j != 4:
+                        main.wait_stream(s2)
+                else:
+                    right(x_i, out=buf[:, :c])
+                    ops.upsample2x(diag(prev_outputs[i + 1]), out=buf[:, c:2 * c])
+                    if i + j != 4:
+                        up = self.convs[f"up_conv_{i + 1}{j}"]
+                        ops.upsample2x(up(outputs[-1]), out=buf[:, 2 * c:3 * c])
                 in_conv = self.convs[f"in_conv_{i}{j}"]
                 output = in_conv[1](in_conv[0](buf))
                 outputs.append(output)
