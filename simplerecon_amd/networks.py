@@ -84,6 +84,9 @@ class CVEncoder(nn.Module):
         return outputs
 
 
+_SIDE_STREAMS = {}  # device -> (stream, stream) for DepthDecoderPP's branch parallelism
+
+
 class DepthDecoderPP(nn.Module):
     """UNet++ depth decoder (reference networks.py:20-96).  Output heads that the reference evaluates
     and then overwrites (`output_i` is recomputed at every node j, the last one wins, networks.py:92)
@@ -125,11 +128,11 @@ class DepthDecoderPP(nn.Module):
     # streams and join before `in_conv`.  (At batch 8 every launch fills the chip and the fork/join only costs.)
     branch_stream_max_batch = 2
 
-    def _side_streams(self, device):
-        cache = self.__dict__.setdefault("_streams", {})
-        if device not in cache:
-            cache[device] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-        return cache[device]
+    @staticmethod
+    def _side_streams(device):
+        if device not in _SIDE_STREAMS:  # process-wide, so modules stay picklable / deep-copyable
+            _SIDE_STREAMS[device] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return _SIDE_STREAMS[device]
 
     def forward(self, input_features):
         from . import ops
