@@ -35,7 +35,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // input channels per LDS slab: 16 for 3x3 convs (18 k-steps per slab), 64 for 1x1 convs (8 k-steps per
 // slab instead of 2: a 1x1 slab of 16 channels is all barrier).  LDS rows carry 4 floats of padding:
 // row strides of 20 and 68 floats are both conflict-free for the 16-byte A-fragment reads.
-__host__ __device__ constexpr int sr_ck(int ks, int stride = 1) { return (ks == 1 && stride == 1) ? 64 : 16; }
+#ifndef SR_CK1
+#define SR_CK1 64   // channels per slab of the 1x1 / stride-1 instantiation
+#endif
+#ifndef SR_CONV_BLOCKS_PER_CU
+#define SR_CONV_BLOCKS_PER_CU 2
+#endif
+__host__ __device__ constexpr int sr_ck(int ks, int stride = 1) { return (ks == 1 && stride == 1) ? SR_CK1 : 16; }
 
 struct SrConvParams {
   const float* in; int64_t in_sb; int in_sp;        // batch stride, pixel stride (elements)
@@ -461,7 +467,7 @@ static int sr_conv_launch(SrConvParams& p, int B, int nt, hipStream_t stream) {
   p.tiles_y = (p.Ho + G::TH - 1) / G::TH;
   p.co_blocks = (p.Co_pad + 32 * nt - 1) / (32 * nt);
   p.total_tiles = p.tiles_x * p.tiles_y * p.co_blocks * B;
-  int blocks = sr_num_cus() * 2;  // persistent grid: 2 workgroups per CU (register / LDS limit)
+  int blocks = sr_num_cus() * (KS == 1 ? SR_CONV_BLOCKS_PER_CU : 2);  // persistent grid: workgroups per CU (register / LDS limit)
   if (blocks > p.total_tiles) blocks = p.total_tiles;
   dim3 grid(blocks), block(256);
   const bool v4 = p.vec4 && (p.Cin % 4 == 0);
