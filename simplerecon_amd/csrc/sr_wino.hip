@@ -284,20 +284,25 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const int cbuf = s % NB, ca = s & 1;
+        // k-step outer, N-tile inner: consecutive MFMAs hit different accumulators.  The prefetches of later steps
+        // (weight fragments, next A fragment) and their address arithmetic sit BETWEEN the MFMA pairs, where the
+        // wave has ~60 idle issue cycles per MFMA; clustered at the step boundary they overran that window.
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].x, b_f[cbuf][n].x, acc[s >> 1][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (s + PD < STEPS) load_b(sl0 + ch, s + PD, b_f[(s + PD) % NB]);
         else if (more) load_b(sl0 + ch + 1, s + PD - STEPS, b_f[(s + PD) % NB]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].y, b_f[cbuf][n].y, acc[s >> 1][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < STEPS) {
           const int xi = 4 * wave + ((s + 1) >> 1), g = (s + 1) & 1;
           a_f[ca ^ 1] = *reinterpret_cast<const float4*>(&V[(xi * 32 + i) * WN_ROW + 8 * g + 4 * kk]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // k-step outer, N-tile inner: consecutive MFMAs hit different accumulators
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].x, b_f[cbuf][n].x, acc[s >> 1][n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].y, b_f[cbuf][n].y, acc[s >> 1][n], 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].z, b_f[cbuf][n].z, acc[s >> 1][n], 0, 0, 0);
