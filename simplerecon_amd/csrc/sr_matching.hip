@@ -12,16 +12,18 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------ stem: conv 7x7 / stride 2 / pad 3, Cin = 3 ---
 //
-// Implicit GEMM  out[pixel, co] = sum_k patch[pixel, k] * W[k, co]  with k = (c, ky, kx) -- 147 real taps, laid out
-// as 84 MFMA k-steps of 2: step = (c*7 + ky)*4 + kxp, k-lane `half` selects kx = 2*kxp + half (kx = 7 is a zero tap).
+// Implicit GEMM  out[pixel, co] = sum_k patch[pixel, k] * W[k, co]  with k = c*49 + ky*7 + kx -- 147 taps packed
+// densely into 74 MFMA k-steps of 2 (the k-lane `half` takes tap 2*step + half; tap 147 is a zero pad).
 // A workgroup (4 waves) owns a 16x16 output tile; its 37x37x3 input patch sits in LDS and every A fragment is a
-// single ds_read_b32 at an immediate offset (stride-2 columns: 64 lanes hit each bank twice = the 2-cycle minimum).
-// The packed weight (42 KB) stays in LDS for the whole (persistent) workgroup: [step][half][32 cols][2 N-tiles].
+// single ds_read_b32 -- at an immediate offset when the two taps of a step are neighbours in a patch row, through a
+// per-lane select in the 11 steps that straddle a row / channel end (stride-2 columns: 64 lanes hit each bank twice =
+// the 2-cycle minimum).  The packed weight (37 KB) stays in LDS for the whole (persistent) workgroup:
+// [step][half][32 cols][2 N-tiles]; two workgroups share a CU (three fit the LDS but spill registers: measured slower).
 // Wave w computes output rows 4w..4w+3 (two 2x16 M-tiles) x 64 channels: 4 MFMAs per 3 LDS reads.
 #define SR_STEM_T 16
 #define SR_STEM_PR 37
-#define SR_STEM_PW 38   // column 37 only ever meets the zero weight of the padding tap, but must hold finite data
-#define SR_STEM_STEPS 84
+#define SR_STEM_PW 37
+#define SR_STEM_STEPS 74
 #define SR_STEM_WFLOATS (SR_STEM_STEPS * 128)
 #define SR_STEM_PFLOATS (3 * SR_STEM_PR * SR_STEM_PW)
 
@@ -38,10 +40,15 @@ __global__ void sr_stem_pack_kernel(const float* __restrict__ w /*[64,3,7,7]*/, 
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < SR_STEM_WFLOATS; idx += gridDim.x * blockDim.x) {
     const int step = idx >> 7, r = idx & 127;
     const int half = r >> 6, col = (r & 63) >> 1, nt = r & 1;
-    const int c = step / 28, ky = (step % 28) >> 2, kx = 2 * (step & 3) + half;
+    const int tap = 2 * step + half;  // = (c*7 + ky)*7 + kx: the [3,7,7] part of the weight, flattened
     const int co = nt * 32 + col;
-    packed[idx] = kx < 7 ? w[((co * 3 + c) * 7 + ky) * 7 + kx] : 0.f;
+    packed[idx] = tap < 147 ? w[co * 147 + tap] : 0.f;
   }
+}
+
+// patch offset of tap k (k = 147: the pad, any valid address)
+__host__ __device__ constexpr int sr_stem_tap_offset(int k) {
+  return k >= 147 ? 0 : ((k / 49) * SR_STEM_PR + (k % 49) / 7) * SR_STEM_PW + (k % 7);
 }
 
 __global__ __launch_bounds__(256, 2) void sr_stem_kernel(SrStemParams p) {
@@ -54,9 +61,9 @@ __global__ __launch_bounds__(256, 2) void sr_stem_kernel(SrStemParams p) {
     reinterpret_cast<float4*>(wl)[e] = reinterpret_cast<const float4*>(p.wp)[e];
 
   // A-fragment bases: M-tile m of this wave = output rows 4*wave + 2*m + {0,1}, 16 columns
-  int abase[2];
+  int abase[2];  // without the k-lane term
 #pragma unroll
-  for (int m = 0; m < 2; ++m) abase[m] = (2 * (4 * wave + 2 * m + (i >> 4))) * SR_STEM_PW + 2 * (i & 15) + half;
+  for (int m = 0; m < 2; ++m) abase[m] = (2 * (4 * wave + 2 * m + (i >> 4))) * SR_STEM_PW + 2 * (i & 15);
   const float2* wl2 = reinterpret_cast<const float2*>(wl) + half * 32 + i;
 
   float sc[2], sh[2];
@@ -112,20 +119,18 @@ __global__ __launch_bounds__(256, 2) void sr_stem_kernel(SrStemParams p) {
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-        for (int kxp = 0; kxp < 4; ++kxp) {
-          const int step = (c * 7 + ky) * 4 + kxp;
-          const int aoff = (c * SR_STEM_PR + ky) * SR_STEM_PW + 2 * kxp;
-          const float a0 = patch[abase[0] + aoff], a1 = patch[abase[1] + aoff];
-          const float2 w = wl2[step * 64];
-          acc[0][0] = SR_MFMA(a0, w.x, acc[0][0]);
-          acc[1][0] = SR_MFMA(a1, w.x, acc[1][0]);
-          acc[0][1] = SR_MFMA(a0, w.y, acc[0][1]);
-          acc[1][1] = SR_MFMA(a1, w.y, acc[1][1]);
-        }
+    for (int step = 0; step < SR_STEM_STEPS; ++step) {
+      constexpr int dummy = 0; (void)dummy;
+      const int o0 = sr_stem_tap_offset(2 * step), o1 = sr_stem_tap_offset(2 * step + 1);
+      // neighbours in a patch row: one immediate offset (+ half); otherwise a per-lane select between two offsets
+      const int oa = (o1 == o0 + 1) ? o0 + half : (half ? o1 : o0);
+      const float a0 = patch[abase[0] + oa], a1 = patch[abase[1] + oa];
+      const float2 w = wl2[step * 64];
+      acc[0][0] = SR_MFMA(a0, w.x, acc[0][0]);
+      acc[1][0] = SR_MFMA(a1, w.x, acc[1][0]);
+      acc[0][1] = SR_MFMA(a0, w.y, acc[0][1]);
+      acc[1][1] = SR_MFMA(a1, w.y, acc[1][1]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // every wave is done reading this tile's patch
     if (next < p.total) stash();

@@ -355,7 +355,7 @@ def stem7x7(image, conv: nn.Conv2d, bn=None, leaky=0.0):
         if prof is not None:
             ev1.record()
             prof.append(("sr_stem_kernel", 2.0 * b * ho * wo * 64 * 147, ev0, ev1, (b, 3, h, w, 64, 7, 2),
-                         2.0 * b * ((ho + 15) // 16) * ((wo + 15) // 16) * 256 * 64 * 168))
+                         2.0 * b * ((ho + 15) // 16) * ((wo + 15) // 16) * 256 * 64 * 148))
     _lib.check(rc, "sr_stem7x7_fwd")
     return out
 
