@@ -94,7 +94,8 @@ def test_conv_properties_at_full_resolution():
     assert_close(y[:, :, :20, :36], y_o[:, :, :20, :36], tol=1e-5, what="240x320 block crop vs oracle")
 
 
-@pytest.mark.parametrize("shape", [(1, 256, 15, 20, 128), (2, 384, 15, 20, 64), (1, 256, 30, 40, 256)])
+@pytest.mark.parametrize("shape", [(1, 256, 15, 20, 128), (2, 384, 15, 20, 64), (1, 256, 30, 40, 256), (1, 320, 15, 20, 64),
+                                   (1, 192, 8, 12, 32)])
 def test_winograd_split_k(shape):
     """Deep low-resolution layers run split-K (partial outputs + deterministic reduce): same result as the oracle,
     bias / residual / LeakyReLU applied once, bit-reproducible."""
