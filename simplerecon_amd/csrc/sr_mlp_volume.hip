@@ -358,13 +358,13 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
           SR_RAY_A(fn, g, kn) SR_SB                                                    \
           SR_STEP(1) SR_RAY_B(fn) SR_SB                                                \
           SR_STEP(2) SR_RAY_C(fn) SR_SB                                                \
-          SR_STEP(3) SR_SB /* taps not touched before step 4 (>= 2k cycles after issue) */ \
-          SR_STEP(4) SR_INTERP2(fn, 0, 0) SR_SB                                        \
-          SR_STEP(5) SR_INTERP2(fn, 0, 1) SR_SB                                        \
-          SR_STEP(6) SR_INTERP2(fn, 1, 0) SR_SB                                        \
-          SR_STEP(7) SR_INTERP2(fn, 1, 1) SR_SB                                        \
-          SR_STEP(8) SR_INTERP2(fn, 2, 0) SR_SB                                        \
-          SR_STEP(9) SR_INTERP2(fn, 2, 1) SR_SB                                        \
+          SR_STEP(3) SR_SB /* taps not touched before step 7 (>= 3.5k cycles after issue) */ \
+          SR_STEP(4) SR_SB                                                             \
+          SR_STEP(5) SR_SB                                                             \
+          SR_STEP(6) SR_SB                                                             \
+          SR_STEP(7) SR_INTERP2(fn, 0, 0) SR_INTERP2(fn, 0, 1) SR_SB                   \
+          SR_STEP(8) SR_INTERP2(fn, 1, 0) SR_INTERP2(fn, 1, 1) SR_SB                   \
+          SR_STEP(9) SR_INTERP2(fn, 2, 0) SR_INTERP2(fn, 2, 1) SR_SB                   \
           SR_STEP(10) SR_INTERP2(fn, 3, 0) SR_SB                                       \
           SR_STEP(11) SR_INTERP2(fn, 3, 1) SR_DOT(fn) SR_SB                            \
           _Pragma("unroll") for (int t = 0; t < SR_VIEW_SLOTS; ++t) f[t] = fn[t];      \
