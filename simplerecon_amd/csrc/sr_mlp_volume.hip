@@ -157,6 +157,13 @@ __device__ __forceinline__ void sr_l1_step_init(f32x16 (&acc)[2][4], const f32x1
   acc[1][3] = SR_MFMA(wA.w, bQ, hc[1][3]);
 }
 
+// Ablation switches (env SR_MLP_DEBUG) exist only in -DSR_MLP_ABLATION builds; in production they are compile-time 0.
+#ifdef SR_MLP_ABLATION
+#define SR_MLP_DBG(bit) (p.debug & (bit))
+#else
+#define SR_MLP_DBG(bit) 0
+#endif
+
 #define SR_LDS_W3_FLOATS 256  // w3tab (128) + b3 + pad, in front of W1 in LDS
 
 template <bool W1_LDS, bool W2_LDS>
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
       const float4* t_ne = reinterpret_cast<const float4*>(img + (size_t)smp.o_ne * C);
       const float4* t_sw = reinterpret_cast<const float4*>(img + (size_t)smp.o_sw * C);
       const float4* t_se = reinterpret_cast<const float4*>(img + (size_t)smp.o_se * C);
-      if (!(p.debug & 2)) {
+      if (!SR_MLP_DBG(2)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           taps[i] = t_nw[i]; taps[4 + i] = t_ne[i]; taps[8 + i] = t_sw[i]; taps[12 + i] = t_se[i];
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
         const float4 wA = wn0;
         wn0 = wn1;
         wn1 = wn2;
-        if (!(p.debug & 1)) wn2 = w2[(size_t)min(t + 3, 64) * 64];
+        if (!SR_MLP_DBG(1)) wn2 = w2[(size_t)min(t + 3, 64) * 64];
         const float aP = acc[0][t >> 4][t & 15], aQ = acc[1][t >> 4][t & 15];
         const float bP = fmaxf(aP, p.slope * aP), bQ = fmaxf(aQ, p.slope * aQ);
         acc2[0][0] = SR_MFMA(wA.x, bP, acc2[0][0]);
