@@ -43,6 +43,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 __host__ __device__ constexpr int sr_ck(int ks, int stride = 1) { return (ks == 1 && stride == 1) ? SR_CK1 : 16; }
 
+// Phase-ablation switches (env SR_CONV_DEBUG) exist only in -DSR_CONV_ABLATION builds; in production they are compile-time 0,
+// which keeps dead branches out of the hot loops (they cost registers: the MLP sweep spilled because of them).
+#ifdef SR_CONV_ABLATION
+#define SR_CV_DBG(bit) (p.debug & (bit))
+#else
+#define SR_CV_DBG(bit) 0
+#endif
+
 struct SrConvParams {
   const float* in; int64_t in_sb; int in_sp;        // batch stride, pixel stride (elements)
   const float* wp;                                  // packed weights [taps][G][2][Co_pad][4]
@@ -92,7 +100,7 @@ __device__ __forceinline__ void sr_conv_stage_setup(const SrConvParams& p, int i
       iy = min(max(iy, 0), p.H - 1);
       ix = min(max(ix, 0), p.W - 1);
     }
-    const bool ok = (e < G::ELEMS) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W) && !(p.debug & 4);
+    const bool ok = (e < G::ELEMS) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W) && !SR_CV_DBG(4);
     offs[it] = ok ? (iy * p.W + ix) * p.in_sp + 4 * q : -1;
   }
 }
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
     float rpf[RES_PF ? MT : 1][RES_PF ? NT : 1][16];  // prefetched residual values (RES_PF only)
-    const float* __restrict__ resp = (p.res && !(p.debug & 2)) ? p.res + (int64_t)t.b * p.res_sb : nullptr;
+    const float* __restrict__ resp = (p.res && !SR_CV_DBG(2)) ? p.res + (int64_t)t.b * p.res_sb : nullptr;
 
     for (int ch = 0; ch < chunks; ++ch) {
       const float* tile = tiles[buf];
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
       const int osp = p.out_sp, rsp = p.res_sp;
       const bool no_res = (resp == nullptr);
       // interior tiles (workgroup-uniform test) take a branch-free path
-      const bool full = (t.oy0 + TH <= p.Ho) && (t.ox0 + CM <= p.Wo) && (t.co0 + 32 * NT <= p.Cout) && !(p.debug & 1);
+      const bool full = (t.oy0 + TH <= p.Ho) && (t.ox0 + CM <= p.Wo) && (t.co0 + 32 * NT <= p.Cout) && !SR_CV_DBG(1);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int oyb = t.oy0 + (wave * MT + m) * RM;
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
               const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
               float v = acc[m][n][r] + bv + rv[r];
               if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
-              if (ok[r] && (!(p.debug & 1) || v == 1.2345e33f)) outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
+              if (ok[r] && (!SR_CV_DBG(1) || v == 1.2345e33f)) outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
             }
           }
         }

@@ -51,6 +51,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WN_STAGE_ELEMS (WN_PH * WN_PW * 4)  // float4 elements per slab (720)
 #define WN_STAGE_PER_THREAD 3
 
+// Phase-ablation switches (env SR_WINO_DEBUG) exist only in -DSR_WINO_ABLATION builds; in production they are compile-time 0,
+// which keeps dead branches out of the hot loops (they cost registers: the MLP sweep spilled because of them).
+#ifdef SR_WINO_ABLATION
+#define SR_WN_DBG(bit) (p.debug & (bit))
+#else
+#define SR_WN_DBG(bit) 0
+#endif
+
 struct SrWinoParams {
   const float* in; int64_t in_sb; int in_sp;
   const float* wu;                                  // packed U: [16][G][2][Co_pad][4]
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #pragma unroll
       for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
         const int c = c0 + 4 * ((tid + it * 256) & 3);
-        const bool ok = (offs[it] >= 0) & (c < p.Cin) & !(p.debug & 4);
+        const bool ok = (offs[it] >= 0) & (c < p.Cin) & !SR_WN_DBG(4);
         const float* src = in_b + (ok ? offs[it] + c0 : 0);
         if (VEC4) {
           const float4 v = *reinterpret_cast<const float4*>(src);
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     const float4* wu4 = nullptr;
     auto load_b = [&](int ch, int s, float4 (&dst)[NT]) {
       const int xi = 4 * wave + (s >> 1), g = s & 1;
-      const float4* wrec = wu4 + ((p.debug & 32) ? (int64_t)0 : (int64_t)(xi * p.G + 2 * ch + g) * rec);
+      const float4* wrec = wu4 + (SR_WN_DBG(32) ? (int64_t)0 : (int64_t)(xi * p.G + 2 * ch + g) * rec);
 #pragma unroll
       for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
     };
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
       }
 
       // ---- T: this wave's row of V = B^T d B, all 32 tiles x 16 channels ----
-      if (!(p.debug & 2)) {
+      if (!SR_WN_DBG(2)) {
         const float* raw = (ch & 1) ? rawA : rawB;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 
       // ---- M: this wave's 4 frequencies x 2 channel groups ----
       a_f[0] = *reinterpret_cast<const float4*>(&V[((4 * wave) * 32 + i) * WN_ROW + 4 * kk]);
-      if (!(p.debug & 8))
+      if (!SR_WN_DBG(8))
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const int cbuf = s % NB, ca = s & 1;
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     // Y = A^T M A is separable: wave w holds the whole frequency ROW ur = w (its 4 accumulators are the columns
     // uc = 0..3), so the column half (M A) is done in registers and only 2 of 4 values per (tile, channel) go
     // through LDS: O[ur][b][tile][co] (64 KB for both N-tiles -> one pass, two barriers).
-    if (!(p.debug & 16)) {
+    if (!SR_WN_DBG(16)) {
       constexpr int CO = 32 * NT;           // channels per workgroup
       if (VOUT) {
         // Vector epilogue (Cout % 4 == 0, 16-byte aligned output / residual rows): a thread owns (tile, 4 consecutive
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
               v.z = fmaxf(v.z, 0.0f) + slope * fminf(v.z, 0.0f);
               v.w = fmaxf(v.w, 0.0f) + slope * fminf(v.w, 0.0f);
             }
-            if (ok[it][q] && (!(p.debug & 1) || v.x == 1.2345e33f))
+            if (ok[it][q] && (!SR_WN_DBG(1) || v.x == 1.2345e33f))
               *reinterpret_cast<float4*>(outp + (opix[it][q] * out_sp + cog)) = v;
           }
         }
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
           for (int q = 0; q < 4; ++q) {
             float v = y[q] + bv + rv[it][q];
             if (slope >= 0.0f) v = fmaxf(v, 0.0f) + slope * fminf(v, 0.0f);
-            if (ok[it][q] && (!(p.debug & 1) || v == 1.2345e33f)) outp[opix[it][q] * out_sp + cog] = v;
+            if (ok[it][q] && (!SR_WN_DBG(1) || v == 1.2345e33f)) outp[opix[it][q] * out_sp + cog] = v;
           }
         }
         __syncthreads();
