@@ -123,6 +123,8 @@ class DepthModel(nn.Module):
 
     # ---- reference depth_model.py:191-245 ----------------------------------------------------
     def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward):
+        if not unbatched_matching_encoder_forward and hasattr(self.matching_model, "forward_pair"):
+            return self.matching_model.forward_pair(cur_image, src_image)   # no image concatenation
         all_frames = torch.cat([cur_image.unsqueeze(1), src_image], dim=1)
         batch_size, num_views = all_frames.shape[:2]
         if unbatched_matching_encoder_forward:

@@ -243,13 +243,33 @@ class ResnetMatchingEncoder(nn.Module):
             nn.InstanceNorm2d(num_ch_out),
         )
 
+    def forward_pair(self, cur_image, src_image):
+        """Features of a batch of reference images [B,3,H,W] and their source images [B,K,3,H,W] in ONE pass over
+        B(1+K) images without concatenating the images first: the stem writes both groups into one buffer (every
+        later layer is per image -- eval BatchNorm, InstanceNorm -- so the order inside the batch is free).
+        Returns (cur_feats [B,C,h,w], src_feats [B,K,C,h,w])."""
+        from . import ops
+        b, k = src_image.shape[:2]
+        h, w = cur_image.shape[-2:]
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        stem = ops.empty_nhwc(b * (1 + k), 64, ho, wo, cur_image.device)
+        ops.stem7x7(cur_image, self.net[0], self.net[1], out=stem[:b])
+        ops.stem7x7(src_image.reshape(b * k, *src_image.shape[2:]), self.net[0], self.net[1], out=stem[b:])
+        feats = self._after_stem(stem)
+        return feats[:b], feats[b:].unflatten(0, (b, k))
+
     def forward(self, input_image):
         """input_image [B,3,H,W] (H, W multiples of 4) -> [B,num_ch_out,H/4,W/4] (channels_last memory)."""
+        from . import ops
+        if self.training:
+            raise RuntimeError("ResnetMatchingEncoder on the HIP path is inference-only (call .eval())")
+        return self._after_stem(ops.stem7x7(input_image, self.net[0], self.net[1]))   # conv1 + bn1 + relu
+
+    def _after_stem(self, x):
         from . import ops
         net = self.net
         if self.training:
             raise RuntimeError("ResnetMatchingEncoder on the HIP path is inference-only (call .eval())")
-        x = ops.stem7x7(input_image, net[0], net[1])                       # conv1 + bn1 + relu
         x = ops.maxblurpool(x)                                              # MaxPool(2,1) + BlurPool(4,2)
         for blk in net[4]:
             t = ops.conv2d(x, blk.conv1, bn=blk.bn1, leaky=0.0)

@@ -307,9 +307,10 @@ def _workspace(device, tag, nbytes):
     return ws
 
 
-def stem7x7(image, conv: nn.Conv2d, bn=None, leaky=0.0):
+def stem7x7(image, conv: nn.Conv2d, bn=None, leaky=0.0, out=None):
     """act(bn(conv7x7_s2_p3(image))): encoder.conv1 + bn1 + relu of the ResNet stem (reference networks.py:176-179).
-    image [B,3,H,W], any strides; returns channels-last [B,64,H/2,W/2]."""
+    image [B,3,H,W], any strides; returns channels-last [B,64,H/2,W/2] (or writes it into `out`, e.g. a batch slice
+    of a larger buffer)."""
     _lib.require_device_f32("image", image)
     _lib.refuse_autograd(image, conv.weight)
     if conv.kernel_size != (7, 7) or conv.stride != (2, 2) or tuple(conv.padding) != (3, 3) or conv.groups != 1 \
@@ -339,7 +340,10 @@ def stem7x7(image, conv: nn.Conv2d, bn=None, leaky=0.0):
     _, wp, scale, shift = hit
     b, _, h, w = image.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    out = empty_nhwc(b, 64, ho, wo, image.device)
+    if out is None:
+        out = empty_nhwc(b, 64, ho, wo, image.device)
+    elif tuple(out.shape) != (b, 64, ho, wo) or not _is_nhwc_view(out):
+        raise ValueError(f"`out` must be a channels-last view of shape {(b, 64, ho, wo)}")
     if b == 0:
         return out
     sb, sc, sy, sx = image.stride()

@@ -153,6 +153,19 @@ def test_full_size_properties():
     assert float(m.abs().max()) < 1e-4 and float((v - 1).abs().max()) < 1e-3, (float(m.abs().max()), float((v - 1).abs().max()))
 
 
+def test_forward_pair_equals_concatenated_forward():
+    """forward_pair (no image concatenation) = forward on cat([cur, src]) regrouped, bit for bit."""
+    enc = synthetic.seeded_fill_(ResnetMatchingEncoder(18, 16), seed=2).to(DEV).eval()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    cur = torch.randn((2, 3, 64, 96), generator=g).to(DEV)
+    src = torch.randn((2, 3, 3, 64, 96), generator=g).to(DEV)
+    with torch.inference_mode():
+        c, s_ = enc.forward_pair(cur, src)
+        ref = enc(torch.cat([cur.unsqueeze(1), src], dim=1).flatten(0, 1)).unflatten(0, (2, 4))
+    assert tuple(c.shape) == (2, 16, 16, 24) and tuple(s_.shape) == (2, 3, 16, 16, 24)
+    assert torch.equal(c, ref[:, 0]) and torch.equal(s_, ref[:, 1:])
+
+
 def test_training_mode_and_bad_configs_fail_loudly():
     enc = ResnetMatchingEncoder(18, 16).to(DEV)
     with pytest.raises(RuntimeError):
