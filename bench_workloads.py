@@ -62,9 +62,13 @@ class DotCfg2:
     name = "dot_cfg2"
     B, K, Cc, D, h, w = 1, 7, 16, 64, 120, 160
 
-    def __init__(self, dev, rank, B=None):
+    def __init__(self, dev, rank, B=None, D=None, name=None):
         if B is not None:
             self.B = B
+        if D is not None:
+            self.D = D
+        if name is not None:
+            self.name = name
         self.dev = dev
         self.frames_per_step = self.B
         self.inp = synthetic.cost_volume_inputs(self.B, self.K, self.Cc, self.h, self.w, seed=rank, device=dev)
@@ -502,5 +506,7 @@ WORKLOADS = {
     "tsdf_fuse": lambda dev, rank: TsdfFuse(dev, rank),
     "dot_cfg2": lambda dev, rank: DotCfg2(dev, rank),
     "dot_b8": lambda dev, rank: DotCfg2(dev, rank, B=8),
+    # evidence for "the sweep is HBM-bound only when there are few planes": 2 planes, batch 64 (not a BASELINE config)
+    "dot_d2_b64": lambda dev, rank: DotCfg2(dev, rank, B=64, D=2, name="dot_d2_b64"),
 }
 DEFAULT = "hero_cfg3"
