@@ -227,6 +227,8 @@ __global__ __launch_bounds__(1024) void sr_dot_volume_kernel(SrDotParams p) {
 // lane = (pixel, channel quad): the 4 lanes of a pixel read the 64 contiguous bytes of a texel (one float4 each), each
 // forms its 4-channel partial dot, and two DPP quad exchanges finish the reduction.  Sample parameters travel from the
 // owning lane with ds_bpermute; per-round reference features are loaded once per tile.
+typedef float sr_f2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float sr_quad_sum(float v) {
   // sum over the 4 lanes of a quad: quad_perm [1,0,3,2] then [2,3,0,1]
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -311,13 +313,19 @@ __global__ __launch_bounds__(1024) void sr_dot_volume_kernel16q(SrDotParams p) {
         const float4 t_ne = *reinterpret_cast<const float4*>(img + (size_t)o_ne * C);
         const float4 t_sw = *reinterpret_cast<const float4*>(img + (size_t)o_sw * C);
         const float4 t_se = *reinterpret_cast<const float4*>(img + (size_t)o_se * C);
-        const float4 c = curq[r];
-        const float d_nw = fmaf(t_nw.w, c.w, fmaf(t_nw.z, c.z, fmaf(t_nw.y, c.y, t_nw.x * c.x)));
-        const float d_ne = fmaf(t_ne.w, c.w, fmaf(t_ne.z, c.z, fmaf(t_ne.y, c.y, t_ne.x * c.x)));
-        const float d_sw = fmaf(t_sw.w, c.w, fmaf(t_sw.z, c.z, fmaf(t_sw.y, c.y, t_sw.x * c.x)));
-        const float d_se = fmaf(t_se.w, c.w, fmaf(t_se.z, c.z, fmaf(t_se.y, c.y, t_se.x * c.x)));
-        // sum_c (sum_taps w_t * tap_c) * cur_c == sum_taps w_t * (tap . cur)   (cost_volume.py:322-326)
-        costr[r] += fmaf(a_se, d_se, fmaf(a_sw, d_sw, fmaf(a_ne, d_ne, a_nw * d_nw)));
+        // sum_c (sum_taps w_t * tap_c) * cur_c (cost_volume.py:322-326) on packed fp32 pairs (v_pk_fma_f32: two FMAs
+        // per lane and instruction -- the sweep is VALU-bound, 260 VALU instructions per 64 samples before this)
+        const sr_f2 cl = {curq[r].x, curq[r].y}, ch = {curq[r].z, curq[r].w};
+        const sr_f2 wnw = {a_nw, a_nw}, wne = {a_ne, a_ne}, wsw = {a_sw, a_sw}, wse = {a_se, a_se};
+        sr_f2 lo = wnw * sr_f2{t_nw.x, t_nw.y}, hi = wnw * sr_f2{t_nw.z, t_nw.w};
+        lo = __builtin_elementwise_fma(wne, sr_f2{t_ne.x, t_ne.y}, lo);
+        hi = __builtin_elementwise_fma(wne, sr_f2{t_ne.z, t_ne.w}, hi);
+        lo = __builtin_elementwise_fma(wsw, sr_f2{t_sw.x, t_sw.y}, lo);
+        hi = __builtin_elementwise_fma(wsw, sr_f2{t_sw.z, t_sw.w}, hi);
+        lo = __builtin_elementwise_fma(wse, sr_f2{t_se.x, t_se.y}, lo);
+        hi = __builtin_elementwise_fma(wse, sr_f2{t_se.z, t_se.w}, hi);
+        const sr_f2 pr = __builtin_elementwise_fma(hi, ch, lo * cl);
+        costr[r] += pr.x + pr.y;
       }
     }
     // quad partial sums -> per-pixel cost, back to lane = pixel
