@@ -41,35 +41,43 @@ struct SrSample {
   int o_nw, o_ne, o_sw, o_se;    // texel indices (y*w + x), clamped in-image
 };
 
+typedef float sr_f2v __attribute__((ext_vector_type(2)));
+
+// x / y components run as packed fp32 pairs (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, FP contraction off, so
+// every value is bit-identical to the scalar formulation) -- half the VALU instructions of the projection.
 __device__ __forceinline__ void sr_project_sample(const float* __restrict__ g /*geom record*/,
                                                   float X0, float X1, float X2, int h, int w,
                                                   float inv_w, float inv_h, SrSample& s) {
 #pragma clang fp contract(off)
   const float eps = 1e-8f;
-  const float q0 = g[0] * X0 + g[1] * X1 + g[2] * X2 + g[3];
-  const float q1 = g[4] * X0 + g[5] * X1 + g[6] * X2 + g[7];
+  const sr_f2v q01 = sr_f2v{g[0], g[4]} * X0 + sr_f2v{g[1], g[5]} * X1 + sr_f2v{g[2], g[6]} * X2 + sr_f2v{g[3], g[7]};
   const float q2 = g[8] * X0 + g[9] * X1 + g[10] * X2 + g[11];
   s.zp = q2 + eps;
   const float sc = (fabsf(q2) > eps) ? 1.0f / s.zp : 1.0f;
-  s.pix_x = q0 * sc;
-  s.pix_y = q1 * sc;
+  const sr_f2v pix = q01 * sc;
+  s.pix_x = pix.x;
+  s.pix_y = pix.y;
   // uv = 2*pix*(1/w,1/h) - 1 (cost_volume.py:199); grid_sample unnormalise, align_corners=False
-  const float u = 2.0f * s.pix_x * inv_w - 1.0f;
-  const float v = 2.0f * s.pix_y * inv_h - 1.0f;
-  const float ix = ((u + 1.0f) * (float)w - 1.0f) / 2.0f;
-  const float iy = ((v + 1.0f) * (float)h - 1.0f) / 2.0f;
+  const sr_f2v uv = 2.0f * pix * sr_f2v{inv_w, inv_h} - 1.0f;
+  const sr_f2v size = {(float)w, (float)h};
+  const sr_f2v ixy = ((uv + 1.0f) * size - 1.0f) / 2.0f;
+  const float ix = ixy.x, iy = ixy.y;
   const float fx0 = floorf(ix), fy0 = floorf(iy);
-  const float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
+  const sr_f2v f0 = {fx0, fy0};
+  const sr_f2v f1 = f0 + 1.0f;
+  const float fx1 = f1.x, fy1 = f1.y;
   const float wm = (float)(w - 1), hm = (float)(h - 1);
   // (bitwise & on purpose: short-circuit && makes hipcc emit divergent branches that split the
   // scheduling region the callers want to interleave with MFMAs)
   const bool vx0 = (fx0 >= 0.0f) & (fx0 <= wm), vx1 = (fx1 >= 0.0f) & (fx1 <= wm);
   const bool vy0 = (fy0 >= 0.0f) & (fy0 <= hm), vy1 = (fy1 >= 0.0f) & (fy1 <= hm);
-  const float ax1 = fx1 - ix, ax0 = ix - fx0, ay1 = fy1 - iy, ay0 = iy - fy0;
-  s.w_nw = (vx0 & vy0) ? ax1 * ay1 : 0.0f;
-  s.w_ne = (vx1 & vy0) ? ax0 * ay1 : 0.0f;
-  s.w_sw = (vx0 & vy1) ? ax1 * ay0 : 0.0f;
-  s.w_se = (vx1 & vy1) ? ax0 * ay0 : 0.0f;
+  const sr_f2v a1 = f1 - ixy, a0 = ixy - f0;            // (ax1, ay1), (ax0, ay0)
+  const sr_f2v wtop = sr_f2v{a1.x, a0.x} * a1.y;        // (ax1*ay1, ax0*ay1)
+  const sr_f2v wbot = sr_f2v{a1.x, a0.x} * a0.y;        // (ax1*ay0, ax0*ay0)
+  s.w_nw = (vx0 & vy0) ? wtop.x : 0.0f;
+  s.w_ne = (vx1 & vy0) ? wtop.y : 0.0f;
+  s.w_sw = (vx0 & vy1) ? wbot.x : 0.0f;
+  s.w_se = (vx1 & vy1) ? wbot.y : 0.0f;
   // clamp (NaN-safe: fmaxf(NaN, 0) = 0) so every tap address is in-image; weight 0 kills it
   const int x0 = (int)fminf(fmaxf(fx0, 0.0f), wm), x1 = (int)fminf(fmaxf(fx1, 0.0f), wm);
   const int y0 = (int)fminf(fmaxf(fy0, 0.0f), hm), y1 = (int)fminf(fmaxf(fy1, 0.0f), hm);
