@@ -121,8 +121,16 @@ __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// float4 add / sub as two packed fp32 pairs (v_pk_add_f32): the transforms are pure add / sub work
+typedef float wn_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) {
+  const wn_f2 lo = wn_f2{a.x, a.y} - wn_f2{b.x, b.y}, hi = wn_f2{a.z, a.w} - wn_f2{b.z, b.w};
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) {
+  const wn_f2 lo = wn_f2{a.x, a.y} + wn_f2{b.x, b.y}, hi = wn_f2{a.z, a.w} + wn_f2{b.z, b.w};
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
 
 template <int NT, bool VEC4, bool VOUT>
 __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
@@ -275,7 +283,10 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
           for (int c = 0; c < 4; ++c) {
             const float4 da = *reinterpret_cast<const float4*>(&raw[base + (t_ra * WN_PW + c) * WN_ROW]);
             const float4 db = *reinterpret_cast<const float4*>(&raw[base + (t_rb * WN_PW + c) * WN_ROW]);
-            wv[c] = make_float4(da.x + t_sign * db.x, da.y + t_sign * db.y, da.z + t_sign * db.z, da.w + t_sign * db.w);
+            const wn_f2 sg = {t_sign, t_sign};
+            const wn_f2 lo = __builtin_elementwise_fma(sg, wn_f2{db.x, db.y}, wn_f2{da.x, da.y});
+            const wn_f2 hi = __builtin_elementwise_fma(sg, wn_f2{db.z, db.w}, wn_f2{da.z, da.w});
+            wv[c] = make_float4(lo.x, lo.y, hi.x, hi.y);
           }
           float* vrow = V + ((4 * wave) * 32 + tt) * WN_ROW + 4 * tq;
           *reinterpret_cast<float4*>(vrow + 0 * 32 * WN_ROW) = f4sub(wv[0], wv[2]);
