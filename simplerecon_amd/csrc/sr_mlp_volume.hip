@@ -303,16 +303,19 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
       const float n2 = fmaxf(sqrtf(((o)[20] * (o)[20] + (o)[21] * (o)[21]) + (o)[22] * (o)[22]), 1e-5f); \
       (o)[19] = (crn0 * ((o)[20] / n2) + crn1 * ((o)[21] / n2)) + crn2 * ((o)[22] / n2);       \
     }
-#define SR_INTERP2(o, i, lo)  /* channels 4i+lo, 4i+lo+1 */                                   \
+#define SR_INTERP2(o, i, lo)  /* channels 4i+2lo, 4i+2lo+1 as one packed fp32 pair (v_pk_fma_f32) */       \
     {                                                                                         \
       const float4 a = taps[i], bq = taps[4 + (i)], c4 = taps[8 + (i)], d4 = taps[12 + (i)];   \
-      if ((lo) == 0) {                                                                        \
-        (o)[4 * (i) + 0] = fmaf(smp.w_se, d4.x, fmaf(smp.w_sw, c4.x, fmaf(smp.w_ne, bq.x, smp.w_nw * a.x))); \
-        (o)[4 * (i) + 1] = fmaf(smp.w_se, d4.y, fmaf(smp.w_sw, c4.y, fmaf(smp.w_ne, bq.y, smp.w_nw * a.y))); \
-      } else {                                                                                \
-        (o)[4 * (i) + 2] = fmaf(smp.w_se, d4.z, fmaf(smp.w_sw, c4.z, fmaf(smp.w_ne, bq.z, smp.w_nw * a.z))); \
-        (o)[4 * (i) + 3] = fmaf(smp.w_se, d4.w, fmaf(smp.w_sw, c4.w, fmaf(smp.w_ne, bq.w, smp.w_nw * a.w))); \
-      }                                                                                       \
+      const sr_f2v ta = (lo) == 0 ? sr_f2v{a.x, a.y} : sr_f2v{a.z, a.w};                       \
+      const sr_f2v tb = (lo) == 0 ? sr_f2v{bq.x, bq.y} : sr_f2v{bq.z, bq.w};                   \
+      const sr_f2v tc = (lo) == 0 ? sr_f2v{c4.x, c4.y} : sr_f2v{c4.z, c4.w};                   \
+      const sr_f2v td = (lo) == 0 ? sr_f2v{d4.x, d4.y} : sr_f2v{d4.z, d4.w};                   \
+      const sr_f2v r2 = __builtin_elementwise_fma(sr_f2v{smp.w_se, smp.w_se}, td,              \
+                        __builtin_elementwise_fma(sr_f2v{smp.w_sw, smp.w_sw}, tc,              \
+                        __builtin_elementwise_fma(sr_f2v{smp.w_ne, smp.w_ne}, tb,              \
+                                                  sr_f2v{smp.w_nw, smp.w_nw} * ta)));          \
+      (o)[4 * (i) + 2 * (lo) + 0] = r2.x;                                                     \
+      (o)[4 * (i) + 2 * (lo) + 1] = r2.y;                                                     \
     }
 #define SR_DOT(o)                                                                             \
     {                                                                                         \
