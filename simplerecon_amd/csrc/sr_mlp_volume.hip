@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
 
       // layer 3 (128 -> 1, no activation: disable_final_activation=True, cost_volume.py:438); w3tab in LDS
       const float4* w3 = reinterpret_cast<const float4*>(lds + half * 64);
-      float oP = 0.0f, oQ = 0.0f;
+      sr_f2v oPQ = {0.0f, 0.0f};  // the two point groups as one packed fp32 pair (v_pk_mul_f32 / v_pk_fma_f32)
+      const sr_f2v slope2 = {p.slope, p.slope};
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -439,11 +440,12 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
           const float wr[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float hp = acc2[0][m][4 * q + i], hq = acc2[1][m][4 * q + i];
-            oP = fmaf(wr[i], fmaxf(hp, p.slope * hp), oP);
-            oQ = fmaf(wr[i], fmaxf(hq, p.slope * hq), oQ);
+            const sr_f2v h2 = {acc2[0][m][4 * q + i], acc2[1][m][4 * q + i]};
+            const sr_f2v s2 = slope2 * h2;
+            oPQ = __builtin_elementwise_fma(sr_f2v{wr[i], wr[i]}, sr_f2v{fmaxf(h2.x, s2.x), fmaxf(h2.y, s2.y)}, oPQ);
           }
         }
+      float oP = oPQ.x, oQ = oPQ.y;
       oP += __shfl_xor(oP, 32);
       oQ += __shfl_xor(oQ, 32);
       const float cost = (half ? oQ : oP) + lds[128];
