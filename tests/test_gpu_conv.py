@@ -113,3 +113,41 @@ def test_winograd_split_k(shape):
     assert torch.equal(y, y2)
     ref = oracle.conv2d(x, conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(), residual=res, leaky=0.2)
     assert_close(y, ref, tol=1e-5, what=f"split-K Winograd conv {shape}")
+
+
+def test_conv_random_shapes_and_options():
+    """Randomised sweep over the conv dispatcher (direct / Winograd / split-K, 32- or 64-channel blocks, vector or
+    scalar epilogue): odd sizes, channel counts that are not multiples of 4 / 16 / 32, with and without bias,
+    residual, activation, writing into a channel slice -- each against the C oracle."""
+    rng = np.random.default_rng(2024)
+    for case in range(28):
+        k = int(rng.choice([1, 3, 3, 3]))
+        stride = int(rng.choice([1, 1, 1, 2])) if k == 3 else 1
+        ci = int(rng.choice([3, 8, 16, 24, 30, 64, 100, 128, 200, 320]))
+        co = int(rng.choice([1, 5, 16, 32, 48, 64, 96, 130]))
+        b = int(rng.choice([1, 2, 3]))
+        h, w = int(rng.integers(5, 34)), int(rng.integers(5, 50))
+        use_bias, use_res = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        leaky = [None, 0.2, 0.0][int(rng.integers(0, 3))]
+        conv = synthetic.seeded_fill_(torch.nn.Conv2d(ci, co, k, stride=stride, padding=k // 2, bias=use_bias),
+                                      seed=case).to(DEV)
+        x = rng.standard_normal((b, ci, h, w), dtype=np.float32)
+        ho, wo = ops.conv_out_hw(h, w, stride, k)
+        res = rng.standard_normal((b, co, ho, wo), dtype=np.float32) if use_res else None
+        xt = torch.from_numpy(x).to(DEV)
+        if case % 3 == 0:
+            xt = xt.contiguous(memory_format=torch.channels_last)
+        rt = torch.from_numpy(res).to(DEV) if use_res else None
+        with torch.inference_mode():
+            if case % 4 == 1:   # into a channel slice of a wider buffer
+                buf = ops.empty_nhwc(b, co + 7, ho, wo, DEV).fill_(3.0)
+                y = ops.conv2d(xt, conv, residual=rt, leaky=leaky, out=buf[:, 3:3 + co])
+                assert bool((buf[:, :3] == 3).all()) and bool((buf[:, 3 + co:] == 3).all())
+            else:
+                y = ops.conv2d(xt, conv, residual=rt, leaky=leaky)
+        ref = oracle.conv2d(x, conv.weight.detach().cpu().numpy(),
+                            conv.bias.detach().cpu().numpy() if use_bias else None, stride=stride, residual=res,
+                            leaky=leaky)
+        assert tuple(y.shape) == ref.shape, (case, tuple(y.shape), ref.shape)
+        assert_close(y, ref, tol=2e-5, what=f"case {case}: B{b} {ci}->{co} k{k} s{stride} {h}x{w} bias={use_bias} "
+                                            f"res={use_res} leaky={leaky}")
