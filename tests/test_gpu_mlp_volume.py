@@ -117,3 +117,17 @@ def test_unsupported_configs_fail_loudly():
     inp = synthetic.cost_volume_inputs(1, 2, 8, 8, 12)
     with pytest.raises(HipLibraryError):
         _run(mgr, inp)
+
+
+@pytest.mark.parametrize("K", [1, 9, 12, 15])
+def test_mlp_volume_other_view_counts(K):
+    """Source-view counts that exercise the other weight placements of the sweep kernel: K <= 7 keeps W2 and the
+    depth-variant part of W1 in LDS, K = 8..12 streams W2 from L2, K >= 13 streams W1 (BASELINE configs[4]: K = 15)."""
+    case = dict(B=1, K=K, C=16, D=5, h=12, w=20, seed=70 + K)
+    inp = synthetic.cost_volume_inputs(case["B"], K, 16, case["h"], case["w"], seed=case["seed"])
+    mgr = _manager(case)
+    vol, lowest, planes, mask = _run(mgr, inp)
+    planes_np = planes[:, :, 0, 0].cpu().numpy()
+    cv_o, low_o, mask_o = _oracle(mgr, inp, planes_np)
+    assert_close(vol, cv_o, tol=2e-5, what=f"K={K} vs oracle")
+    assert mismatch_fraction(mask, mask_o) == 0.0
