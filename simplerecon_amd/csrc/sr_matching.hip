@@ -401,6 +401,7 @@ __global__ void sr_t16_pack_kernel(const float* __restrict__ w /*[Cout,Cin,3,3]*
   }
 }
 
+template <bool NORM, bool IN_ACT>
 __global__ __launch_bounds__(256, 2) void sr_t16_kernel(SrT16Params p) {
   __shared__ __attribute__((aligned(16))) float tiles[2][SR_T16_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void sr_t16_kernel(SrT16Params p) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
     const int oy0 = 8 * ty, ox0 = 16 * tx;
     const float* __restrict__ in_b = p.in + (int64_t)b * p.in_sb;
-    const float* st = p.stats ? p.stats + (int64_t)b * 2 * p.Cin : nullptr;
+    const float* st = NORM ? p.stats + (int64_t)b * 2 * p.Cin : nullptr;
 
     int offs[SR_T16_STAGE];
 #pragma unroll
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void sr_t16_kernel(SrT16Params p) {
     };
     auto stage_store = [&](int slab, float* tl) {
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f), r = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (st) {
+      if (NORM) {
         m = *reinterpret_cast<const float4*>(st + 32 * slab + 4 * cq);
         r = *reinterpret_cast<const float4*>(st + p.Cin + 32 * slab + 4 * cq);
       }
@@ -444,8 +445,8 @@ __global__ __launch_bounds__(256, 2) void sr_t16_kernel(SrT16Params p) {
         const int e = tid + it * 256, px = e >> 3;
         if (px < SR_T16_HH * SR_T16_HW) {
           float4 v = stg[it];
-          v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w;
-          if (p.in_slope >= 0.f) {
+          if (NORM) { v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w; }
+          if (IN_ACT) {
             v.x = v.x >= 0.f ? v.x : v.x * p.in_slope; v.y = v.y >= 0.f ? v.y : v.y * p.in_slope;
             v.z = v.z >= 0.f ? v.z : v.z * p.in_slope; v.w = v.w >= 0.f ? v.w : v.w * p.in_slope;
           }
@@ -559,7 +560,11 @@ extern "C" int sr_conv3x3_c16_nhwc_fwd(const float* in, int64_t in_batch_stride,
   p.out_slope = leaky_slope;
   int blocks = 2 * sr_cus();
   if (blocks > p.total) blocks = p.total;
-  hipLaunchKernelGGL(sr_t16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
+  const bool norm = in_stats != nullptr, act = in_leaky_slope >= 0.f;
+  if (norm && act) hipLaunchKernelGGL((sr_t16_kernel<true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
+  else if (norm) hipLaunchKernelGGL((sr_t16_kernel<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
+  else if (act) hipLaunchKernelGGL((sr_t16_kernel<false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
+  else hipLaunchKernelGGL((sr_t16_kernel<false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
   return sr_hip_rc(hipGetLastError());
 }
 
