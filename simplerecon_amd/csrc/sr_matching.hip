@@ -402,7 +402,7 @@ __global__ void sr_t16_pack_kernel(const float* __restrict__ w /*[Cout,Cin,3,3]*
 }
 
 template <bool NORM, bool IN_ACT>
-__global__ __launch_bounds__(256, 2) void sr_t16_kernel(SrT16Params p) {
+__global__ __launch_bounds__(256, 3) void sr_t16_kernel(SrT16Params p) {
   __shared__ __attribute__((aligned(16))) float tiles[2][SR_T16_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -558,7 +558,7 @@ extern "C" int sr_conv3x3_c16_nhwc_fwd(const float* in, int64_t in_batch_stride,
   p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
   p.total = p.tiles_x * p.tiles_y * B;
   p.out_slope = leaky_slope;
-  int blocks = 2 * sr_cus();
+  int blocks = 3 * sr_cus();
   if (blocks > p.total) blocks = p.total;
   const bool norm = in_stats != nullptr, act = in_leaky_slope >= 0.f;
   if (norm && act) hipLaunchKernelGGL((sr_t16_kernel<true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
