@@ -148,16 +148,19 @@ class DotCfg2:
 
 class HeroCfg3:
     """BASELINE.json configs[2]: hero_model.yaml (metadata-MLP matching), batch 8, 7 source views,
-    64 planes, 640x480: the hot path = ResnetMatchingEncoder on the B*(1+K) images -> FeatureVolumeManager sweep
-    -> CVEncoder -> DepthDecoderPP -> exp, all on hand-written HIP kernels.  Inputs = the images and the image-prior
-    pyramid (the third-party EfficientNetV2-S encoder is outside the path), resident in HBM.
-    with_encoder=False ("*_core" workloads) starts from synthetic matching features instead."""
+    64 planes, 640x480: the whole DepthModel.forward = image-prior encoder (EfficientNetV2-S pyramid) on the B
+    reference images + ResnetMatchingEncoder on the B*(1+K) images -> FeatureVolumeManager sweep -> CVEncoder ->
+    DepthDecoderPP -> exp, all on hand-written HIP kernels.  Inputs = the images and camera matrices, resident in HBM.
+    prior=False ("*_noprior") feeds a synthetic image-prior pyramid instead of running that encoder (the r01 workload
+    definition before the encoder was native); with_encoder=False ("*_core") also starts from synthetic matching
+    features."""
     name = "hero_cfg3"
     B, K, Cc, D, h, w = 8, 7, 16, 64, 120, 160
     feature_volume_type = "mlp_feature_volume"
 
-    def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None, graph=False):
+    def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None, graph=False, prior=None):
         from simplerecon_amd import depth_model as dm
+        self.prior = with_encoder if prior is None else (prior and with_encoder)
         if B is not None:
             self.B = B
         if name is not None:
@@ -170,10 +173,12 @@ class HeroCfg3:
         self.frames_per_step = self.B
         opts = dm.default_options(image_width=4 * self.w, image_height=4 * self.h, model_num_views=self.K + 1,
                                   matching_num_depth_bins=self.D, feature_volume_type=self.feature_volume_type)
-        model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(),
+        model = dm.DepthModel(opts, image_encoder=None if self.prior else dm.StandInPyramidEncoder(),
                               matching_encoder=None if with_encoder else dm.StandInMatchingEncoder())
         if with_encoder:
             synthetic.seeded_fill_(model.matching_model, seed=4)
+        if self.prior:
+            synthetic.seeded_fill_(model.encoder, seed=5)
         synthetic.seeded_fill_(model.cost_volume_net, seed=1)
         synthetic.seeded_fill_(model.depth_decoder, seed=2)
         if hasattr(model.cost_volume, "mlp"):
@@ -192,6 +197,9 @@ class HeroCfg3:
         self.last = None
 
     def _eager(self, feats_or_images, pyramid, ext, poses, Ks, invK):
+        if self.prior:
+            return self.model.forward_tensors(feats_or_images[0], feats_or_images[1], ext, poses, Ks, invK,
+                                              return_mask=True)
         if self.with_encoder:
             cur_f, src_f = self.model.compute_matching_feats(feats_or_images[0], feats_or_images[1], False)
         else:
@@ -201,7 +209,8 @@ class HeroCfg3:
     def step(self, i=0):
         inp = self.inp
         first = [self.cur_image, self.src_image] if self.with_encoder else [inp["cur_feats"], inp["src_feats"]]
-        args = (first, self.pyramid, inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"], inp["cur_invK"])
+        args = (first, None if self.prior else self.pyramid, inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
+                inp["cur_invK"])
         if self.use_graph:
             if self._graphed is None:  # capture once (warm-up steps): the ~230 launches of a step become one HIP graph
                 from simplerecon_amd.graph import GraphedCallable
@@ -221,8 +230,10 @@ class HeroCfg3:
         kind = "FeatureVolumeManager (metadata-MLP matching)" if self.feature_volume_type == "mlp_feature_volume" \
             else "CostVolumeManager (dot-product matching)"
         enc = (f"ResnetMatchingEncoder on {self.B}x{self.K + 1} images -> " if self.with_encoder else "")
-        skipped = ("image-prior encoder (third-party EfficientNetV2-S, outside the path) not timed: its pyramid is a "
-                   "synthetic input" if self.with_encoder else
+        if self.prior:
+            enc = (f"EfficientNetV2-S image-prior encoder on {self.B} images (side HIP stream) + " + enc)
+        skipped = ("whole DepthModel.forward timed, nothing skipped" if self.prior else
+                   "image-prior encoder not timed: its pyramid is a synthetic input" if self.with_encoder else
                    "image-prior and matching encoders not timed: their outputs are synthetic inputs")
         return {"workload": f"{self.name}: hot path = {enc}{kind} -> CVEncoder -> DepthDecoderPP -> exp, batch "
                             f"{self.B}/GPU, {self.K} source views, {self.D} planes, 640x480 image ({self.h}x{self.w} "
@@ -246,10 +257,11 @@ class HeroCfg3:
             ops.PROFILE = []
             try:
                 for _ in range(n):
+                    pyramid = list(self.model.encoder(self.cur_image)) if self.prior else self.pyramid
                     if self.with_encoder:
                         self.model.compute_matching_feats(self.cur_image, self.src_image, False)
-                    feats = self.model.cost_volume_net(vol, self.pyramid[1:])
-                    self.model.depth_decoder(self.pyramid[:1] + feats)
+                    feats = self.model.cost_volume_net(vol, pyramid[1:])
+                    self.model.depth_decoder(pyramid[:1] + feats)
                 torch.cuda.synchronize()
                 rec = ops.PROFILE
             finally:
@@ -340,9 +352,14 @@ class HeroCfg3:
         if self.with_encoder:
             msd = {k: v.cpu().numpy() for k, v in m.matching_model.state_dict().items()}
             images = torch.cat([self.cur_image[:1].unsqueeze(1), self.src_image[:1]], dim=1)[0].cpu().numpy()
+        if self.prior:
+            psd = {k: v.cpu().numpy() for k, v in m.encoder.state_dict().items()}
 
         def run():
+            nonlocal pyr
             cur_f, src_f = inp["cur_feats"], inp["src_feats"]
+            if self.prior:
+                pyr = oracle.efficientnetv2_s_features(images[:1], psd)
             if self.with_encoder:
                 f = oracle.resnet_matching_encoder(images, msd)
                 cur_f, src_f = f[None, 0], f[None, 1:]
@@ -363,6 +380,7 @@ class HeroCfg3:
         dt = (time.perf_counter() - t0) / reps
         return {"value": 1.0 / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
                 "sample": f"{reps} repetition(s) of 1 frame of {self.name} ("
+                          f"{'image-prior encoder on 1 image + ' if self.prior else ''}"
                           f"{'matching encoder on 8 images + ' if self.with_encoder else ''}"
                           f"cost volume + CVEncoder + DepthDecoderPP) "
                           f"through oracle/ (plain C + OpenMP restatement, {oracle.num_threads()} threads of "
@@ -492,6 +510,8 @@ class DotFull(HeroCfg3):
 WORKLOADS = {
     "hero_cfg3": lambda dev, rank: HeroCfg3(dev, rank),
     "hero_b1": lambda dev, rank: HeroCfg3(dev, rank, B=1, name="hero_b1"),
+    "hero_cfg3_noprior": lambda dev, rank: HeroCfg3(dev, rank, prior=False, name="hero_cfg3_noprior"),
+    "hero_b1_noprior": lambda dev, rank: HeroCfg3(dev, rank, B=1, prior=False, name="hero_b1_noprior"),
     "hero_cfg3_core": lambda dev, rank: HeroCfg3(dev, rank, with_encoder=False, name="hero_cfg3_core"),
     "hero_b1_core": lambda dev, rank: HeroCfg3(dev, rank, B=1, with_encoder=False, name="hero_b1_core"),
     "hero_cfg3_graph": lambda dev, rank: HeroCfg3(dev, rank, graph=True, name="hero_cfg3_graph"),

@@ -47,7 +47,7 @@ def camera_path(n, seed=0):
 
 def run(frames=120, height=192, width=256, views=8, device="cuda:0", verbose=True):
     opts = dm.default_options(image_width=width, image_height=height, model_num_views=views)
-    model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder())
+    model = dm.DepthModel(opts)
     for i, m in enumerate((model.encoder, model.matching_model, model.cost_volume_net, model.depth_decoder,
                            model.cost_volume.mlp)):
         synthetic.seeded_fill_(m, seed=20 + i)

@@ -181,6 +181,20 @@ int sr_conv2d_replicate_nhwc_fwd(const float* in, int64_t in_batch_stride, int i
                                  int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
                                  int Cout, int ksize, int stride, float leaky_slope, void* stream);
 
+/* Same operator with explicit zero padding on each side (output size floor((H + top + bottom - ksize) / stride) + 1):
+ * TensorFlow-"SAME" convolutions of the image-prior encoder pad 0 above / left and 1 below / right when a
+ * stride-2 3x3 conv meets an even-sized map.  `leaky_slope` here -- and in every convolution entry point of this
+ * header -- also carries the activation code: >= 0 LeakyReLU slope (0 = ReLU), SR_ACT_NONE = identity,
+ * SR_ACT_SILU = x * sigmoid(x) (the Winograd entry points implement LeakyReLU / identity only). */
+#define SR_ACT_NONE (-1.0f)
+#define SR_ACT_SILU (-2.0f)
+int sr_conv2d_padded_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                              const float* packed_weight, const float* bias, const float* residual,
+                              int64_t res_batch_stride, int res_pix_stride, float* out,
+                              int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                              int Cout, int ksize, int stride, int pad_top, int pad_left, int pad_bottom,
+                              int pad_right, float leaky_slope, void* stream);
+
 /* 3x3 / stride-1 / pad-1 convolution through Winograd F(2x2, 3x3) on the fp32 matrix cores: same operator and
  * epilogue as sr_conv2d_nhwc_fwd (fp32 products and accumulation; 2.25x fewer multiplies).  `packed_u` comes from
  * sr_wino_pack_weights (U = G g G^T in MFMA B-fragment order).  sr_conv_prefers_wino() tells whether this kernel
@@ -299,6 +313,47 @@ int sr_tsdf_integrate_fwd(void* tsdf_values, void* tsdf_weights, const void* vox
                           const uint8_t* depth_mask, const void* K, const void* T, int B, int H, int W,
                           float min_depth, float max_depth, float depth_range, float truncation, float maxW,
                           void* stream);
+
+/* ------------------------------------------------------ image-prior encoder ------------
+ *
+ * timm `tf_efficientnetv2_s` feature pyramid (reference modules/depth_model.py:110-116: the `encoder` of
+ * DepthModel; third-party architecture).  Dense convolutions (stem, ConvBnAct, FusedMBConv, every 1x1) use
+ * sr_conv2d_padded_nhwc_fwd / sr_conv2d_nhwc_fwd with eval-mode BatchNorm folded into weight and bias and
+ * SR_ACT_SILU; the entry points below cover the depthwise / squeeze-excite part of the MBConv blocks.
+ * All tensors channels-last fp32, C % 4 == 0, 16-byte aligned. */
+
+/* Depthwise 3x3 convolution + bias + activation (`leaky_slope` as above).  weight9c: [9][C] tap-major
+ * (= nn.Conv2d(C, C, 3, groups=C).weight[c, 0, ky, kx] at [(ky * 3 + kx) * C + c], BatchNorm scale folded in).
+ * pool_partial (optional): [B][sr_dwconv3x3_pool_bands(Ho)][C] sums of the activated output over bands of
+ * output rows -- the squeeze-excite average pool, finished by sr_se_gate_fwd. */
+int sr_dwconv3x3_pool_bands(int Ho);
+int sr_dwconv3x3_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* weight9c,
+                          const float* bias, float* out, int64_t out_batch_stride, int out_pix_stride,
+                          float* pool_partial, int B, int H, int W, int C, int stride, int pad_top, int pad_left,
+                          int pad_bottom, int pad_right, float leaky_slope, void* stream);
+
+/* Squeeze-excite gate: gate[b, c] = sigmoid(w_expand[c, :] . silu(w_reduce . mean[b, :] + b_reduce) + b_expand[c])
+ * with mean[b, c] = (sum over bands of pool_partial[b, band, c]) / pixels.  w_reduce: [rd][C]; w_expand: [C][rd]. */
+int sr_se_gate_fwd(const float* pool_partial, int bands, int pixels, const float* w_reduce, const float* b_reduce,
+                   const float* w_expand, const float* b_expand, float* gate, int B, int C, int rd, void* stream);
+
+/* The whole squeeze-excite step of an MBConv block in two short launches: hidden[b, j] = silu(w_reduce[j] . mean[b]
+ * + b_reduce[j]) (workspace `hidden`: B * rd floats), then out[b, y, x, c] = in[b, y, x, c] * gate[b, c] with the gate
+ * of sr_se_gate_fwd (also written to `gate` [B][C] when non-null).  rd <= 256; in-place allowed. */
+int sr_se_scale_nhwc_fwd(const float* pool_partial, int bands, const float* w_reduce, const float* b_reduce,
+                         const float* w_expand, const float* b_expand, float* hidden, const float* in,
+                         int64_t in_batch_stride, int in_pix_stride, float* out, int64_t out_batch_stride,
+                         int out_pix_stride, float* gate, int B, int H, int W, int C, int rd, void* stream);
+
+/* out = a + b on channels-last views (in-place allowed): the identity skip of the stage-0 ConvBnAct blocks. */
+int sr_add_nhwc_fwd(const float* a, int64_t a_batch_stride, int a_pix_stride, const float* b, int64_t b_batch_stride,
+                    int b_pix_stride, float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W,
+                    int C, void* stream);
+
+/* out[b, y, x, c] = in[b, y, x, c] * gate[b, c] (in-place allowed). */
+int sr_scale_channels_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* gate,
+                               float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C,
+                               void* stream);
 
 #ifdef __cplusplus
 }

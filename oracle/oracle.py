@@ -315,6 +315,97 @@ def resnet_matching_encoder(img, sd, precision="f32", taps=None):
     return instance_norm(x)
 
 
+# ---------------------------------------------------------------- image-prior encoder (§8f "next" #1) --
+# DepthModel's `encoder` is timm's tf_efficientnetv2_s feature pyramid (experiment_modules/depth_model.py:110-118:
+# `timm.create_model("tf_efficientnetv2_s_in21ft1k", pretrained=True, features_only=True)`, five maps with
+# 24/48/64/160/256 channels at strides 2..32).  timm is an UNPINNED third-party dependency (simplerecon_env.yml:22)
+# absent from /root/reference and from this container: **PARITY UNPINNED**.  What is restated here is the published
+# architecture (Tan & Le, EfficientNetV2, table 4 = timm arch definition `cn_r2_k3_s1_e1_c24_skip / er_r4_k3_s2_e4_c48 /
+# er_r4_k3_s2_e4_c64 / ir_r6_k3_s2_e4_c128_se0.25 / ir_r9_k3_s1_e6_c160_se0.25 / ir_r15_k3_s2_e6_c256_se0.25`,
+# stem 24, SiLU, BatchNorm eps 1e-3 and TF-"SAME" padding for the tf_* weights) with timm's EfficientNetFeatures
+# state-dict names.  Sanity anchors available without timm: 19.85 M parameters in these stages (timm reports
+# 21.46 M for the classifier model = + conv_head 0.33 M + bn 2.6 k + fc 1.28 M), channel list [24,48,64,160,256].
+
+EFFNETV2_S_STAGES = (("cn", 2, 1, 1, 24), ("er", 4, 2, 4, 48), ("er", 4, 2, 4, 64),
+                     ("ir", 6, 2, 4, 128), ("ir", 9, 1, 6, 160), ("ir", 15, 2, 6, 256))
+EFFNETV2_S_FEATURE_STAGES = (0, 1, 2, 4, 5)
+
+
+def silu(x):
+    dt = x.dtype.type
+    with np.errstate(over="ignore"):   # exp(-x) -> inf gives x / inf = -0, the limit
+        return x / (dt(1) + np.exp(-x))
+
+
+def tf_same_pad(x, k, stride):
+    """Zero padding of a TensorFlow-"SAME" conv: out = ceil(in / stride), the odd pixel goes below / right."""
+    def one(i):
+        total = max((-(-i // stride) - 1) * stride + k - i, 0)
+        return total // 2, total - total // 2
+    return np.pad(np.asarray(x), ((0, 0), (0, 0), one(x.shape[2]), one(x.shape[3])))
+
+
+def conv2d_same(x, wgt, stride=1, precision="f32"):
+    k = wgt.shape[-1]
+    return conv2d(tf_same_pad(x, k, stride), wgt, None, stride=stride, pad=0, precision=precision)
+
+
+def dwconv3x3_same(x, wgt, stride=1):
+    """Depthwise 3x3 conv (weight [C,1,3,3]) with TF-"SAME" padding."""
+    xp = tf_same_pad(x, 3, stride)
+    Ho, Wo = (xp.shape[2] - 3) // stride + 1, (xp.shape[3] - 3) // stride + 1
+    w = np.asarray(wgt, dtype=x.dtype)
+    out = np.zeros(x.shape[:2] + (Ho, Wo), x.dtype)
+    for i in range(3):
+        for j in range(3):
+            out += w[None, :, 0, i, j, None, None] * xp[:, :, i:i + stride * Ho:stride, j:j + stride * Wo:stride]
+    return out
+
+
+def _bn_act(x, sd, prefix, act, precision):
+    y = batchnorm_eval(x, sd, prefix, eps=1e-3, precision=precision)
+    return silu(y) if act else y
+
+
+def efficientnetv2_s_features(img, sd, precision="f32", taps=None):
+    """[f2, f4, f8, f16, f32] of the tf_efficientnetv2_s feature extractor for an image batch [B,3,H,W]."""
+    dt, _ = _dt(precision)
+    x = _bn_act(conv2d_same(np.asarray(img, dtype=dt), sd["conv_stem.weight"], 2, precision), sd, "bn1.", True,
+                precision)
+    feats, cin = [], 24
+    for si, (kind, repeats, stride, _e, cout) in enumerate(EFFNETV2_S_STAGES):
+        for bi in range(repeats):
+            pre, s = f"blocks.{si}.{bi}.", (stride if bi == 0 else 1)
+            skip = x if (s == 1 and cin == cout) else None
+            if kind == "cn":      # ConvBnAct: act(bn(conv)) + x
+                y = _bn_act(conv2d_same(x, sd[pre + "conv.weight"], s, precision), sd, pre + "bn1.", True, precision)
+            elif kind == "er":    # FusedMBConv: bn(conv1x1(act(bn(conv3x3)))) + x
+                y = _bn_act(conv2d_same(x, sd[pre + "conv_exp.weight"], s, precision), sd, pre + "bn1.", True,
+                            precision)
+                y = _bn_act(conv2d(y, sd[pre + "conv_pwl.weight"], None, precision=precision), sd, pre + "bn2.",
+                            False, precision)
+            else:                 # MBConv: expand 1x1, depthwise 3x3, squeeze-excite, project 1x1
+                y = _bn_act(conv2d(x, sd[pre + "conv_pw.weight"], None, precision=precision), sd, pre + "bn1.", True,
+                            precision)
+                y = _bn_act(dwconv3x3_same(y, sd[pre + "conv_dw.weight"], s), sd, pre + "bn2.", True, precision)
+                m = y.mean(axis=(2, 3), keepdims=True, dtype=y.dtype)
+                w1, b1 = np.asarray(sd[pre + "se.conv_reduce.weight"], dt), np.asarray(sd[pre + "se.conv_reduce.bias"], dt)
+                w2, b2 = np.asarray(sd[pre + "se.conv_expand.weight"], dt), np.asarray(sd[pre + "se.conv_expand.bias"], dt)
+                h = silu(np.einsum("oc,bc->bo", w1[:, :, 0, 0], m[:, :, 0, 0]) + b1)
+                g = np.einsum("oc,bc->bo", w2[:, :, 0, 0], h) + b2
+                with np.errstate(over="ignore"):
+                    y = y * (dt(1) / (dt(1) + np.exp(-g)))[:, :, None, None]
+                y = _bn_act(conv2d(y, sd[pre + "conv_pwl.weight"], None, precision=precision), sd, pre + "bn3.",
+                            False, precision)
+            x = y + skip if skip is not None else y
+            cin = cout
+            if taps is not None:
+                taps[pre[:-1]] = x
+        if si in EFFNETV2_S_FEATURE_STAGES:
+            feats.append(x)
+    return feats
+
+
 # ---------------------------------------------------------------- TSDF fusion (§8f "next" #2) --
 # Restates tools/tsdf.py (TSDF.from_bounds :69-97, generate_voxel_coords :99-111, TSDFFuser.project_to_camera
 # :218-236, integrate_depth :238-320) as the reference executes it: EVERY tensor is fp16 (OurFuser.fuse_frames

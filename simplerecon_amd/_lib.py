@@ -42,6 +42,16 @@ SIGNATURES = {
     "sr_conv2d_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "sr_conv2d_replicate_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i,
                                           _f, _p]),
+    "sr_conv2d_padded_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i,
+                                       _i, _i, _i, _i, _f, _p]),
+    "sr_dwconv3x3_pool_bands": (_i, [_i]),
+    "sr_dwconv3x3_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f,
+                                   _p]),
+    "sr_add_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "sr_se_scale_nhwc_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _i64, _i, _p, _i, _i, _i, _i, _i,
+                                  _p]),
+    "sr_se_gate_fwd": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "sr_scale_channels_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "sr_wino_packed_weight_floats": (_sz, [_i, _i]),
     "sr_wino_pack_weights": (_i, [_p, _i, _i, _p, _p]),
     "sr_conv_prefers_wino": (_i, [_i, _i, _i, _i, _i, _i, _i]),

@@ -92,6 +92,16 @@ __device__ __forceinline__ bool sr_in_bounds(const SrSample& s, int h, int w) {
   return (s.pix_x > 2.0f) & (s.pix_x < (float)(w - 2)) & (s.pix_y > 2.0f) & (s.pix_y < (float)(h - 2));
 }
 
+// Activation code carried by the `leaky_slope` argument of the convolution entry points (simplerecon_hip.h): a value
+// >= 0 is the LeakyReLU slope (0 = ReLU), SR_ACT_NONE (any value in (-1.5, 0)) the identity, SR_ACT_SILU x * sigmoid(x).
+#ifdef __HIPCC__
+__device__ __forceinline__ float sr_activate(float v, float slope) {
+  if (slope >= 0.0f) return fmaxf(v, 0.0f) + slope * fminf(v, 0.0f);
+  if (slope < -1.5f) return v / (1.0f + __expf(-v));
+  return v;
+}
+#endif
+
 // workspace carving: [geom records | channels-last source features]
 static inline float* sr_ws_geom(void* workspace) { return (float*)sr_align_up((size_t)workspace, 256); }
 static inline float* sr_ws_src_nhwc(void* workspace, int B, int K) {

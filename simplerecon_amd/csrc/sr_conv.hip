@@ -59,7 +59,8 @@ struct SrConvParams {
   float* out; int64_t out_sb; int out_sp;
   int H, W, Cin, Ho, Wo, Cout, Co_pad, G;           // G = 8-channel groups (even, zero padded)
   int tiles_x, tiles_y, co_blocks, total_tiles;
-  float slope;                                      // < 0: no activation
+  float slope;                                      // >= 0: LeakyReLU slope; SR_ACT_NONE; SR_ACT_SILU
+  int pad_y, pad_x;                                 // zero (or replicate) padding above / left of the image
   int vec4;                                         // input rows 16-byte aligned
   int debug;                                        // ablation bits (env SR_CONV_DEBUG), 0 in production
   int replicate;                                    // padding_mode="replicate": halo coordinates clamp to the border
@@ -168,7 +169,6 @@ template <int KS, int S, int MT, int NT, int CM, bool VEC4>
 __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
   using G = SrConvGeom<KS, S, MT, CM>;
   constexpr int TH = G::TH, HW = G::HW, RM = G::RM;
-  constexpr int PAD = KS / 2;
   constexpr int GPS = G::CK / 8;        // 8-channel groups per slab
   constexpr int STEPS = KS * KS * GPS;  // (tap, 8-channel group) steps per slab
   constexpr int ROW = G::ROW;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
     for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
   };
 
-  sr_conv_stage_setup<KS, S, MT, CM>(p, t.oy0 * S - PAD, t.ox0 * S - PAD, offs);
+  sr_conv_stage_setup<KS, S, MT, CM>(p, t.oy0 * S - p.pad_y, t.ox0 * S - p.pad_x, offs);
   sr_conv_stage_load<KS, S, MT, CM, VEC4>(p, p.in + (int64_t)t.b * p.in_sb, 0, offs, stg);
   sr_conv_stage_store<KS, S, MT, CM>(tiles[0], stg);
 #pragma unroll
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
       const bool last = ch + 1 == chunks;
       const bool more = !last || have_next;        // is there a following slab in the pipeline?
       if (more) {
-        if (last) sr_conv_stage_setup<KS, S, MT, CM>(p, tn.oy0 * S - PAD, tn.ox0 * S - PAD, offs);  // next tile
+        if (last) sr_conv_stage_setup<KS, S, MT, CM>(p, tn.oy0 * S - p.pad_y, tn.ox0 * S - p.pad_x, offs);  // next tile
         sr_conv_stage_load<KS, S, MT, CM, VEC4>(p, p.in + (int64_t)(last ? tn.b : t.b) * p.in_sb,
                                             last ? 0 : (ch + 1) * G::CK, offs, stg);
       }
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
             for (int r = 0; r < 16; ++r) {
               const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
               float v = acc[m][n][r] + bv + rv[r];
-              if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
+              v = sr_activate(v, p.slope);
               outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
             }
           } else {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
             for (int r = 0; r < 16; ++r) {
               const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
               float v = acc[m][n][r] + bv + rv[r];
-              if (p.slope >= 0.0f) v = fmaxf(v, 0.0f) + p.slope * fminf(v, 0.0f);
+              v = sr_activate(v, p.slope);
               if (ok[r] && (!SR_CV_DBG(1) || v == 1.2345e33f)) outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
             }
           }
@@ -529,20 +529,26 @@ static int sr_conv2d_dispatch(const float* in, int64_t in_batch_stride, int in_p
                              const float* packed_weight, const float* bias, const float* residual,
                              int64_t res_batch_stride, int res_pix_stride, float* out, int64_t out_batch_stride,
                              int out_pix_stride, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
-                             float leaky_slope, int replicate, void* stream_) {
+                             float leaky_slope, int replicate, void* stream_, const int* pads = nullptr) {
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (B == 0) return SR_OK;
   if (!in || !packed_weight || !out) return SR_ERR_INVALID_ARGUMENT;
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return SR_ERR_UNSUPPORTED;
   const int pad = ksize / 2;
+  // pads = {top, left, bottom, right}; default: ksize / 2 on every side
+  const int pt = pads ? pads[0] : pad, pl = pads ? pads[1] : pad, pb = pads ? pads[2] : pad, pr = pads ? pads[3] : pad;
+  if (pt < 0 || pl < 0 || pb < 0 || pr < 0 || pt >= ksize || pl >= ksize || pb >= ksize || pr >= ksize ||
+      H + pt + pb < ksize || W + pl + pr < ksize)
+    return SR_ERR_INVALID_ARGUMENT;
   SrConvParams p;
   p.in = in; p.in_sb = in_batch_stride; p.in_sp = in_pix_stride;
   p.wp = packed_weight; p.bias = bias;
   p.res = residual; p.res_sb = res_batch_stride; p.res_sp = res_pix_stride;
   p.out = out; p.out_sb = out_batch_stride; p.out_sp = out_pix_stride;
   p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-  p.Ho = (H + 2 * pad - ksize) / stride + 1;
-  p.Wo = (W + 2 * pad - ksize) / stride + 1;
+  p.Ho = (H + pt + pb - ksize) / stride + 1;
+  p.Wo = (W + pl + pr - ksize) / stride + 1;
+  p.pad_y = pt; p.pad_x = pl;
   p.Co_pad = ((Cout + 31) / 32) * 32;
   p.G = ((Cin + sr_ck(ksize) - 1) / sr_ck(ksize)) * (sr_ck(ksize) / 8);
   p.slope = leaky_slope;
@@ -589,6 +595,18 @@ extern "C" int sr_conv2d_replicate_nhwc_fwd(const float* in, int64_t in_batch_st
   return sr_conv2d_dispatch(in, in_batch_stride, in_pix_stride, packed_weight, bias, residual, res_batch_stride,
                             res_pix_stride, out, out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, ksize, stride,
                             leaky_slope, 1, stream_);
+}
+
+extern "C" int sr_conv2d_padded_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                         const float* packed_weight, const float* bias, const float* residual,
+                                         int64_t res_batch_stride, int res_pix_stride, float* out,
+                                         int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                                         int Cout, int ksize, int stride, int pad_top, int pad_left, int pad_bottom,
+                                         int pad_right, float leaky_slope, void* stream_) {
+  const int pads[4] = {pad_top, pad_left, pad_bottom, pad_right};
+  return sr_conv2d_dispatch(in, in_batch_stride, in_pix_stride, packed_weight, bias, residual, res_batch_stride,
+                            res_pix_stride, out, out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, ksize, stride,
+                            leaky_slope, 0, stream_, pads);
 }
 
 // Symbol of the kernel instantiation sr_conv2d_nhwc_fwd picks for these arguments (for profilers / bench).

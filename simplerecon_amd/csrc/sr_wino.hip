@@ -404,12 +404,10 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float4 v = f4add(f4add(y[q], bv), rv[it][q]);
-            if (slope >= 0.0f) {
-              v.x = fmaxf(v.x, 0.0f) + slope * fminf(v.x, 0.0f);
-              v.y = fmaxf(v.y, 0.0f) + slope * fminf(v.y, 0.0f);
-              v.z = fmaxf(v.z, 0.0f) + slope * fminf(v.z, 0.0f);
-              v.w = fmaxf(v.w, 0.0f) + slope * fminf(v.w, 0.0f);
-            }
+            v.x = sr_activate(v.x, slope);
+            v.y = sr_activate(v.y, slope);
+            v.z = sr_activate(v.z, slope);
+            v.w = sr_activate(v.w, slope);
             if (ok[it][q] && (!SR_WN_DBG(1) || v.x == 1.2345e33f))
               *reinterpret_cast<float4*>(outp + (opix[it][q] * out_sp + cog)) = v;
           }
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float v = y[q] + bv + rv[it][q];
-            if (slope >= 0.0f) v = fmaxf(v, 0.0f) + slope * fminf(v, 0.0f);
+            v = sr_activate(v, slope);
             if (ok[it][q] && (!SR_WN_DBG(1) || v == 1.2345e33f)) outp[opix[it][q] * out_sp + cog] = v;
           }
         }
@@ -494,12 +492,10 @@ __global__ __launch_bounds__(256) void sr_wino_reduce_kernel(const float* __rest
     for (int k = 1; k < ksplit; ++k) v = f4add(v, *reinterpret_cast<const float4*>(q + k * part_stride));
     if (bias) v = f4add(v, *reinterpret_cast<const float4*>(bias + 4 * c4));
     if (res) v = f4add(v, *reinterpret_cast<const float4*>(res + (int64_t)b * res_sb + px * res_sp + 4 * c4));
-    if (slope >= 0.0f) {
-      v.x = fmaxf(v.x, 0.0f) + slope * fminf(v.x, 0.0f);
-      v.y = fmaxf(v.y, 0.0f) + slope * fminf(v.y, 0.0f);
-      v.z = fmaxf(v.z, 0.0f) + slope * fminf(v.z, 0.0f);
-      v.w = fmaxf(v.w, 0.0f) + slope * fminf(v.w, 0.0f);
-    }
+    v.x = sr_activate(v.x, slope);
+    v.y = sr_activate(v.y, slope);
+    v.z = sr_activate(v.z, slope);
+    v.w = sr_activate(v.w, slope);
     *reinterpret_cast<float4*>(out + (int64_t)b * out_sb + px * out_sp + 4 * c4) = v;
   }
 }

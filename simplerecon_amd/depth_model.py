@@ -5,11 +5,13 @@ without the PyTorch-Lightning / losses / training machinery (out of scope, SURVE
     model = DepthModel(opts)                      # opts: reference options.Options or default_options()
     outputs = model("test", cur_data, src_data, unbatched_matching_encoder_forward=True, return_mask=True)
 
-The matching encoder (antialiased ResNet-18 stem + InstanceNorm tail, reference networks.py:149-205,
-SURVEY.md §8 a16) is built natively (networks.ResnetMatchingEncoder, HIP kernels).  The image-prior
-encoder (timm EfficientNetV2-S, reference depth_model.py:110-116) is a third-party model outside this
-path (SURVEY.md §8f "next" #1): it is pluggable, and by default the reference's own constructor is
-used when timm is importable.  `hot_path()` -- what bench.py times -- starts from the encoders' outputs.
+Both encoders are built natively on the HIP kernels: the matching encoder (antialiased ResNet-18 stem +
+InstanceNorm tail, reference networks.py:149-205) = networks.ResnetMatchingEncoder, and
+the image-prior encoder (timm tf_efficientnetv2_s feature pyramid, reference depth_model.py:110-116,
+SURVEY.md §8f "next" #1) = image_encoder.EfficientNetV2SFeatures (third-party architecture restated from
+its public definition; timm's parameter names, so `encoder.*` checkpoint entries load).  Both stay
+pluggable (`image_encoder=`, `matching_encoder=`); `timm_image_encoder()` builds the reference's own
+constructor call when timm is importable.  `hot_path()` starts from the encoders' outputs.
 """
 from dataclasses import dataclass
 
@@ -19,6 +21,7 @@ from torch import nn
 from .cost_volume import CostVolumeManager, FeatureVolumeManager
 from .layers import TensorFormatter
 from . import ops
+from .image_encoder import EfficientNetV2SFeatures
 from .networks import CVEncoder, DepthDecoderPP, ResnetMatchingEncoder
 
 
@@ -48,6 +51,21 @@ def default_options(**kw):
 IMAGE_PRIOR_CHANNELS = [24, 48, 64, 160, 256]  # tf_efficientnetv2_s features_only (depth_model.py:110-118)
 
 
+class PendingPyramid:
+    """The image-prior pyramid while its encoder is still running on a side HIP stream.  The pyramid is first needed
+    by the CVEncoder, AFTER the matching encoder and the plane sweep: `wait()` joins the side stream into the
+    current one at that point, so the encoder's many small, latency-bound launches overlap the big kernels of the
+    main stream.  (The side stream always forks from the main stream first -- `side.wait_stream(main)` -- which also
+    orders the allocator's reuse of the pyramid buffers behind the previous frame's consumers.)"""
+
+    def __init__(self, stream, feats):
+        self.stream, self.feats = stream, list(feats)
+
+    def wait(self):
+        torch.cuda.current_stream(self.feats[0].device).wait_stream(self.stream)
+        return self.feats
+
+
 def tensor_B_to_bM(t, batch_size, num_views):
     return t.view([batch_size, num_views] + list(t.shape[1:]))  # reference generic_utils.py:110-118
 
@@ -56,13 +74,15 @@ def tensor_bM_to_B(t):
     return t.view([t.shape[0] * t.shape[1]] + list(t.shape[2:]))  # reference generic_utils.py:121-130
 
 
-def _reference_image_encoder():
+def timm_image_encoder(pretrained=True):
+    """The reference's own constructor call (depth_model.py:110-116) -- a torch module, NOT the HIP path; for
+    side-by-side checks on machines that have timm."""
     try:
         import timm
     except ImportError as e:
-        raise ImportError("the image-prior encoder needs `timm` (reference depth_model.py:110-116); pass "
-                          "image_encoder=... to DepthModel to plug in another 5-scale pyramid encoder") from e
-    enc = timm.create_model("tf_efficientnetv2_s_in21ft1k", pretrained=True, features_only=True)
+        raise ImportError("timm is not installed; DepthModel's default image-prior encoder is the native "
+                          "image_encoder.EfficientNetV2SFeatures") from e
+    enc = timm.create_model("tf_efficientnetv2_s_in21ft1k", pretrained=pretrained, features_only=True)
     enc.num_ch_enc = enc.feature_info.channels()
     return enc
 
@@ -74,7 +94,7 @@ class DepthModel(nn.Module):
         if image_encoder is None:
             if "efficientnet" not in opts.image_encoder_name:
                 raise ValueError("Unrecognized option for image encoder type!")
-            image_encoder = _reference_image_encoder()
+            image_encoder = EfficientNetV2SFeatures()
         self.encoder = image_encoder
         num_ch_enc = list(getattr(self.encoder, "num_ch_enc", IMAGE_PRIOR_CHANNELS))
 
@@ -120,6 +140,9 @@ class DepthModel(nn.Module):
         self.num_streams = 1
         self._streams = {}
         self._range_cache = {}
+        # run the image-prior encoder on a side HIP stream, concurrently with matching encoder + plane sweep
+        self.prior_on_side_stream = True
+        self._prior_streams = {}
 
     # ---- reference depth_model.py:191-245 ----------------------------------------------------
     def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward):
@@ -141,6 +164,8 @@ class DepthModel(nn.Module):
         DepthDecoderPP -> exp.  `cur_feats` is the image-prior pyramid (list of 5)."""
         b = matching_cur_feats.shape[0]
         n = min(self.num_streams, b)
+        if n > 1 and isinstance(cur_feats, PendingPyramid):
+            cur_feats = cur_feats.wait()
         if n <= 1:
             return self._hot_path_one(cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
                                       cur_cam_T_src_cam, src_K, cur_invK, return_mask, flip)
@@ -189,17 +214,21 @@ class DepthModel(nn.Module):
 
     def graphed(self, cur_image, src_image, cur_feats, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK,
                 return_mask=False):
-        """HIP-graph version of `matching encoder -> hot_path` for fixed shapes: returns a
-        `graph.GraphedCallable` taking (cur_image, src_image, cur_feats (pyramid list), src_cam_T_cur_cam,
-        cur_cam_T_src_cam, src_K, cur_invK).  One submission per keyframe batch instead of ~230 launches."""
+        """HIP-graph version of `forward_tensors` for fixed shapes: returns a `graph.GraphedCallable` taking
+        (cur_image, src_image, cur_feats, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK).  cur_feats=None:
+        the image-prior encoder runs inside the graph (the whole model, ~430 launches, in one submission per keyframe
+        batch); cur_feats = a pyramid list: it is an input and only matching encoder -> hot_path are captured."""
         from .graph import GraphedCallable
 
         def step(cur_image, src_image, cur_feats, src_T_cur, cur_T_src, src_K, cur_invK):
+            if cur_feats is None:
+                return self.forward_tensors(cur_image, src_image, src_T_cur, cur_T_src, src_K, cur_invK,
+                                            return_mask=return_mask)
             mc, ms = self.compute_matching_feats(cur_image, src_image, False)
             return self.hot_path(list(cur_feats), mc, ms, src_T_cur, cur_T_src, src_K, cur_invK,
                                  return_mask=return_mask)
-        return GraphedCallable(step, cur_image, src_image, list(cur_feats), src_cam_T_cur_cam, cur_cam_T_src_cam,
-                               src_K, cur_invK)
+        return GraphedCallable(step, cur_image, src_image, None if cur_feats is None else list(cur_feats),
+                               src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK)
 
     def _hot_path_one(self, cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam, cur_cam_T_src_cam,
                       src_K, cur_invK, return_mask=False, flip=False):
@@ -211,6 +240,8 @@ class DepthModel(nn.Module):
             max_depth=max_depth, return_mask=return_mask)
         if flip:
             cost_volume = torch.flip(cost_volume, (-1,))
+        if isinstance(cur_feats, PendingPyramid):
+            cur_feats = cur_feats.wait()
         cost_volume_features = self.cost_volume_net(cost_volume, cur_feats[o.matching_scale:])
         feats = list(cur_feats[:o.matching_scale]) + cost_volume_features
         depth_outputs = self.depth_decoder(feats)
@@ -238,13 +269,35 @@ class DepthModel(nn.Module):
         if flip:
             cur_image = torch.flip(cur_image, (-1,))
             src_image = torch.flip(src_image, (-1,))
-        cur_feats = self.encoder(cur_image)
+        return self.forward_tensors(cur_image, src_image, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK,
+                                    unbatched_matching_encoder_forward=unbatched_matching_encoder_forward,
+                                    return_mask=return_mask, flip=flip)
+
+    def image_prior_pyramid(self, cur_image):
+        """`self.encoder(cur_image)` (reference depth_model.py:358), launched on a side HIP stream when the encoder
+        runs HIP kernels on the GPU: returns a PendingPyramid that hot_path() joins where the pyramid is consumed."""
+        if not (self.prior_on_side_stream and cur_image.is_cuda and isinstance(self.encoder, EfficientNetV2SFeatures)):
+            return list(self.encoder(cur_image))
+        dev = cur_image.device
+        side = self._prior_streams.get(dev)
+        if side is None:
+            side = self._prior_streams[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            feats = self.encoder(cur_image)
+        return PendingPyramid(side, feats)
+
+    def forward_tensors(self, cur_image, src_image, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK,
+                        unbatched_matching_encoder_forward=False, return_mask=False, flip=False):
+        """DepthModel.forward after the dict unpacking / relative-pose step (reference depth_model.py:358-405):
+        image-prior encoder, matching encoder, cost volume, CVEncoder, decoder, exp -- every stage on HIP kernels."""
+        cur_feats = self.image_prior_pyramid(cur_image)
         matching_cur_feats, matching_src_feats = self.compute_matching_feats(
             cur_image, src_image, unbatched_matching_encoder_forward)
         if flip:
             matching_cur_feats = torch.flip(matching_cur_feats, (-1,))
             matching_src_feats = torch.flip(matching_src_feats, (-1,))
-        return self.hot_path(list(cur_feats), matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
+        return self.hot_path(cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
                              cur_cam_T_src_cam, src_K, cur_invK, return_mask=return_mask, flip=flip)
 
 

@@ -28,6 +28,27 @@ def conv_out_hw(h, w, stride, ksize=3):
     return (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
 
 
+def tf_same_pads(h, w, ksize, stride):
+    """(top, left, bottom, right) zero padding of a TensorFlow-"SAME" convolution: output size ceil(i / stride),
+    the odd pixel of padding goes below / right (what timm's Conv2dSame computes per call for its tf_* models)."""
+    def one(i):
+        total = max((-(-i // stride) - 1) * stride + ksize - i, 0)
+        return total // 2, total - total // 2
+    (pt, pb), (pl, pr) = one(h), one(w)
+    return pt, pl, pb, pr
+
+
+def _act_code(leaky, act):
+    """The activation code the C ABI carries in `leaky_slope` (include/simplerecon_hip.h)."""
+    if act is None:
+        return -1.0 if leaky is None else float(leaky)
+    if leaky is not None:
+        raise ValueError("pass either `leaky` or `act`, not both")
+    if act == "silu":
+        return -2.0
+    raise ValueError(f"unknown activation {act!r}")
+
+
 def _is_nhwc_view(t):
     if t.dim() != 4:
         return False
@@ -173,9 +194,11 @@ def packed_wino_weight(conv: nn.Conv2d, bn=None):
     return packed, bias
 
 
-def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None):
+def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act=None, tf_same=False):
     """act(bn(conv(x) + bias) [+ residual]) with nn.Conv2d semantics (zero or replicate padding); `bn` is an
-    eval-mode BatchNorm2d folded into weight and bias.  Returns a channels-last view."""
+    eval-mode BatchNorm2d folded into weight and bias.  `leaky` = LeakyReLU slope, or act="silu".  tf_same=True
+    replaces the module's symmetric padding by TensorFlow-"SAME" padding (tf_same_pads).  Returns a channels-last
+    view."""
     _lib.refuse_autograd(x, conv.weight)
     x = as_nhwc(x, "conv input")
     b, ci, h, w = x.shape
@@ -184,7 +207,8 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None):
     k, s = conv.kernel_size[0], conv.stride[0]
     if conv.stride[0] != conv.stride[1] or s not in (1, 2):
         raise _lib.HipLibraryError(f"unsupported stride {conv.stride}")
-    ho, wo = conv_out_hw(h, w, s, k)
+    pads = tf_same_pads(h, w, k, s) if tf_same else (k // 2,) * 4
+    ho, wo = (h + pads[0] + pads[2] - k) // s + 1, (w + pads[1] + pads[3] - k) // s + 1
     co = conv.out_channels
     if out is None:
         out = empty_nhwc(b, co, ho, wo, x.device)
@@ -194,7 +218,10 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None):
         _lib.require_device_f32("out", out)
     lib = _lib.lib()
     replicate = conv.padding_mode == "replicate"
-    use_wino = (not replicate) and bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, s))
+    padded = pads != (k // 2,) * 4
+    if padded and replicate:
+        raise _lib.HipLibraryError("explicit padding is implemented for zero padding only")
+    use_wino = (not replicate) and (not padded) and bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, s))
     wp, bias = packed_wino_weight(conv, bn) if use_wino else packed_weight(conv, bn)
     if residual is not None:
         residual = as_nhwc(residual, "residual")
@@ -205,13 +232,27 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None):
     isb, isp = _strides(x)
     osb, osp = _strides(out)
     rsb, rsp = _strides(residual) if residual is not None else (0, 0)
+    if k == 1 and s == 1 and (w % 32 != 0 or h % 4 != 0) and (isp, isb) == (ci, h * w * ci) \
+            and (osp, osb) == (co, h * w * co) and (residual is None or (rsp, rsb) == (co, h * w * co)):
+        # a 1x1 conv over dense channels-last maps is a [B*H*W, Cin] x [Cin, Cout] product: hand the kernel the
+        # pixels as one 32- (or 8-) wide strip so that no output tile is cut at image borders (15x20 maps would
+        # leave 37 % of every 4x32 tile empty).  Same per-pixel arithmetic, same result.
+        m = b * h * w
+        fw = 32 if m % 32 == 0 else 8 if m % 8 == 0 else 0
+        if fw:
+            b, h, w, ho, wo = 1, m // fw, fw, m // fw, fw
+            isb, osb, rsb = m * ci, m * co, (m * co if residual is not None else 0)
     prof = PROFILE
-    slope = C.c_float(-1.0 if leaky is None else float(leaky))
+    slope = C.c_float(_act_code(leaky, act))
     with torch.cuda.device(x.device):
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if use_wino:
+        if padded:
+            rc = lib.sr_conv2d_padded_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
+                                               rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, *pads, slope,
+                                               _lib.stream_ptr(x.device))
+        elif use_wino:
             nbytes = lib.sr_wino_splitk_workspace_bytes(b, h, w, ci, co)   # 0 unless the launch plan splits K
             ws = _workspace(x.device, "wino_splitk", nbytes) if nbytes else None
             rc = lib.sr_conv3x3_wino_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
@@ -468,3 +509,152 @@ def conv3x3_c16(x, conv: nn.Conv2d, in_stats=None, in_leaky=None, leaky=None):
                          2.0 * b * ((h + 7) // 8) * ((w + 15) // 16) * 128 * 16 * ci * 9))
     _lib.check(rc, "sr_conv3x3_c16_nhwc_fwd")
     return out
+
+
+# ---- MBConv pieces of the image-prior encoder (csrc/sr_mbconv.hip) -----------------------------------------------
+
+_PACKED_DW = weakref.WeakKeyDictionary()  # depthwise nn.Conv2d -> (state key, [9, C] weight, bias)
+
+
+def packed_dw_weight(conv: nn.Conv2d, bn=None):
+    """([9, C] tap-major depthwise weight with the eval-mode BatchNorm scale folded in, bias); cached."""
+    _lib.require_device_f32("depthwise conv weight", conv.weight)
+    c = conv.in_channels
+    if conv.kernel_size != (3, 3) or conv.groups != c or conv.out_channels != c or conv.dilation != (1, 1) \
+            or conv.padding_mode != "zeros":
+        raise _lib.HipLibraryError(f"unsupported depthwise Conv2d configuration for the HIP path: {conv}")
+    key = _state_key(conv, bn)
+    hit = _PACKED_DW.get(conv)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    w, bias = _effective_weight(conv, bn)                      # [C, 1, 3, 3]
+    w9c = w.reshape(c, 9).t().contiguous()
+    bias = bias.contiguous() if bias is not None else None
+    _PACKED_DW[conv] = (key, w9c, bias)
+    return w9c, bias
+
+
+def dwconv3x3(x, conv: nn.Conv2d, bn=None, leaky=None, act=None, tf_same=False, want_pool=False):
+    """act(bn(depthwise_conv3x3(x))) on a channels-last view; with want_pool also returns the per-band partial sums
+    of the result ([B, bands, C]) from which `se_gate` finishes the squeeze-excite average pool."""
+    _lib.refuse_autograd(x, conv.weight)
+    x = as_nhwc(x, "depthwise conv input")
+    b, c, h, w = x.shape
+    if c != conv.in_channels:
+        raise ValueError(f"depthwise conv expects {conv.in_channels} channels, got {c}")
+    s = conv.stride[0]
+    if conv.stride[0] != conv.stride[1] or s not in (1, 2):
+        raise _lib.HipLibraryError(f"unsupported stride {conv.stride}")
+    if not tf_same and tuple(conv.padding) != (1, 1):
+        raise _lib.HipLibraryError(f"unsupported padding {conv.padding}")
+    pads = tf_same_pads(h, w, 3, s) if tf_same else (1, 1, 1, 1)
+    ho, wo = (h + pads[0] + pads[2] - 3) // s + 1, (w + pads[1] + pads[3] - 3) // s + 1
+    w9c, bias = packed_dw_weight(conv, bn)
+    lib = _lib.lib()
+    out = empty_nhwc(b, c, ho, wo, x.device)
+    bands = lib.sr_dwconv3x3_pool_bands(ho)
+    pool = torch.empty((b, bands, c), dtype=torch.float32, device=x.device) if want_pool else None
+    if b > 0:
+        isb, isp = _strides(x)
+        osb, osp = _strides(out)
+        with torch.cuda.device(x.device):
+            rc = lib.sr_dwconv3x3_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(w9c), _lib.ptr(bias), _lib.ptr(out), osb,
+                                           osp, _lib.ptr(pool), b, h, w, c, s, *pads,
+                                           C.c_float(_act_code(leaky, act)), _lib.stream_ptr(x.device))
+        _lib.check(rc, "sr_dwconv3x3_nhwc_fwd")
+    return (out, pool) if want_pool else out
+
+
+def se_gate(pool_partial, pixels, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2d):
+    """sigmoid(conv_expand(silu(conv_reduce(mean)))) per image from dwconv3x3's partial sums: [B, C] gates."""
+    _lib.require_device_f32("pool partial sums", pool_partial)
+    b, bands, c = pool_partial.shape
+    rd = conv_reduce.out_channels
+    if conv_reduce.kernel_size != (1, 1) or conv_expand.kernel_size != (1, 1) or conv_reduce.in_channels != c \
+            or conv_expand.in_channels != rd or conv_expand.out_channels != c:
+        raise _lib.HipLibraryError("squeeze-excite expects 1x1 convs C -> rd -> C")
+    _lib.refuse_autograd(pool_partial, conv_reduce.weight, conv_expand.weight)
+    gate = torch.empty((b, c), dtype=torch.float32, device=pool_partial.device)
+    if b == 0:
+        return gate
+    w1 = conv_reduce.weight.detach().reshape(rd, c)
+    w2 = conv_expand.weight.detach().reshape(c, rd)
+    b1 = conv_reduce.bias.detach() if conv_reduce.bias is not None else None
+    b2 = conv_expand.bias.detach() if conv_expand.bias is not None else None
+    for t in (w1, w2):
+        _lib.require_device_f32("squeeze-excite weight", t)
+    with torch.cuda.device(gate.device):
+        rc = _lib.lib().sr_se_gate_fwd(_lib.ptr(pool_partial.contiguous()), bands, pixels, _lib.ptr(w1.contiguous()),
+                                       _lib.ptr(b1), _lib.ptr(w2.contiguous()), _lib.ptr(b2), _lib.ptr(gate), b, c, rd,
+                                       _lib.stream_ptr(gate.device))
+    _lib.check(rc, "sr_se_gate_fwd")
+    return gate
+
+
+def se_scale_(x, pool_partial, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2d, want_gate=False):
+    """x *= squeeze-excite gate, in place on a channels-last view (se_gate + scale_channels_ in two short launches)."""
+    _lib.require_device_f32("pool partial sums", pool_partial)
+    if not _is_nhwc_view(x):
+        raise ValueError("se_scale_ needs a channels-last view")
+    b, c, h, w = x.shape
+    rd = conv_reduce.out_channels
+    if conv_reduce.kernel_size != (1, 1) or conv_expand.kernel_size != (1, 1) or conv_reduce.in_channels != c \
+            or conv_expand.in_channels != rd or conv_expand.out_channels != c or pool_partial.shape[0] != b \
+            or pool_partial.shape[2] != c or not pool_partial.is_contiguous():
+        raise _lib.HipLibraryError("squeeze-excite expects 1x1 convs C -> rd -> C and [B, bands, C] partial sums")
+    _lib.refuse_autograd(x, pool_partial, conv_reduce.weight, conv_expand.weight)
+    gate = torch.empty((b, c), dtype=torch.float32, device=x.device) if want_gate else None
+    if b == 0:
+        return (x, gate) if want_gate else x
+    hidden = torch.empty((b, rd), dtype=torch.float32, device=x.device)
+    w1, w2 = conv_reduce.weight.detach(), conv_expand.weight.detach()
+    if not (w1.is_contiguous() and w2.is_contiguous()):
+        w1, w2 = w1.contiguous(), w2.contiguous()
+    b1 = conv_reduce.bias.detach() if conv_reduce.bias is not None else None
+    b2 = conv_expand.bias.detach() if conv_expand.bias is not None else None
+    sb, sp = _strides(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().sr_se_scale_nhwc_fwd(_lib.ptr(pool_partial), pool_partial.shape[1], _lib.ptr(w1), _lib.ptr(b1),
+                                             _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(hidden), _lib.ptr(x), sb, sp,
+                                             _lib.ptr(x), sb, sp, _lib.ptr(gate), b, h, w, c, rd,
+                                             _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_se_scale_nhwc_fwd")
+    return (x, gate) if want_gate else x
+
+
+def scale_channels_(x, gate):
+    """x[b, c, :, :] *= gate[b, c] in place on a channels-last view."""
+    _lib.require_device_f32("gate", gate)
+    if not _is_nhwc_view(x):
+        raise ValueError("scale_channels_ needs a channels-last view")
+    _lib.refuse_autograd(x, gate)
+    b, c, h, w = x.shape
+    if tuple(gate.shape) != (b, c) or not gate.is_contiguous():
+        raise ValueError(f"gate must be a contiguous [{b}, {c}] tensor")
+    if b == 0:
+        return x
+    sb, sp = _strides(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().sr_scale_channels_nhwc_fwd(_lib.ptr(x), sb, sp, _lib.ptr(gate), _lib.ptr(x), sb, sp, b, h, w, c,
+                                                   _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_scale_channels_nhwc_fwd")
+    return x
+
+
+def add_(y, x):
+    """y += x on channels-last views (same shape)."""
+    _lib.require_device_f32("y", y)
+    x = as_nhwc(x, "x")
+    if not _is_nhwc_view(y) or tuple(x.shape) != tuple(y.shape):
+        raise ValueError("add_ needs two channels-last views of the same shape")
+    _lib.refuse_autograd(x, y)
+    b, c, h, w = y.shape
+    if b == 0:
+        return y
+    ysb, ysp = _strides(y)
+    xsb, xsp = _strides(x)
+    with torch.cuda.device(y.device):
+        rc = _lib.lib().sr_add_nhwc_fwd(_lib.ptr(y), ysb, ysp, _lib.ptr(x), xsb, xsp, _lib.ptr(y), ysb, ysp, b, h, w, c,
+                                        _lib.stream_ptr(y.device))
+    _lib.check(rc, "sr_add_nhwc_fwd")
+    return y

@@ -56,6 +56,57 @@ def test_hot_path_matches_oracle_chain(fvt):
     assert out["lowest_cost_bhw"].shape == (B, h, w)
 
 
+def test_forward_all_native_matches_oracle_chain():
+    """DepthModel.forward with BOTH encoders native (default construction) against the whole chain through the CPU
+    oracle: EfficientNetV2-S pyramid, ResnetMatchingEncoder on cur + source images, metadata-MLP sweep, CVEncoder,
+    DepthDecoderPP, exp."""
+    B, K, H, W, D = 1, 2, 96, 128, 8
+    h, w = H // 4, W // 4
+    opts = dm.default_options(image_width=W, image_height=H, model_num_views=K + 1, matching_num_depth_bins=D)
+    model = dm.DepthModel(opts)
+    assert type(model.encoder).__name__ == "EfficientNetV2SFeatures"
+    assert type(model.matching_model).__name__ == "ResnetMatchingEncoder"
+    synthetic.seeded_fill_(model.encoder, seed=6, gain=1.0)
+    for i, m in enumerate((model.matching_model, model.cost_volume_net, model.depth_decoder, model.cost_volume.mlp)):
+        synthetic.seeded_fill_(m, seed=20 + i)
+    model = model.to(DEV).eval()
+    inp = synthetic.cost_volume_inputs(B, K, 16, h, w, seed=4)
+    g = torch.Generator().manual_seed(8)
+    cur_img, src_img = torch.randn((B, 3, H, W), generator=g), torch.randn((B, K, 3, H, W), generator=g)
+    eye = torch.eye(4).expand(B, 4, 4).contiguous()
+    cur = {"image_b3hw": cur_img.to(DEV), "invK_s1_b44": inp["cur_invK"].to(DEV), "cam_T_world_b44": eye.to(DEV),
+           "world_T_cam_b44": eye.to(DEV)}
+    src = {"image_b3hw": src_img.to(DEV), "K_s1_b44": inp["src_Ks"].to(DEV),
+           "cam_T_world_b44": inp["src_extrinsics"].to(DEV), "world_T_cam_b44": inp["src_poses"].to(DEV)}
+    with torch.inference_mode():
+        out = model("test", cur, src, return_mask=True)
+        unb = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+    torch.cuda.synchronize()
+
+    def sd(m):
+        return {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+    n = {k: v.numpy() for k, v in inp.items()}
+    pyr = oracle.efficientnetv2_s_features(cur_img.numpy(), sd(model.encoder))
+    msd = sd(model.matching_model)
+    mcur = oracle.resnet_matching_encoder(cur_img.numpy(), msd)
+    msrc = oracle.resnet_matching_encoder(src_img.numpy().reshape(B * K, 3, H, W), msd).reshape(B, K, 16, h, w)
+    planes = model.cost_volume.generate_depth_planes(B, inp["min_depth"].to(DEV), inp["max_depth"].to(DEV))
+    planes = planes[:, :, 0, 0].cpu().numpy()
+    ms = sd(model.cost_volume.mlp)
+    mlp = dict(W1=ms["net.0.weight"], b1=ms["net.0.bias"], W2=ms["net.2.weight"], b2=ms["net.2.bias"],
+               W3=ms["net.4.weight"], b3=ms["net.4.bias"])
+    vol, low, mask = oracle.mlp_volume(mcur, msrc, n["src_Ks"], n["src_extrinsics"], n["src_poses"], n["cur_invK"],
+                                       planes, mlp, want_mask=True)
+    feats = oracle.cv_encoder(vol, pyr[1:], sd(model.cost_volume_net))
+    ref = oracle.depth_decoder_pp([pyr[0]] + feats, sd(model.depth_decoder))
+    assert mismatch_fraction(out["overall_mask_bhw"], mask) == 0.0
+    for i in range(4):
+        k = f"log_depth_pred_s{i}_b1hw"
+        assert_close(out[k], ref[k], what=k)
+        assert_close(out[k.replace("log_", "")], np.exp(ref[k]), what="depth " + k)
+        assert_close(unb[k], ref[k], what=k + " (unbatched matching encoder)")
+
+
 def test_forward_api_with_stand_in_encoders():
     """DepthModel.forward keeps the reference's call signature and output keys (depth_model.py:247-407)."""
     B, K, H, W = 1, 2, 96, 128

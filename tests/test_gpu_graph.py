@@ -47,3 +47,32 @@ def test_graphed_step_equals_eager_and_follows_new_inputs():
             assert torch.equal(out[k], ref[k]), k   # same kernels, same order: bit-identical
     with pytest.raises(ValueError):
         graphed(*(t[:1] if isinstance(t, torch.Tensor) else [f[:1] for f in t] for t in a))
+
+
+def test_whole_model_graph_with_side_stream_prior_encoder():
+    """cur_feats=None: the image-prior encoder (on its side stream) is captured with the rest of forward_tensors."""
+    B, K, D, h, w = 1, 2, 8, 24, 32
+    opts = dm.default_options(image_width=4 * w, image_height=4 * h, model_num_views=K + 1, matching_num_depth_bins=D)
+    model = dm.DepthModel(opts)
+    synthetic.seeded_fill_(model.encoder, seed=9, gain=1.0)
+    for i, m in enumerate((model.matching_model, model.cost_volume_net, model.depth_decoder, model.cost_volume.mlp)):
+        synthetic.seeded_fill_(m, seed=10 + i)
+    model = model.to(DEV).eval()
+    a, b = _inputs(B, K, h, w, 3), _inputs(B, K, h, w, 4)
+
+    def eager(cur, src, _pyr, ext, poses, Ks, invK, side):
+        model.prior_on_side_stream = side
+        with torch.inference_mode():
+            out = model.forward_tensors(cur, src, ext, poses, Ks, invK, return_mask=True)
+            return {k: (v.clone() if v is not None else None) for k, v in out.items()}
+    ref_a, ref_b = eager(*a, side=True), eager(*b, side=True)
+    same_stream = eager(*a, side=False)
+    for k in ref_a:
+        assert same_stream[k] is None and ref_a[k] is None or torch.equal(same_stream[k], ref_a[k]), k
+    model.prior_on_side_stream = True
+    graphed = model.graphed(a[0], a[1], None, *a[3:], return_mask=True)
+    for inputs, ref in ((a, ref_a), (b, ref_b), (a, ref_a)):
+        out = graphed(inputs[0], inputs[1], None, *inputs[3:])
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), k
