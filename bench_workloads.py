@@ -185,6 +185,8 @@ class HeroCfg3:
             synthetic.seeded_fill_(model.cost_volume.mlp, seed=3)
         self.model = model.to(dev).eval()
         self.model.num_streams = streams
+        if os.environ.get("SR_PRIOR_SIDE"):   # experiment switch: image-prior encoder on the main stream (0) / a side stream (1)
+            self.model.prior_on_side_stream = os.environ["SR_PRIOR_SIDE"] != "0"
         inp = synthetic.cost_volume_inputs(self.B, self.K, self.Cc, self.h, self.w, seed=rank, device=dev)
         self.inp = inp
         self.pyramid = [f.contiguous(memory_format=torch.channels_last) for f in

@@ -195,6 +195,20 @@ int sr_conv2d_padded_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_p
                               int Cout, int ksize, int stride, int pad_top, int pad_left, int pad_bottom,
                               int pad_right, float leaky_slope, void* stream);
 
+/* sr_conv2d_nhwc_fwd with a split-K launch plan for 1x1 / stride-1 convolutions whose long input-channel chain would
+ * otherwise run on a handful of workgroups (e.g. 1536 -> 256 channels on 8 x 15x20 pixels): the channel slabs of a
+ * tile are spread over up to 8 work items that store raw partial sums into `workspace`, and a second launch adds them
+ * in index order (deterministic) and applies bias / residual / activation.  sr_conv_splitk_workspace_bytes() returns
+ * the workspace size for a shape, 0 when the plan would not split (then this entry point equals sr_conv2d_nhwc_fwd
+ * and `workspace` may be NULL). */
+size_t sr_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int sr_conv2d_splitk_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                              const float* packed_weight, const float* bias, const float* residual,
+                              int64_t res_batch_stride, int res_pix_stride, float* out,
+                              int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                              int Cout, int ksize, int stride, float leaky_slope, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* 3x3 / stride-1 / pad-1 convolution through Winograd F(2x2, 3x3) on the fp32 matrix cores: same operator and
  * epilogue as sr_conv2d_nhwc_fwd (fp32 products and accumulation; 2.25x fewer multiplies).  `packed_u` comes from
  * sr_wino_pack_weights (U = G g G^T in MFMA B-fragment order).  sr_conv_prefers_wino() tells whether this kernel

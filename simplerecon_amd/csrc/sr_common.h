@@ -113,5 +113,10 @@ int sr_launch_geom(const float* K_src, const float* T_src_cur, const float* T_cu
                    int n, hipStream_t stream);
 int sr_launch_argmax_planes(const float* cv, int64_t sb, int64_t sd, int64_t sp, SrPlanes planes, int B, int h, int w,
                             int D, float* lowest, hipStream_t stream);
+// out = act(sum_k part[k * part_stride + ...] + bias + res): finish of a split-K convolution (partials dense
+// channels-last [B, HW, Cout], Cout % 4 == 0, 16-byte aligned operands); defined in sr_wino.hip
+int sr_launch_splitk_reduce(const float* part, int ksplit, int64_t part_stride, const float* bias, const float* res,
+                            int64_t res_sb, int res_sp, float* out, int64_t out_sb, int out_sp, int B, int HW, int Cout,
+                            float slope, hipStream_t stream);
 int sr_launch_pack_nhwc(const float* src_nchw, float* dst_nhwc, int images, int C, int npix,
                         hipStream_t stream);

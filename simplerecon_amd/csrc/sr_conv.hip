@@ -64,6 +64,10 @@ struct SrConvParams {
   int vec4;                                         // input rows 16-byte aligned
   int debug;                                        // ablation bits (env SR_CONV_DEBUG), 0 in production
   int replicate;                                    // padding_mode="replicate": halo coordinates clamp to the border
+  // split-K (1x1 convs with a long channel chain on few tiles): a work item covers 1/ksplit of the input slabs and
+  // stores its raw partial sums (no bias / residual / activation) to part + ks * part_stride, dense channels-last
+  // [B, Ho*Wo, Cout]; sr_launch_splitk_reduce() finishes.  ksplit = 1: off.
+  int ksplit; float* part; int64_t part_stride;
 };
 
 // Stages global -> registers (issued before the MFMA phase of the previous slab) -> LDS (after it):
@@ -145,13 +149,15 @@ __device__ __forceinline__ void sr_conv_stage_store(float* __restrict__ tile,
   }
 }
 
-struct SrTileCoord { int b, co0, oy0, ox0; };
+struct SrTileCoord { int b, co0, oy0, ox0, ks; };
 
 template <int TH, int NT, int CM>
 __device__ __forceinline__ SrTileCoord sr_conv_tile(const SrConvParams& p, int work) {
   // work = ((b * tiles_y + ty) * tiles_x + tx) * co_blocks + cb: the output-channel blocks of one pixel tile are
   // neighbours in the work order, so they run at about the same time and share the input tile through L2
   SrTileCoord t;
+  t.ks = 0;
+  if (p.ksplit > 1) { t.ks = work % p.ksplit; work /= p.ksplit; }   // the K-parts of a tile are neighbours too
   const int cb = work % p.co_blocks; work /= p.co_blocks;
   const int tx = work % p.tiles_x; work /= p.tiles_x;
   const int ty = work % p.tiles_y;
@@ -209,13 +215,16 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
     for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
   };
 
+  // slab range [c_beg, c_end) of this work item (all of them unless split-K)
+  int c_beg = t.ks * chunks / p.ksplit, c_end = (t.ks + 1) * chunks / p.ksplit;
   sr_conv_stage_setup<KS, S, MT, CM>(p, t.oy0 * S - p.pad_y, t.ox0 * S - p.pad_x, offs);
-  sr_conv_stage_load<KS, S, MT, CM, VEC4>(p, p.in + (int64_t)t.b * p.in_sb, 0, offs, stg);
+  sr_conv_stage_load<KS, S, MT, CM, VEC4>(p, p.in + (int64_t)t.b * p.in_sb, c_beg * G::CK, offs, stg);
   sr_conv_stage_store<KS, S, MT, CM>(tiles[0], stg);
 #pragma unroll
-  for (int s = 0; s < PD; ++s) load_b(wp4, 0, s, b_f[s]);
+  for (int s = 0; s < PD; ++s) load_b(wp4, c_beg, s, b_f[s]);
   __syncthreads();
   int buf = 0;
+  const bool partial = p.ksplit > 1;
 
   while (true) {
     const int next_work = work + gridDim.x;
@@ -223,6 +232,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
     SrTileCoord tn = t;
     if (have_next) tn = sr_conv_tile<TH, NT, CM>(p, next_work);
     const float4* wp4n = reinterpret_cast<const float4*>(p.wp) + (kk * p.Co_pad + tn.co0 + i);
+    const int cn_beg = tn.ks * chunks / p.ksplit, cn_end = (tn.ks + 1) * chunks / p.ksplit;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -232,19 +242,19 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
     float rpf[RES_PF ? MT : 1][RES_PF ? NT : 1][16];  // prefetched residual values (RES_PF only)
-    const float* __restrict__ resp = (p.res && !SR_CV_DBG(2)) ? p.res + (int64_t)t.b * p.res_sb : nullptr;
+    const float* __restrict__ resp = (p.res && !partial && !SR_CV_DBG(2)) ? p.res + (int64_t)t.b * p.res_sb : nullptr;
 
-    for (int ch = 0; ch < chunks; ++ch) {
+    for (int ch = c_beg; ch < c_end; ++ch) {
       const float* tile = tiles[buf];
-      const bool last = ch + 1 == chunks;
+      const bool last = ch + 1 == c_end;
       const bool more = !last || have_next;        // is there a following slab in the pipeline?
       if (more) {
         if (last) sr_conv_stage_setup<KS, S, MT, CM>(p, tn.oy0 * S - p.pad_y, tn.ox0 * S - p.pad_x, offs);  // next tile
         sr_conv_stage_load<KS, S, MT, CM, VEC4>(p, p.in + (int64_t)(last ? tn.b : t.b) * p.in_sb,
-                                            last ? 0 : (ch + 1) * G::CK, offs, stg);
+                                            (last ? cn_beg : ch + 1) * G::CK, offs, stg);
       }
       const float4* wnext = last ? wp4n : wp4;
-      const int chn = last ? 0 : ch + 1;
+      const int chn = last ? cn_beg : ch + 1;
       if (RES_PF && last) {
         // residual of THIS tile: 16 x MT x NT dword loads, branch-free (masked), 5 k-steps of slack before the
         // in-order VMEM queue is needed again
@@ -301,8 +311,10 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
     // 4*kk part is per lane, the rest folds to immediates.  32-bit element offsets off one scalar base per
     // tensor; all residual loads of a fragment are issued before its stores (out / residual may alias).
     {
-      float* __restrict__ outp = p.out + (int64_t)t.b * p.out_sb;
-      const int osp = p.out_sp, rsp = p.res_sp;
+      float* __restrict__ outp = partial ? p.part + t.ks * p.part_stride + (int64_t)t.b * p.Ho * p.Wo * p.Cout
+                                         : p.out + (int64_t)t.b * p.out_sb;
+      const int osp = partial ? p.Cout : p.out_sp, rsp = p.res_sp;
+      const float slope = partial ? SR_ACT_NONE : p.slope;
       const bool no_res = (resp == nullptr);
       // interior tiles (workgroup-uniform test) take a branch-free path
       const bool full = (t.oy0 + TH <= p.Ho) && (t.ox0 + CM <= p.Wo) && (t.co0 + 32 * NT <= p.Cout) && !SR_CV_DBG(1);
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
         for (int n = 0; n < NT; ++n) {
           const int co = t.co0 + 32 * n + i;
           const bool okc = co < p.Cout;
-          const float bv = (p.bias && okc) ? p.bias[co] : 0.0f;
+          const float bv = (p.bias && okc && !partial) ? p.bias[co] : 0.0f;
           const unsigned ob = (unsigned)(pixb * osp + co), rb = (unsigned)(pixb * rsp + co);
           float rv[16];
           if (RES_PF) {
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
             for (int r = 0; r < 16; ++r) {
               const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
               float v = acc[m][n][r] + bv + rv[r];
-              v = sr_activate(v, p.slope);
+              v = sr_activate(v, slope);
               outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
             }
           } else {
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
             for (int r = 0; r < 16; ++r) {
               const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
               float v = acc[m][n][r] + bv + rv[r];
-              v = sr_activate(v, p.slope);
+              v = sr_activate(v, slope);
               if (ok[r] && (!SR_CV_DBG(1) || v == 1.2345e33f)) outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
             }
           }
@@ -362,6 +374,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
     if (!have_next) break;
     work = next_work;
     t = tn;
+    c_beg = cn_beg; c_end = cn_end;
     wp4 = wp4n;
   }
 }
@@ -475,6 +488,14 @@ static int sr_conv_launch(SrConvParams& p, int B, int nt, hipStream_t stream) {
   p.tiles_y = (p.Ho + G::TH - 1) / G::TH;
   p.co_blocks = (p.Co_pad + 32 * nt - 1) / (32 * nt);
   p.total_tiles = p.tiles_x * p.tiles_y * p.co_blocks * B;
+  if (p.ksplit > 1) {   // split-K plan (1x1 / stride 1 only, see sr_conv2d_dispatch): fill the 2-per-CU slots once
+    const int chunks = p.G / (G::CK / 8);
+    int ks = (2 * sr_num_cus()) / p.total_tiles;
+    if (ks > chunks / 2) ks = chunks / 2;
+    if (ks > p.ksplit) ks = p.ksplit;
+    p.ksplit = ks < 2 ? 1 : ks;
+    p.total_tiles *= p.ksplit;
+  }
   int blocks = sr_num_cus() * (KS == 1 ? SR_CONV_BLOCKS_PER_CU : 2);  // persistent grid: workgroups per CU (register / LDS limit)
   if (blocks > p.total_tiles) blocks = p.total_tiles;
   dim3 grid(blocks), block(256);
@@ -525,11 +546,27 @@ static SrConvCfg sr_conv_cfg(const SrConvParams& p, int B, int stride, int ksize
   return cfg;
 }
 
+// Split-K is planned for 1x1 / stride-1 convolutions only (the deep projections of the image-prior encoder's MBConv
+// blocks: 1536 -> 256 channels on 15x20 maps is 24 slabs in a row on a few dozen workgroups); the finishing kernel
+// works on 16-byte channel quads.
+#define SR_CONV_KSPLIT_MAX 8
+static bool sr_conv_splitk_eligible(const float* out, int64_t out_sb, int out_sp, const float* bias, const float* res,
+                                    int64_t res_sb, int res_sp, int Cin, int Cout, int ksize, int stride) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SR_CONV_KSPLIT"); on = e ? atoi(e) : 1; }
+  if (!on || ksize != 1 || stride != 1 || Cout % 4 != 0 || Cin < 4 * SR_CK1) return false;
+  auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (!al(out) || out_sp % 4 != 0 || out_sb % 4 != 0 || (bias && !al(bias))) return false;
+  if (res && (!al(res) || res_sp % 4 != 0 || res_sb % 4 != 0)) return false;
+  return true;
+}
+
 static int sr_conv2d_dispatch(const float* in, int64_t in_batch_stride, int in_pix_stride,
                              const float* packed_weight, const float* bias, const float* residual,
                              int64_t res_batch_stride, int res_pix_stride, float* out, int64_t out_batch_stride,
                              int out_pix_stride, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
-                             float leaky_slope, int replicate, void* stream_, const int* pads = nullptr) {
+                             float leaky_slope, int replicate, void* stream_, const int* pads = nullptr,
+                             void* workspace = nullptr, size_t workspace_bytes = 0) {
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (B == 0) return SR_OK;
   if (!in || !packed_weight || !out) return SR_ERR_INVALID_ARGUMENT;
@@ -553,27 +590,39 @@ static int sr_conv2d_dispatch(const float* in, int64_t in_batch_stride, int in_p
   p.G = ((Cin + sr_ck(ksize) - 1) / sr_ck(ksize)) * (sr_ck(ksize) / 8);
   p.slope = leaky_slope;
   p.replicate = replicate;
+  p.ksplit = 1; p.part = nullptr; p.part_stride = 0;
+  if (workspace && sr_conv_splitk_eligible(out, out_batch_stride, out_pix_stride, bias, residual, res_batch_stride,
+                                           res_pix_stride, Cin, Cout, ksize, stride)) {
+    p.part_stride = (int64_t)B * p.Ho * p.Wo * Cout;
+    const size_t fit = workspace_bytes / ((size_t)p.part_stride * sizeof(float));
+    p.ksplit = fit < 2 ? 1 : (fit < SR_CONV_KSPLIT_MAX ? (int)fit : SR_CONV_KSPLIT_MAX);   // upper bound: the launch plans
+    p.part = (float*)workspace;
+  }
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0);
   hipStream_t stream = (hipStream_t)stream_;
   const SrConvCfg cfg = sr_conv_cfg(p, B, stride, ksize);
   const int c = cfg.shape, nt = cfg.nt;
+  int rc;
   if (ksize == 3 && stride == 1) {
-    if (c == 0) return sr_conv_launch<3, 1, 2, 32>(p, B, nt, stream);
-    if (c == 1) return sr_conv_launch<3, 1, 1, 32>(p, B, nt, stream);
-    return sr_conv_launch<3, 1, 1, 8>(p, B, nt, stream);
+    if (c == 0) rc = sr_conv_launch<3, 1, 2, 32>(p, B, nt, stream);
+    else if (c == 1) rc = sr_conv_launch<3, 1, 1, 32>(p, B, nt, stream);
+    else rc = sr_conv_launch<3, 1, 1, 8>(p, B, nt, stream);
+  } else if (ksize == 3 && stride == 2) {
+    if (c == 1) rc = sr_conv_launch<3, 2, 1, 32>(p, B, nt, stream);
+    else rc = sr_conv_launch<3, 2, 1, 8>(p, B, nt, stream);
+  } else if (ksize == 1 && stride == 1) {
+    if (c == 0) rc = sr_conv_launch<1, 1, 2, 32>(p, B, nt, stream);
+    else if (c == 1) rc = sr_conv_launch<1, 1, 1, 32>(p, B, nt, stream);
+    else rc = sr_conv_launch<1, 1, 1, 8>(p, B, nt, stream);
+  } else {
+    if (c == 1) rc = sr_conv_launch<1, 2, 1, 32>(p, B, nt, stream);
+    else rc = sr_conv_launch<1, 2, 1, 8>(p, B, nt, stream);
   }
-  if (ksize == 3 && stride == 2) {
-    if (c == 1) return sr_conv_launch<3, 2, 1, 32>(p, B, nt, stream);
-    return sr_conv_launch<3, 2, 1, 8>(p, B, nt, stream);
-  }
-  if (ksize == 1 && stride == 1) {
-    if (c == 0) return sr_conv_launch<1, 1, 2, 32>(p, B, nt, stream);
-    if (c == 1) return sr_conv_launch<1, 1, 1, 32>(p, B, nt, stream);
-    return sr_conv_launch<1, 1, 1, 8>(p, B, nt, stream);
-  }
-  if (c == 1) return sr_conv_launch<1, 2, 1, 32>(p, B, nt, stream);
-  return sr_conv_launch<1, 2, 1, 8>(p, B, nt, stream);
+  if (rc == SR_OK && p.ksplit > 1)   // the launch settled the final split factor in p.ksplit
+    rc = sr_launch_splitk_reduce(p.part, p.ksplit, p.part_stride, bias, residual, res_batch_stride, res_pix_stride, out,
+                                 out_batch_stride, out_pix_stride, B, p.Ho * p.Wo, Cout, leaky_slope, stream);
+  return rc;
 }
 
 extern "C" int sr_conv2d_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
@@ -607,6 +656,26 @@ extern "C" int sr_conv2d_padded_nhwc_fwd(const float* in, int64_t in_batch_strid
   return sr_conv2d_dispatch(in, in_batch_stride, in_pix_stride, packed_weight, bias, residual, res_batch_stride,
                             res_pix_stride, out, out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, ksize, stride,
                             leaky_slope, 0, stream_, pads);
+}
+
+extern "C" size_t sr_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  if (B <= 0 || H <= 0 || W <= 0 || ksize != 1 || stride != 1 || Cout % 4 != 0 || Cin < 4 * SR_CK1) return 0;
+  // small pixel counts only: with >= 2 work items per CU already there is nothing to gain
+  const int64_t px = (int64_t)B * H * W;
+  const int64_t tiles = ((px + 127) / 128) * ((Cout + 31) / 32);
+  if (tiles >= 2 * sr_num_cus()) return 0;
+  return (size_t)SR_CONV_KSPLIT_MAX * px * Cout * sizeof(float);
+}
+
+extern "C" int sr_conv2d_splitk_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                         const float* packed_weight, const float* bias, const float* residual,
+                                         int64_t res_batch_stride, int res_pix_stride, float* out,
+                                         int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                                         int Cout, int ksize, int stride, float leaky_slope, void* workspace,
+                                         size_t workspace_bytes, void* stream_) {
+  return sr_conv2d_dispatch(in, in_batch_stride, in_pix_stride, packed_weight, bias, residual, res_batch_stride,
+                            res_pix_stride, out, out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, ksize, stride,
+                            leaky_slope, 0, stream_, nullptr, workspace, workspace_bytes);
 }
 
 // Symbol of the kernel instantiation sr_conv2d_nhwc_fwd picks for these arguments (for profilers / bench).

@@ -500,6 +500,16 @@ __global__ __launch_bounds__(256) void sr_wino_reduce_kernel(const float* __rest
   }
 }
 
+int sr_launch_splitk_reduce(const float* part, int ksplit, int64_t part_stride, const float* bias, const float* res,
+                            int64_t res_sb, int res_sp, float* out, int64_t out_sb, int out_sp, int B, int HW, int Cout,
+                            float slope, hipStream_t stream) {
+  const int64_t total = (int64_t)HW * (Cout / 4);
+  const int rblocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(sr_wino_reduce_kernel, dim3(rblocks, B), dim3(256), 0, stream, part, ksplit, part_stride, bias, res,
+                     res_sb, res_sp, out, out_sb, out_sp, HW, Cout / 4, slope);
+  return sr_hip_rc(hipGetLastError());
+}
+
 // ------------------------------------------------------------------ C ABI -------------
 
 static int sr_wino_num_cus() {
@@ -678,12 +688,8 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
 #endif
   int rc = sr_hip_rc(hipGetLastError());
   if (rc == SR_OK && p.ksplit > 1) {
-    const int64_t total = (int64_t)H * W * (Cout / 4);
-    const int rblocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(sr_wino_reduce_kernel, dim3(rblocks, B), dim3(256), 0, stream, p.part, p.ksplit, p.part_stride,
-                       bias, residual, res_batch_stride, res_pix_stride, out, out_batch_stride, out_pix_stride, H * W,
-                       Cout / 4, leaky_slope);
-    rc = sr_hip_rc(hipGetLastError());
+    rc = sr_launch_splitk_reduce(p.part, p.ksplit, p.part_stride, bias, residual, res_batch_stride, res_pix_stride, out,
+                                 out_batch_stride, out_pix_stride, B, H * W, Cout, leaky_slope, stream);
   }
   return rc;
 }

@@ -258,10 +258,16 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
             rc = lib.sr_conv3x3_wino_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
                                                      _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
                                                      co, slope, _lib.ptr(ws), nbytes, _lib.stream_ptr(x.device))
+        elif replicate:
+            rc = lib.sr_conv2d_replicate_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
+                                                  _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
+                                                  co, k, s, slope, _lib.stream_ptr(x.device))
         else:
-            fwd = lib.sr_conv2d_replicate_nhwc_fwd if replicate else lib.sr_conv2d_nhwc_fwd
-            rc = fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb, rsp, _lib.ptr(out),
-                     osb, osp, b, h, w, ci, co, k, s, slope, _lib.stream_ptr(x.device))
+            nbytes = lib.sr_conv_splitk_workspace_bytes(b, h, w, ci, co, k, s)   # 0 unless the launch plan may split K
+            ws = _workspace(x.device, "conv_splitk", nbytes) if nbytes else None
+            rc = lib.sr_conv2d_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
+                                               rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope,
+                                               _lib.ptr(ws), nbytes, _lib.stream_ptr(x.device))
         if prof is not None:
             ev1.record()
             v4 = int(x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0)

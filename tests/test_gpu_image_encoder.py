@@ -92,6 +92,31 @@ def test_dwconv_se_scale(shape, stride):
     assert_close(d1, ref * g[:, :, None, None], what="gated depthwise output (two-launch path)")
 
 
+@pytest.mark.parametrize("shape,cout,res", [((8, 1536, 15, 20), 256, True), ((1, 1536, 15, 20), 256, False),
+                                            ((2, 960, 30, 40), 160, True), ((1, 512, 5, 7), 128, False),
+                                            ((3, 768, 9, 11), 160, True)])
+def test_deep_projection_conv_splitk(shape, cout, res):
+    """1x1 projections with a long channel chain on few pixels: the split-K plan of sr_conv2d_splitk_nhwc_fwd
+    (partials + deterministic finish) against the oracle, with folded BatchNorm and the block's identity skip."""
+    b, c, h, w = shape
+    rng = np.random.default_rng(c + cout)
+    x = rng.standard_normal(shape, dtype=np.float32)
+    r = rng.standard_normal((b, cout, h, w), dtype=np.float32) if res else None
+    conv = synthetic.seeded_fill_(nn.Conv2d(c, cout, 1, bias=False), seed=cout).to(DEV)
+    bn = _bn(cout, seed=7).to(DEV)
+    xt = torch.from_numpy(x).to(DEV).contiguous(memory_format=torch.channels_last)
+    rt = torch.from_numpy(r).to(DEV).contiguous(memory_format=torch.channels_last) if res else None
+    with torch.inference_mode():
+        y = ops.conv2d(xt, conv, bn=bn, residual=rt)
+        y2 = ops.conv2d(xt, conv, bn=bn, residual=rt)
+    sd = {k_: _np(v) for k_, v in bn.state_dict().items()}
+    ref = oracle.batchnorm_eval(oracle.conv2d(x, _np(conv.weight)), sd, "", eps=1e-3)
+    if res:
+        ref = ref + r
+    assert torch.equal(y, y2), "split-K finish must be deterministic"
+    assert_close(y, ref, what=f"1x1 projection {shape}->{cout}")
+
+
 def test_add_inplace_on_channel_slice():
     rng = np.random.default_rng(3)
     buf = torch.from_numpy(rng.standard_normal((2, 17, 19, 48), dtype=np.float32)).to(DEV).permute(0, 3, 1, 2)
