@@ -538,7 +538,7 @@ static SrConvCfg sr_conv_pick(const SrConvParams& p, int B, int stride, int ksiz
 static SrConvCfg sr_conv_cfg(const SrConvParams& p, int B, int stride, int ksize) {
   SrConvCfg cfg = sr_conv_pick(p, B, stride, ksize);
   const char* e = getenv("SR_CONV_TILE");  // ablation override: shape + 10 * nt (nt = 0: keep)
-  if (e) {
+  if (e && *e) {
     const int v = atoi(e), shape = v % 10, nt = v / 10;
     if (shape >= 0 && shape <= 2 && !(stride == 2 && shape == 0)) cfg.shape = shape;
     if (nt == 1 || (nt == 2 && p.Co_pad % 64 == 0)) cfg.nt = nt;

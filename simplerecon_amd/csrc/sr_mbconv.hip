@@ -220,7 +220,9 @@ inline bool aligned16(const void* ptr) { return (((uintptr_t)ptr) & 15) == 0; }
 
 extern "C" int sr_dwconv3x3_pool_bands(int Ho) {
   if (Ho <= 0) return 0;
-  const int rows = Ho >= 24 ? 6 : Ho >= 8 ? 4 : Ho;   // output rows per workgroup
+  // output rows per workgroup: short bands = many workgroups (the kernel is latency-bound on these small maps:
+  // 15x20 x 1536 channels x 8 images with 4-row bands is only 2 workgroups per CU)
+  const int rows = Ho > 64 ? 4 : 2;
   return (Ho + rows - 1) / rows;
 }
 
