@@ -7,6 +7,8 @@ python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/sm
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_hero_cfg3.json 2> $O/bench_hero_cfg3.err
 timeout 300 python bench.py --workload hero_b1 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_hero_b1.json 2> $O/bench_hero_b1.err
+timeout 300 python bench.py --workload hero_cfg3_noprior --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_hero_cfg3_noprior.json 2> $O/bench_hero_cfg3_noprior.err
+timeout 300 python bench.py --workload tsdf_fuse --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_tsdf_fuse.json 2> $O/bench_tsdf_fuse.err
 timeout 300 python bench.py --workload dot_cfg2 --steps 50 --warmup 5 > $O/bench_dot_cfg2.json 2> $O/bench_dot_cfg2.err
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_hero_cfg3 -o hero_cfg3 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/prof_hero_cfg3.log 2>&1

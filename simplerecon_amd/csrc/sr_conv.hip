@@ -528,7 +528,12 @@ static SrConvCfg sr_conv_pick(const SrConvParams& p, int B, int stride, int ksiz
                          ((p.Co_pad + 32 * nt - 1) / (32 * nt)) * B;
       // + 0.04*nt: weight fragments come from L2 (VMEM) per N-tile, A fragments from LDS -- measured: at equal
       // MFMA work an 8x32x32 tile is ~4 % faster than a 4x32x64 tile
-      const double cost = (double)((tiles + cus - 1) / cus) * (mt[c] * nt + 0.12 + 0.04 * nt + stage_w * mt[c]);
+      double rounds = (double)((tiles + cus - 1) / cus);
+      // 1x1 convs with at most two tiles per CU are latency- rather than MFMA-bound: the second resident workgroup
+      // of a CU costs ~35 % (measured: 960 -> 160 channels on 9600 pixels, 375 tiles of 4x32x32: 57 us; 190 tiles of
+      // 8x32x32: 79 us)
+      if (ksize == 1 && tiles > cus && tiles <= 2 * cus) rounds = 1.0 + 0.35 * (double)(tiles - cus) / cus;
+      const double cost = rounds * (mt[c] * nt + 0.12 + 0.04 * nt + stage_w * mt[c]);
       if (best_cost < 0 || cost < best_cost) { best = {c, nt}; best_cost = cost; }
     }
   }

@@ -49,31 +49,42 @@ __global__ __launch_bounds__(256) void sr_dwconv3x3_kernel(SrDwParams p) {
   if (live && p.bias) bv = *reinterpret_cast<const float4*>(p.bias + c);
   const float* __restrict__ inb = p.in + (int64_t)b * p.in_sb + c;
   float* __restrict__ outb = p.out + (int64_t)b * p.out_sb + c;
-  const int oy_end = min(p.Ho, (band + 1) * p.rows);
+  const int oy0 = band * p.rows;
+  const int npx = (min(p.Ho, oy0 + p.rows) - oy0) * p.Wo;   // output pixels of this band, row-major
   if (live) {
-    for (int oy = band * p.rows; oy < oy_end; ++oy) {
-      const int iy0 = oy * p.stride - p.pad_y;
-      for (int ox = xl; ox < p.Wo; ox += DW_XL) {
-        const int ix0 = ox * p.stride - p.pad_x;
-        float4 v[9];
+    // two output pixels per pass: 18 independent 16-byte loads in flight (the kernel is latency-bound)
+    for (int q0 = xl; q0 < npx; q0 += 2 * DW_XL) {
+      float4 v[2][9];
+      int opix[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = q0 + u * DW_XL;
+        const bool have = q < npx;
+        const int oy = oy0 + (have ? q / p.Wo : 0), ox = have ? q % p.Wo : 0;
+        opix[u] = have ? oy * p.Wo + ox : -1;
+        const int iy0 = oy * p.stride - p.pad_y, ix0 = ox * p.stride - p.pad_x;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const int iy = iy0 + ky, ix = ix0 + kx;
-            const bool ok = (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W);
+            const bool ok = have && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W);
             const float4 t = *reinterpret_cast<const float4*>(inb + (int64_t)(ok ? iy * p.W + ix : 0) * p.in_sp);
-            v[ky * 3 + kx] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[u][ky * 3 + kx] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (opix[u] < 0) continue;
         float4 acc = bv;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc = f4fma(v[t], wt[t], acc);
+        for (int t = 0; t < 9; ++t) acc = f4fma(v[u][t], wt[t], acc);
         acc.x = sr_activate(acc.x, p.slope);
         acc.y = sr_activate(acc.y, p.slope);
         acc.z = sr_activate(acc.z, p.slope);
         acc.w = sr_activate(acc.w, p.slope);
-        *reinterpret_cast<float4*>(outb + (int64_t)(oy * p.Wo + ox) * p.out_sp) = acc;
+        *reinterpret_cast<float4*>(outb + (int64_t)opix[u] * p.out_sp) = acc;
         sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;
       }
     }
@@ -133,17 +144,34 @@ __global__ __launch_bounds__(256) void sr_se_gate_kernel(SrSeParams p) {
 //   sr_se_hidden_kernel   one wave per (image, hidden unit): hid = silu(w1[j] . mean + b1[j]);
 //   sr_se_scale_kernel    one workgroup per (image, 64 channels): gates from hid, then scales those channels of
 //                         every pixel of the image.
+// (Both kernels are pure latency: every loop keeps 8-16 independent loads in flight through explicit register
+// arrays -- with run-time trip counts the compiler otherwise waits on each load before issuing the next.)
 __global__ __launch_bounds__(256) void sr_se_hidden_kernel(SrSeParams p, float* __restrict__ hidden) {
+  extern __shared__ float mean[];   // [C]: all 256 threads finish the average pool, then one wave per hidden unit
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 4 + wave, b = blockIdx.y;
-  if (j >= p.rd) return;
   const float* __restrict__ pool = p.pool + (int64_t)b * p.bands * p.C;
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float m = 0.f;
+    for (int k0 = 0; k0 < p.bands; k0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = (k0 + k < p.bands) ? pool[(int64_t)(k0 + k) * p.C + c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m += v[k];   // band order: deterministic
+    }
+    mean[c] = m * p.inv_count;
+  }
+  __syncthreads();
+  if (j >= p.rd) return;
   const float* __restrict__ w = p.w1 + (int64_t)j * p.C;
   float s = 0.f;
-  for (int c = lane; c < p.C; c += 64) {
-    float m = 0.f;
-    for (int k = 0; k < p.bands; ++k) m += pool[(int64_t)k * p.C + c];
-    s = fmaf(w[c], m * p.inv_count, s);
+  for (int c0 = 0; c0 < p.C; c0 += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int c = c0 + 64 * u + lane; v[u] = c < p.C ? w[c] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int c = c0 + 64 * u + lane; s = fmaf(v[u], c < p.C ? mean[c] : 0.f, s); }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -158,17 +186,29 @@ __global__ __launch_bounds__(256) void sr_se_scale_kernel(SrSeParams p, const fl
   const int b = blockIdx.y, c0 = blockIdx.x * DW_CH;
   for (int j = threadIdx.x; j < p.rd; j += 256) hid[j] = hidden[(int64_t)b * p.rd + j];
   __syncthreads();
-  if (threadIdx.x < DW_CH) {
-    const int c = c0 + threadIdx.x;
+  {  // gates of the 64 channels: 4 threads per channel, each a quarter of the hidden units, 8 loads in flight
+    const int cl = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int c = c0 + cl;
     float s = 0.f;
     if (c < p.C) {
-      s = p.b2 ? p.b2[c] : 0.f;
       const float* __restrict__ w = p.w2 + (int64_t)c * p.rd;
-      for (int j = 0; j < p.rd; ++j) s = fmaf(w[j], hid[j], s);
-      s = 1.0f / (1.0f + __expf(-s));
-      if (p.gate) p.gate[(int64_t)b * p.C + c] = s;
+      for (int j0 = q; j0 < p.rd; j0 += 4 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = j0 + 4 * u; v[u] = j < p.rd ? w[j] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = j0 + 4 * u; s = fmaf(v[u], j < p.rd ? hid[j] : 0.f, s); }
+      }
     }
-    g[threadIdx.x] = s;
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (q == 0) {
+      if (c < p.C) {
+        s = 1.0f / (1.0f + __expf(-(s + (p.b2 ? p.b2[c] : 0.f))));
+        if (p.gate) p.gate[(int64_t)b * p.C + c] = s;
+      }
+      g[cl] = s;
+    }
   }
   __syncthreads();
   const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
@@ -177,10 +217,20 @@ __global__ __launch_bounds__(256) void sr_se_scale_kernel(SrSeParams p, const fl
   const float4 gv = *reinterpret_cast<const float4*>(&g[4 * c4]);
   const float* __restrict__ inb = in + (int64_t)b * in_sb + c;
   float* __restrict__ outb = out + (int64_t)b * out_sb + c;
-  for (int px = pl; px < HW; px += 16) {
-    float4 v = *reinterpret_cast<const float4*>(inb + (int64_t)px * in_sp);
-    v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
-    *reinterpret_cast<float4*>(outb + (int64_t)px * out_sp) = v;
+  for (int px0 = pl; px0 < HW; px0 += 16 * 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int px = px0 + 16 * u;
+      v[u] = px < HW ? *reinterpret_cast<const float4*>(inb + (int64_t)px * in_sp) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int px = px0 + 16 * u;
+      if (px < HW)
+        *reinterpret_cast<float4*>(outb + (int64_t)px * out_sp) =
+            make_float4(v[u].x * gv.x, v[u].y * gv.y, v[u].z * gv.z, v[u].w * gv.w);
+    }
   }
 }
 
@@ -317,14 +367,14 @@ extern "C" int sr_se_scale_nhwc_fwd(const float* pool_partial, int bands, const 
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || rd <= 0 || bands <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (B == 0) return SR_OK;
   if (!pool_partial || !w_reduce || !w_expand || !hidden || !in || !out) return SR_ERR_INVALID_ARGUMENT;
-  if (rd > 256 || C % 4 != 0 || in_pix_stride % 4 != 0 || out_pix_stride % 4 != 0 || in_batch_stride % 4 != 0 ||
+  if (rd > 256 || C > 16384 || C % 4 != 0 || in_pix_stride % 4 != 0 || out_pix_stride % 4 != 0 || in_batch_stride % 4 != 0 ||
       out_batch_stride % 4 != 0 || !aligned16(in) || !aligned16(out))
     return SR_ERR_UNSUPPORTED;
   SrSeParams p;
   p.pool = pool_partial; p.bands = bands; p.inv_count = 1.0f / (float)((int64_t)H * W);
   p.w1 = w_reduce; p.b1 = b_reduce; p.w2 = w_expand; p.b2 = b_expand; p.gate = gate; p.C = C; p.rd = rd;
   hipStream_t stream = (hipStream_t)stream_;
-  hipLaunchKernelGGL(sr_se_hidden_kernel, dim3((rd + 3) / 4, B), dim3(256), 0, stream, p, hidden);
+  hipLaunchKernelGGL(sr_se_hidden_kernel, dim3((rd + 3) / 4, B), dim3(256), (size_t)C * sizeof(float), stream, p, hidden);
   hipLaunchKernelGGL(sr_se_scale_kernel, dim3((C + DW_CH - 1) / DW_CH, B), dim3(256), 0, stream, p,
                      (const float*)hidden, in, in_batch_stride, in_pix_stride, out, out_batch_stride, out_pix_stride,
                      H * W);
