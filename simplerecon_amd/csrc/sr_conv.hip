@@ -529,10 +529,12 @@ static SrConvCfg sr_conv_pick(const SrConvParams& p, int B, int stride, int ksiz
       // + 0.04*nt: weight fragments come from L2 (VMEM) per N-tile, A fragments from LDS -- measured: at equal
       // MFMA work an 8x32x32 tile is ~4 % faster than a 4x32x64 tile
       double rounds = (double)((tiles + cus - 1) / cus);
-      // 1x1 convs with at most two tiles per CU are latency- rather than MFMA-bound: the second resident workgroup
-      // of a CU costs ~35 % (measured: 960 -> 160 channels on 9600 pixels, 375 tiles of 4x32x32: 57 us; 190 tiles of
-      // 8x32x32: 79 us)
-      if (ksize == 1 && tiles > cus && tiles <= 2 * cus) rounds = 1.0 + 0.35 * (double)(tiles - cus) / cus;
+      // 1x1 convs with at most two of the SMALLEST tiles per CU are latency- rather than MFMA-bound: the second
+      // resident workgroup of a CU costs ~35 % (measured: 960 -> 160 channels on 9600 pixels, 375 tiles of 4x32x32:
+      // 57 us; 190 tiles of 8x32x32: 79 us).  Larger tiles do serialise on the MFMA pipe (128 -> 512 channels: 304
+      // tiles of 8x32x64 50 us, 600 tiles of 4x32x64 33 us): they keep the whole-round count.
+      if (ksize == 1 && mt[c] * nt == 1 && tiles > cus && tiles <= 2 * cus)
+        rounds = 1.0 + 0.35 * (double)(tiles - cus) / cus;
       const double cost = rounds * (mt[c] * nt + 0.12 + 0.04 * nt + stage_w * mt[c]);
       if (best_cost < 0 || cost < best_cost) { best = {c, nt}; best_cost = cost; }
     }
