@@ -12,9 +12,9 @@
 //   * sr_scale_channels_nhwc_fwd   x[b, p, c] *= gate[b, c];
 //   * sr_add_nhwc_fwd         a + b (the identity skip of stage 0's ConvBnAct blocks, where the sum follows the
 //                             activation and therefore cannot ride in a convolution epilogue).
-// All three are HBM/L2-bound byte shuffling on small maps (<= 30x40 at 640x480 input): channels-last,
-// one 16-byte load per lane, a workgroup covers 64 channels x a band of rows so that every image row is
-// read from HBM once and re-read (x3 vertically, x3 horizontally) from L1/L2 only.
+// All of them are byte shuffling on small maps (<= 30x40 at 640x480 input), bound by load latency rather than
+// bandwidth: channels-last, one 16-byte access per lane, many short workgroups, and 8-18 independent loads in
+// flight per lane (explicit register arrays) -- see DESIGN.md §3.7 for the measurements.
 #include "sr_common.h"
 
 namespace {

@@ -73,3 +73,42 @@ def test_matching_encoder_state_dict_names():
         expect |= {f"net.4.{blk}.conv1.weight", f"net.4.{blk}.conv2.weight"}
         expect |= {f"net.4.{blk}.bn{i}.{k}" for i in (1, 2) for k in bn}
     assert keys == expect
+
+
+def test_tf_same_padding_and_activation_codes():
+    """Host logic of the image-prior encoder's conv wrappers: TF-"SAME" pads equal what timm's Conv2dSame computes
+    (tests/effnet_torch._same), activation codes match include/simplerecon_hip.h."""
+    import torch
+    import effnet_torch
+    from simplerecon_amd import ops
+    for h, w in ((480, 640), (15, 20), (9, 11), (1, 7), (30, 1), (37, 51)):
+        for k, s in ((3, 1), (3, 2), (1, 1)):
+            pt, pl, pb, pr = ops.tf_same_pads(h, w, k, s)
+            padded = effnet_torch._same(torch.zeros(1, 1, h, w), k, s)
+            assert padded.shape[-2:] == (h + pt + pb, w + pl + pr)
+            assert (h + pt + pb - k) // s + 1 == -(-h // s) and (w + pl + pr - k) // s + 1 == -(-w // s)
+            assert pb - pt in (0, 1) and pr - pl in (0, 1)      # the odd pixel goes below / right
+    hdr = open(os.path.join(ROOT, "include", "simplerecon_hip.h")).read()
+    assert "#define SR_ACT_NONE (-1.0f)" in hdr and "#define SR_ACT_SILU (-2.0f)" in hdr
+    assert ops._act_code(None, None) == -1.0 and ops._act_code(0.2, None) == 0.2 and ops._act_code(None, "silu") == -2.0
+    with pytest.raises(ValueError):
+        ops._act_code(0.2, "silu")
+    with pytest.raises(ValueError):
+        ops._act_code(None, "gelu")
+
+
+def test_depth_model_default_construction_is_all_native():
+    """DepthModel(opts) builds both encoders on the HIP modules, keeps the reference's sub-module names (checkpoint
+    prefixes) and refuses host tensors (no CPU fallback)."""
+    import torch
+    from simplerecon_amd import depth_model as dm
+    from simplerecon_amd._lib import HipLibraryError
+    model = dm.DepthModel(dm.default_options(image_width=128, image_height=96, model_num_views=3,
+                                             matching_num_depth_bins=8))
+    assert type(model.encoder).__name__ == "EfficientNetV2SFeatures"
+    assert type(model.matching_model).__name__ == "ResnetMatchingEncoder"
+    prefixes = {k.split(".")[0] for k in model.state_dict()}
+    assert prefixes == {"encoder", "cost_volume_net", "depth_decoder", "cost_volume", "matching_model"}
+    with pytest.raises(HipLibraryError), torch.inference_mode():
+        model.forward_tensors(torch.zeros(1, 3, 96, 128), torch.zeros(1, 2, 3, 96, 128), torch.eye(4).expand(1, 2, 4, 4),
+                              torch.eye(4).expand(1, 2, 4, 4), torch.eye(4).expand(1, 2, 4, 4), torch.eye(4)[None])
