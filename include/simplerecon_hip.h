@@ -328,6 +328,22 @@ int sr_tsdf_integrate_fwd(void* tsdf_values, void* tsdf_weights, const void* vox
                           float min_depth, float max_depth, float depth_range, float truncation, float maxW,
                           void* stream);
 
+/* ------------------------------------------------------ backward (training) -------------
+ *
+ * Backward of sr_dot_volume_sweep (reference: autograd through CostVolumeManager.build_cost_volume,
+ * modules/cost_volume.py:237-335 -- grid_sample backward + the broadcasting mul / sum): given grad_cv = dL/d
+ * cost_volume (strides g_sb, g_sd, g_sp like the forward's volume strides), writes d_cur [B,C,h,w] and / or
+ * d_src [B,K,C,h,w] (either may be NULL).  Poses, intrinsics and depth planes are data (no gradient, as in the
+ * reference).  `workspace` must have been filled by sr_volume_prepare for the same src / K_src / T_src_cur (what
+ * sr_dot_volume_fwd leaves behind); `scratch` (sr_dot_volume_bwd_scratch_bytes, 16-byte aligned) holds the
+ * channels-last d_src accumulation image.  d_src is accumulated with hardware fp32 atomics: its summation order, like
+ * torch's grid_sample backward, is not fixed. */
+size_t sr_dot_volume_bwd_scratch_bytes(int B, int K, int C, int h, int w);
+int sr_dot_volume_bwd(const float* grad_cv, int64_t g_sb, int64_t g_sd, int64_t g_sp, const float* cur,
+                      const float* invK_cur, const float* planes, int64_t ps_b, int64_t ps_d, int64_t ps_y,
+                      int64_t ps_x, int B, int K, int C, int h, int w, int D, float* d_cur, float* d_src,
+                      void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ------------------------------------------------------ image-prior encoder ------------
  *
  * timm `tf_efficientnetv2_s` feature pyramid (reference modules/depth_model.py:110-116: the `encoder` of

@@ -9,7 +9,9 @@ parameter/buffer names as the reference (cost_volume.py:13-380 `CostVolumeManage
 works exactly like the reference's own `to_fast()` seam (reference test.py:196-198) and a
 reference checkpoint loads with strict=True.  The arithmetic runs in hand-written gfx950
 kernels reached through the C ABI of include/simplerecon_hip.h; there is no torch/CPU
-fallback (inputs must be fp32 device tensors, inference only).
+fallback (inputs must be fp32 device tensors).  Inference everywhere; in addition the dot-product
+`CostVolumeManager` is differentiable w.r.t. the matching features (HIP backward kernel,
+`_DotVolumeFunction`) -- the first piece of the training path (SURVEY.md §8f "next" #3).
 """
 import ctypes as C
 
@@ -21,8 +23,55 @@ from .geometry import BackprojectDepth, Project3D
 from .networks import MLP
 
 
+class _DotVolumeFunction(torch.autograd.Function):
+    """cost_volume, lowest_cost = sweep(cur_feats, src_feats; geometry) with the HIP backward
+    (csrc/sr_dot_volume_bwd.hip) for the two feature tensors.  Geometry (poses, intrinsics, depth planes) is data, as
+    in the reference, whose `lowest_cost` is computed under no_grad (cost_volume.py:360-372)."""
+
+    @staticmethod
+    def forward(ctx, mgr, cur, src, Ks, T, invK, planes):
+        vol, lowest = mgr._launch_sweep(cur, src, Ks, T, invK, planes)
+        ctx.save_for_backward(cur, src, Ks, T, invK, planes)
+        ctx.mark_non_differentiable(lowest)
+        return vol, lowest
+
+    @staticmethod
+    def backward(ctx, g_vol, _g_lowest):
+        cur, src, Ks, T, invK, planes = ctx.saved_tensors
+        need_cur, need_src = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if any(ctx.needs_input_grad[3:]):
+            raise NotImplementedError("the cost volume is not differentiated w.r.t. poses / intrinsics / depth planes "
+                                      "(they are data in the reference's training too)")
+        b, k, c, h, w = src.shape
+        d = planes.shape[1]
+        dev = src.device
+        lib = _lib.lib()
+        g = g_vol if g_vol.dtype == torch.float32 else g_vol.float()
+        if g.stride(2) != w * g.stride(3):
+            g = g.contiguous()
+        d_cur = torch.empty_like(cur) if need_cur else None
+        d_src = torch.empty_like(src) if need_src else None
+        if b == 0 or not (need_cur or need_src):
+            return None, d_cur, d_src, None, None, None, None
+        ws = torch.empty(lib.sr_volume_workspace_bytes(b, k, c, h, w), dtype=torch.uint8, device=dev)
+        nscratch = lib.sr_dot_volume_bwd_scratch_bytes(b, k, c, h, w) if need_src else 0
+        scratch = torch.empty(nscratch // 4, dtype=torch.float32, device=dev) if need_src else None
+        st = _lib.stream_ptr(dev)
+        with torch.cuda.device(dev):
+            # the forward's workspace may have been reused since: rebuild the geometry records + channels-last sources
+            _lib.check(lib.sr_volume_prepare(_lib.ptr(src), _lib.ptr(Ks), _lib.ptr(T), None, b, k, c, h, w, _lib.ptr(ws),
+                                             ws.numel(), st), "sr_volume_prepare")
+            rc = lib.sr_dot_volume_bwd(_lib.ptr(g), g.stride(0), g.stride(1), g.stride(3), _lib.ptr(cur), _lib.ptr(invK),
+                                       _lib.ptr(planes), *planes.stride(), b, k, c, h, w, d, _lib.ptr(d_cur),
+                                       _lib.ptr(d_src), _lib.ptr(ws), ws.numel(), _lib.ptr(scratch), nscratch, st)
+        _lib.check(rc, "sr_dot_volume_bwd")
+        return None, d_cur, d_src, None, None, None, None
+
+
 class CostVolumeManager(nn.Module):
     """Dot-product plane-sweep volume (reference cost_volume.py:13-380)."""
+
+    differentiable = True   # HIP backward for cur_feats / src_feats (the MLP managers are inference-only so far)
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, matching_dim_size=None,
                  num_source_views=None):
@@ -66,7 +115,10 @@ class CostVolumeManager(nn.Module):
         for name, t in (("cur_feats", cur_feats), ("src_feats", src_feats), ("src_extrinsics", src_extrinsics),
                         ("src_Ks", src_Ks), ("cur_invK", cur_invK)):
             _lib.require_device_f32(name, t)
-        _lib.refuse_autograd(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
+        if self.differentiable:
+            _lib.refuse_autograd(src_extrinsics, src_poses, src_Ks, cur_invK)
+        else:
+            _lib.refuse_autograd(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
         if src_feats.dim() != 5 or cur_feats.dim() != 4:
             raise ValueError("expected cur_feats [b,c,h,w] and src_feats [b,k,c,h,w]")
         b, k, c, h, w = src_feats.shape
@@ -116,13 +168,23 @@ class CostVolumeManager(nn.Module):
                depth_planes_bdhw, return_mask):
         b, k, c, h, w = self._check_inputs(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
         planes = self._planes(b, min_depth, max_depth, depth_planes_bdhw)
-        dev = src_feats.device
+        cur, src = cur_feats.contiguous(), src_feats.contiguous()
+        Ks, T, invK = src_Ks.contiguous(), src_extrinsics.contiguous(), cur_invK.contiguous()
+        if torch.is_grad_enabled() and (cur.requires_grad or src.requires_grad):
+            _lib.refuse_autograd(planes)
+            vol, lowest = _DotVolumeFunction.apply(self, cur, src, Ks, T, invK, planes)
+        else:
+            vol, lowest = self._launch_sweep(cur, src, Ks, T, invK, planes)
+        # the dot model ignores return_mask and returns None (reference cost_volume.py:286, 335)
+        return vol, lowest, planes, None
+
+    def _launch_sweep(self, cur, src, Ks, T, invK, planes):
+        b, k, c, h, w = src.shape
+        dev = src.device
         lib = _lib.lib()
         vol, lowest, _ = self._alloc_outputs(b, h, w, dev, False)
         if b == 0:
-            return vol, lowest, planes, None
-        cur, src = cur_feats.contiguous(), src_feats.contiguous()
-        Ks, T, invK = src_Ks.contiguous(), src_extrinsics.contiguous(), cur_invK.contiguous()
+            return vol, lowest
         nws = lib.sr_volume_workspace_bytes(b, k, c, h, w)
         ws = self._get_workspace(nws, dev)
         sb, sd, sp = self._volume_strides(vol)
@@ -132,8 +194,7 @@ class CostVolumeManager(nn.Module):
                 *planes.stride(), b, k, c, h, w, self.num_depth_bins, _lib.ptr(vol), sb, sd, sp,
                 _lib.ptr(lowest), C.c_void_p(0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "sr_dot_volume_fwd")
-        # the dot model ignores return_mask and returns None (reference cost_volume.py:286, 335)
-        return vol, lowest, planes, None
+        return vol, lowest
 
     def _warp(self, src_feats, src_extrinsics, src_Ks, cur_invK, planes, want_pix):
         """Runs sr_warp_features_fwd for the Dp planes of `planes` ([b,Dp,h,w], any strides)."""
@@ -203,6 +264,8 @@ class FeatureVolumeManager(CostVolumeManager):
 
     `mlp_channels` is taken BY VALUE (the reference mutates a shared default list,
     cost_volume.py:402, 429 -- harmless there, not replicated)."""
+
+    differentiable = False   # inference only: the fused MLP sweep has no backward kernel yet (SURVEY.md §8f #3)
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=(202, 128, 128, 1),
                  matching_dim_size=16, num_source_views=7):

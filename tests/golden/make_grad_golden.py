@@ -1,0 +1,54 @@
+"""Generates tests/golden/grad_*.npz: gradients of the reference's cost-volume managers, from the reference's own
+autograd on CPU (build container only; needs /root/reference):
+
+    python tests/golden/make_grad_golden.py
+
+Groundwork for SURVEY.md §8f "next" #3 (backward pass of the fused cost volume): loss = sum(cost_volume * R) with a
+seeded cotangent R; stored are dL/d cur_feats, dL/d src_feats and (hero model) dL/d of the six MLP tensors.  Inputs,
+weights and R are regenerated from (seed, shape): see tests/golden_cases.py::GRAD_CASES / grad_cotangent.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import refshim  # noqa: E402
+import golden_cases as gc  # noqa: E402
+from simplerecon_amd import synthetic  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    torch.set_num_threads(8)
+    cv = refshim.import_reference()[0]
+    for name, case in gc.GRAD_CASES.items():
+        inp = gc.volume_inputs(case)
+        h, w, D, K, C = case["h"], case["w"], case["D"], case["K"], case["C"]
+        if case["model"] == "dot":
+            mgr = cv.CostVolumeManager(h, w, num_depth_bins=D)
+        else:
+            mgr = cv.FeatureVolumeManager(h, w, num_depth_bins=D, mlp_channels=[C * (K + 1) + 10 * K + 4, 128, 128, 1],
+                                          matching_dim_size=C, num_source_views=K)
+            synthetic.seeded_fill_(mgr.mlp, seed=case["seed"])
+        inp["cur_feats"].requires_grad_()
+        inp["src_feats"].requires_grad_()
+        vol = mgr(**inp)[0]
+        R = torch.from_numpy(gc.grad_cotangent(case))
+        (vol * R).sum().backward()
+        out = dict(cost_volume=vol.detach().numpy(), d_cur_feats=inp["cur_feats"].grad.numpy(),
+                   d_src_feats=inp["src_feats"].grad.numpy())
+        if case["model"] == "hero":
+            for k, prm in mgr.mlp.state_dict(keep_vars=True).items():
+                out["d_mlp." + k] = prm.grad.numpy()
+        np.savez_compressed(os.path.join(OUT, f"grad_{name}.npz"), **out)
+        print(name, {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,19 @@ def volume_inputs(case, device="cpu"):
     return {k: v.to(device) for k, v in inp.items()}
 
 
+# gradients of the cost-volume managers (reference autograd; groundwork for the backward pass)
+GRAD_CASES = {
+    "dot": dict(model="dot", B=1, K=2, C=16, D=4, h=12, w=16, seed=51),
+    "hero": dict(model="hero", B=1, K=2, C=16, D=3, h=10, w=12, seed=52),
+}
+
+
+def grad_cotangent(case):
+    """dL/d cost_volume of the gradient goldens: L = sum(cost_volume * R), R ~ N(0, 1) seeded."""
+    rng = np.random.default_rng(7000 + case["seed"])
+    return rng.standard_normal((case["B"], case["D"], case["h"], case["w"]), dtype=np.float32)
+
+
 def load_golden(prefix, name):
     return dict(np.load(os.path.join(GOLDEN_DIR, f"{prefix}_{name}.npz")))
 
