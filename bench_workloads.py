@@ -173,8 +173,7 @@ class HeroCfg3:
         self.frames_per_step = self.B
         opts = dm.default_options(image_width=4 * self.w, image_height=4 * self.h, model_num_views=self.K + 1,
                                   matching_num_depth_bins=self.D, feature_volume_type=self.feature_volume_type)
-        model = dm.DepthModel(opts, image_encoder=None if self.prior else dm.StandInPyramidEncoder(),
-                              matching_encoder=None if with_encoder else dm.StandInMatchingEncoder())
+        model = dm.DepthModel(opts)   # both encoders native; "*_noprior" / "*_core" simply do not run them
         if with_encoder:
             synthetic.seeded_fill_(model.matching_model, seed=4)
         if self.prior:

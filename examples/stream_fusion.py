@@ -1,12 +1,11 @@
 """End-to-end streaming example on synthetic data: posed frames -> online keyframe / source selection
-(simplerecon_amd.keyframes) -> DepthModel.forward (native matching encoder + plane-sweep cost volume + cost-volume
-encoder + UNet++ decoder on HIP kernels) -> TSDF fusion of the predicted depth (simplerecon_amd.tsdf).  It mirrors
+(simplerecon_amd.keyframes) -> DepthModel.forward (image-prior + matching encoders, plane-sweep cost volume, cost-volume
+encoder and UNet++ decoder, all on HIP kernels) -> TSDF fusion of the predicted depth (simplerecon_amd.tsdf).  It mirrors
 what the reference's test.py does per scan (test.py:210-410) without datasets, checkpoints or mesh export.
 
     python examples/stream_fusion.py [--frames 120] [--height 192] [--width 256]
 
-The image-prior encoder is a stand-in (the reference uses timm's EfficientNetV2-S, which is outside this path);
-weights are random, so the depth maps are meaningless -- the point is the data flow and the API.
+Weights are random, so the depth maps are meaningless -- the point is the data flow and the API.
 """
 import argparse
 import os

@@ -299,37 +299,3 @@ class DepthModel(nn.Module):
             matching_src_feats = torch.flip(matching_src_feats, (-1,))
         return self.hot_path(cur_feats, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam,
                              cur_cam_T_src_cam, src_K, cur_invK, return_mask=return_mask, flip=flip)
-
-
-class StandInPyramidEncoder(nn.Module):
-    """Shape-compatible stand-in for the image-prior encoder (5 scales, EfficientNetV2-S channel
-    counts) for synthetic runs where timm is unavailable.  NOT the reference's network."""
-
-    def __init__(self, chans=IMAGE_PRIOR_CHANNELS):
-        super().__init__()
-        self.num_ch_enc = list(chans)
-        cin = 3
-        self.stages = nn.ModuleList()
-        for c in chans:
-            self.stages.append(nn.Sequential(nn.Conv2d(cin, c, 3, stride=2, padding=1), nn.SiLU()))
-            cin = c
-
-    def forward(self, x):
-        out = []
-        for s in self.stages:
-            x = s(x)
-            out.append(x)
-        return out
-
-
-class StandInMatchingEncoder(nn.Module):
-    """Shape-compatible stand-in for ResnetMatchingEncoder (image/4 resolution, InstanceNorm'd
-    features).  NOT the reference's network."""
-
-    def __init__(self, dims=16):
-        super().__init__()
-        self.net = nn.Sequential(nn.Conv2d(3, 32, 7, stride=2, padding=3), nn.ReLU(),
-                                 nn.Conv2d(32, dims, 3, stride=2, padding=1), nn.InstanceNorm2d(dims))
-
-    def forward(self, x):
-        return self.net(x)

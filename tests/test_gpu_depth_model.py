@@ -18,7 +18,7 @@ def test_hot_path_matches_oracle_chain(fvt):
     B, K, C, D, h, w = 2, 3, 16, 8, 24, 32
     opts = dm.default_options(image_width=4 * w, image_height=4 * h, model_num_views=K + 1,
                               matching_num_depth_bins=D, feature_volume_type=fvt)
-    model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(), matching_encoder=dm.StandInMatchingEncoder())
+    model = dm.DepthModel(opts)
     synthetic.seeded_fill_(model.cost_volume_net, seed=1)
     synthetic.seeded_fill_(model.depth_decoder, seed=2)
     if fvt == "mlp_feature_volume":
@@ -107,11 +107,11 @@ def test_forward_all_native_matches_oracle_chain():
         assert_close(unb[k], ref[k], what=k + " (unbatched matching encoder)")
 
 
-def test_forward_api_with_stand_in_encoders():
+def test_forward_api_signature_and_output_keys():
     """DepthModel.forward keeps the reference's call signature and output keys (depth_model.py:247-407)."""
     B, K, H, W = 1, 2, 96, 128
     opts = dm.default_options(image_width=W, image_height=H, model_num_views=K + 1, matching_num_depth_bins=8)
-    model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(), matching_encoder=dm.StandInMatchingEncoder())
+    model = dm.DepthModel(opts)
     model = model.to(DEV).eval()
     inp = synthetic.cost_volume_inputs(B, K, 16, H // 4, W // 4, seed=2, device=DEV)
     eye = torch.eye(4, device=DEV)
@@ -138,7 +138,7 @@ def test_full_size_hot_path_properties():
     exp(log-depth), mask/argmax consistency of the sweep outputs."""
     B, K, C, D, h, w = 2, 7, 16, 64, 120, 160
     opts = dm.default_options(image_width=4 * w, image_height=4 * h, model_num_views=K + 1, matching_num_depth_bins=D)
-    model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder(), matching_encoder=dm.StandInMatchingEncoder())
+    model = dm.DepthModel(opts)
     synthetic.seeded_fill_(model.cost_volume_net, seed=1)
     synthetic.seeded_fill_(model.depth_decoder, seed=2)
     synthetic.seeded_fill_(model.cost_volume.mlp, seed=3)

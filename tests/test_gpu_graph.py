@@ -12,7 +12,7 @@ DEV = "cuda:0"
 
 def _model(h, w, K, D):
     opts = dm.default_options(image_width=4 * w, image_height=4 * h, model_num_views=K + 1, matching_num_depth_bins=D)
-    model = dm.DepthModel(opts, image_encoder=dm.StandInPyramidEncoder())
+    model = dm.DepthModel(opts)
     for i, m in enumerate((model.matching_model, model.cost_volume_net, model.depth_decoder, model.cost_volume.mlp)):
         synthetic.seeded_fill_(m, seed=10 + i)
     return model.to(DEV).eval()
