@@ -88,6 +88,22 @@ def dot_volume(cur, src, K_src, T_src_cur, invK_cur, planes, want_mask=False, pr
     return cv, low, (mask.astype(bool) if want_mask else None)
 
 
+def dot_volume_backward(grad_cv, cur, src, K_src, T_src_cur, invK_cur, planes, precision="f32"):
+    """(d_cur_feats, d_src_feats) of L for grad_cv = dL/d cost_volume [B,D,h,w] (sr_oracle_dot_volume_bwd)."""
+    cur, src, g = _f32(cur), _f32(src), _f32(grad_cv)
+    B, K, Cc, h, w = src.shape
+    K_src, T_src_cur, invK_cur = _f32(K_src), _f32(T_src_cur), _f32(invK_cur)
+    D = planes.shape[1]
+    p, ps = _planes_arg(planes, B, D, h, w)
+    dt, sfx = _dt(precision)
+    d_cur, d_src = np.empty((B, Cc, h, w), dt), np.empty((B, K, Cc, h, w), dt)
+    rc = getattr(lib(), "sr_oracle_dot_volume_bwd" + sfx)(
+        _ptr(g), _ptr(cur), _ptr(src), _ptr(K_src), _ptr(T_src_cur), _ptr(invK_cur), _ptr(p), C.c_long(ps[0]),
+        C.c_long(ps[1]), C.c_long(ps[2]), C.c_long(ps[3]), B, K, Cc, h, w, D, _ptr(d_cur), _ptr(d_src))
+    assert rc == 0, rc
+    return d_cur, d_src
+
+
 def pose_features(T_cur_src):
     """pose_distance (utils/geometry_utils.py:178-191) -> [B,K,3] = (dist, R_measure, t_measure), fp32."""
     T = _f32(T_cur_src)

@@ -140,6 +140,63 @@ int FN(sr_oracle_dot_volume)(const float* cur /*[B,C,h,w]*/, const float* src /*
   return 0;
 }
 
+/* Backward of the dot-product volume w.r.t. cur / src features (SURVEY.md §8f "next" #3): what autograd computes
+ * through CostVolumeManager.build_cost_volume -- F.grid_sample backward (cost_volume.py:201-212: each bilinear tap
+ * receives weight x upstream gradient, out-of-image taps nothing) and the backward of the masked dot product
+ * (cost_volume.py:322-329).  Geometry is data.  grad_cv is dense [B,D,h,w].  Serial over pixels inside an image
+ * (the scatter into d_src must not race): parallel over the batch only. */
+int FN(sr_oracle_dot_volume_bwd)(const float* grad_cv, const float* cur, const float* src, const float* K_src,
+                                 const float* T_src_cur, const float* invK_cur, const float* planes, long ps_b,
+                                 long ps_d, long ps_y, long ps_x, int B, int K, int C, int h, int w, int D,
+                                 OUT_T* d_cur /*[B,C,h,w]*/, OUT_T* d_src /*[B,K,C,h,w]*/) {
+  if (B < 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return 1;
+  const long N = (long)h * w;
+  for (long i = 0; i < (long)B * C * N; ++i) d_cur[i] = 0;
+  for (long i = 0; i < (long)B * K * C * N; ++i) d_src[i] = 0;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b) {
+    REAL* P = (REAL*)malloc(sizeof(REAL) * 16 * K);
+    for (int k = 0; k < K; ++k)
+      FN(mat44_mul)(K_src + ((long)b * K + k) * 16, T_src_cur + ((long)b * K + k) * 16, P + 16 * k);
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        const long pix = (long)y * w + x;
+        for (int j = 0; j < D; ++j) {
+          const REAL d = (REAL)planes[b * ps_b + j * ps_d + y * ps_y + x * ps_x];
+          const REAL g = (REAL)grad_cv[((long)b * D + j) * N + pix];
+          for (int k = 0; k < K; ++k) {
+            FN(proj_t) pr;
+            FN(backproject_project)(invK_cur + (long)b * 16, P + 16 * k, x, y, d, &pr);
+            if (!(pr.zp > 0)) continue; /* mask_k = 0: no gradient through this view */
+            /* the taps of bilinear_sample above */
+            const REAL sx = (REAL)(float)(1.0 / (double)w), sy = (REAL)(float)(1.0 / (double)h);
+            const REAL u = (REAL)2 * pr.pix_x * sx - (REAL)1, v = (REAL)2 * pr.pix_y * sy - (REAL)1;
+            const REAL ix = ((u + (REAL)1) * (REAL)w - (REAL)1) / (REAL)2;
+            const REAL iy = ((v + (REAL)1) * (REAL)h - (REAL)1) / (REAL)2;
+            const REAL fx0 = FLOOR(ix), fy0 = FLOOR(iy);
+            const REAL fx1 = fx0 + 1, fy1 = fy0 + 1;
+            const REAL wt[4] = {(fx1 - ix) * (fy1 - iy), (ix - fx0) * (fy1 - iy), (fx1 - ix) * (iy - fy0),
+                                (ix - fx0) * (iy - fy0)};
+            const REAL tx[4] = {fx0, fx1, fx0, fx1}, ty[4] = {fy0, fy0, fy1, fy1};
+            for (int t = 0; t < 4; ++t) {
+              if (!(tx[t] >= 0 && tx[t] <= (REAL)(w - 1) && ty[t] >= 0 && ty[t] <= (REAL)(h - 1))) continue;
+              const long tap = (long)ty[t] * w + (long)tx[t];
+              const REAL gw = g * wt[t];
+              for (int c = 0; c < C; ++c) {
+                const long sidx = (((long)b * K + k) * C + c) * N + tap;
+                const long cidx = ((long)b * C + c) * N + pix;
+                d_cur[cidx] += (OUT_T)(gw * (REAL)src[sidx]);
+                d_src[sidx] += (OUT_T)(gw * (REAL)cur[cidx]);
+              }
+            }
+          }
+        }
+      }
+    free(P);
+  }
+  return 0;
+}
+
 /* ---- metadata-MLP feature volume ---------------------------------------- */
 
 static inline REAL FN(leaky)(REAL v, REAL slope) { return v > 0 ? v : v * slope; }

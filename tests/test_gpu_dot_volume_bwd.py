@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import golden_cases as gc
+import oracle
 from parity import assert_close
 from simplerecon_amd import synthetic
 from simplerecon_amd.cost_volume import CostVolumeManager, FeatureVolumeManager
@@ -82,3 +83,21 @@ def test_bilinearity_identity_full_size(B, K, D, h, w):
         got = loss(**{key: inp[key] + v}) - base
         scale = float(grad.double().norm() * v.double().norm()) / np.sqrt(v.numel())
         assert abs(got - want) <= 2e-4 * max(scale, abs(want)), (key, got, want, scale)
+
+
+@pytest.mark.parametrize("case", [dict(B=2, K=3, D=5, h=37, w=29, seed=3), dict(B=1, K=4, D=6, h=20, w=28, seed=5, edge=True)])
+def test_gradients_match_oracle(case):
+    """Sizes / poses without reference goldens (ragged maps; a view behind the camera, identity pose, large rotation):
+    against oracle.dot_volume_backward, itself pinned to the reference's autograd in tests/test_oracle_grad_golden.py."""
+    case = dict(case, C=16, model="dot")
+    inp = {k: v.to(DEV) for k, v in gc.volume_inputs(case).items()}
+    mgr = CostVolumeManager(case["h"], case["w"], num_depth_bins=case["D"]).to(DEV)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    R = torch.randn((case["B"], case["D"], case["h"], case["w"]), generator=g)
+    _, d_cur, d_src = _grads(mgr, inp, R.to(DEV))
+    n = {k: v.cpu().numpy() for k, v in inp.items()}
+    planes = mgr.generate_depth_planes(case["B"], inp["min_depth"], inp["max_depth"])[:, :, 0, 0].cpu().numpy()
+    o_cur, o_src = oracle.dot_volume_backward(R.numpy(), n["cur_feats"], n["src_feats"], n["src_Ks"], n["src_extrinsics"],
+                                              n["cur_invK"], planes)
+    assert_close(d_cur, o_cur, what="d cur_feats vs oracle")
+    assert_close(d_src, o_src, what="d src_feats vs oracle")
