@@ -141,6 +141,31 @@ def mlp_volume(cur, src, K_src, T_src_cur, T_cur_src, invK_cur, planes, mlp, wan
     return cv, low, (mask.astype(bool) if want_mask else None)
 
 
+def mlp_volume_backward(grad_cv, cur, src, K_src, T_src_cur, T_cur_src, invK_cur, planes, mlp, precision="f32"):
+    """Gradients of L w.r.t. (cur_feats, src_feats, W1, b1, W2, b2, W3, b3) for grad_cv = dL/d cost_volume of the
+    metadata-MLP volume (sr_oracle_mlp_volume_bwd); returns a dict keyed d_cur_feats, d_src_feats, dW1, ..."""
+    cur, src, g = _f32(cur), _f32(src), _f32(grad_cv)
+    B, K, Cc, h, w = src.shape
+    K_src, T_src_cur, T_cur_src, invK_cur = _f32(K_src), _f32(T_src_cur), _f32(T_cur_src), _f32(invK_cur)
+    D = planes.shape[1]
+    p, ps = _planes_arg(planes, B, D, h, w)
+    pf = _f32(pose_features(T_cur_src))
+    W1, b1, W2, b2, W3, b3 = (_f32(mlp[k]) for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
+    Hd, Cin = W1.shape
+    assert Cin == Cc * (K + 1) + 10 * K + 4, (W1.shape, Cc, K)
+    dt, sfx = _dt(precision)
+    out = dict(d_cur_feats=np.empty((B, Cc, h, w), dt), d_src_feats=np.empty((B, K, Cc, h, w), dt),
+               dW1=np.empty((Hd, Cin), dt), db1=np.empty((Hd,), dt), dW2=np.empty((Hd, Hd), dt),
+               db2=np.empty((Hd,), dt), dW3=np.empty((1, Hd), dt), db3=np.empty((1,), dt))
+    rc = getattr(lib(), "sr_oracle_mlp_volume_bwd" + sfx)(
+        _ptr(g), _ptr(cur), _ptr(src), _ptr(K_src), _ptr(T_src_cur), _ptr(T_cur_src), _ptr(invK_cur), _ptr(pf),
+        _ptr(p), C.c_long(ps[0]), C.c_long(ps[1]), C.c_long(ps[2]), C.c_long(ps[3]),
+        _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(W3), _ptr(b3), B, K, Cc, h, w, D, Hd,
+        *[_ptr(out[k]) for k in ("d_cur_feats", "d_src_feats", "dW1", "db1", "dW2", "db2", "dW3", "db3")])
+    assert rc == 0, rc
+    return out
+
+
 def mlp_input(cur, src, K_src, T_src_cur, T_cur_src, invK_cur, d, b, y, x, precision="f32"):
     cur, src = _f32(cur), _f32(src)
     B, K, Cc, h, w = src.shape

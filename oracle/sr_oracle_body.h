@@ -303,6 +303,190 @@ int FN(sr_oracle_mlp_volume)(const float* cur, const float* src, const float* K_
   return 0;
 }
 
+/* Backward of the metadata-MLP volume (SURVEY.md §8f "next" #3) -- what autograd computes through
+ * FeatureVolumeManager.build_cost_volume + MLP for grad_cv = dL/d cost_volume (dense [B,D,h,w]):
+ *   MLP:  d3 = g;  dh2 = W3^T d3;  dz2 = dh2 * lrelu'(z2);  dh1 = W2^T dz2;  dz1 = dh1 * lrelu'(z1);  df = W1^T dz1
+ *         dW3 += g h2^T, db3 += g, dW2 += dz2 h1^T, db2 += dz2, dW1 += dz1 f^T, db1 += dz1      (networks.py:129-147)
+ *   features that depend on the matching features (cost_volume.py:691-723):
+ *         warped[k,c] = f[kC+c] (unmasked), cur[c] = f[KC+c], dot_k = m_k sum_c warped[k,c] cur[c]
+ *     => d_warped[k,c] = df[kC+c] + df[o_dot+k] m_k cur[c];   d_cur[c] += df[KC+c] + sum_k df[o_dot+k] m_k warped[k,c]
+ *     => grid_sample backward: d_src[b,k,c,tap_t] += w_t d_warped[k,c] for the in-image taps (cost_volume.py:201-212)
+ *   every other channel (mask, z', d, rays, angles, pose measures) is a function of the geometry only: no gradient.
+ * Weight gradients are accumulated in REAL per thread and merged at the end; d_src entries with omp atomic. */
+int FN(sr_oracle_mlp_volume_bwd)(const float* grad_cv, const float* cur, const float* src, const float* K_src,
+                                 const float* T_src_cur, const float* T_cur_src, const float* invK_cur,
+                                 const float* pose_feats, const float* planes, long ps_b, long ps_d, long ps_y,
+                                 long ps_x, const float* W1, const float* b1, const float* W2, const float* b2,
+                                 const float* W3, const float* b3, int B, int K, int C, int h, int w, int D, int Hd,
+                                 OUT_T* d_cur, OUT_T* d_src, OUT_T* dW1, OUT_T* db1, OUT_T* dW2, OUT_T* db2,
+                                 OUT_T* dW3, OUT_T* db3) {
+  if (B < 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0 || Hd <= 0) return 1;
+  (void)b3;
+  const long N = (long)h * w;
+  const int Cin = C * (K + 1) + 10 * K + 4;
+  const REAL slope = (REAL)0.01f;
+  const long nW = (long)Hd * Cin + Hd + (long)Hd * Hd + Hd + Hd + 1;   /* dW1 | db1 | dW2 | db2 | dW3 | db3 */
+  REAL* total = (REAL*)calloc((size_t)nW, sizeof(REAL));
+  for (long i = 0; i < (long)B * C * N; ++i) d_cur[i] = 0;
+  for (long i = 0; i < (long)B * K * C * N; ++i) d_src[i] = 0;
+#pragma omp parallel
+  {
+    REAL* acc = (REAL*)calloc((size_t)nW, sizeof(REAL));
+    REAL *aW1 = acc, *ab1 = aW1 + (long)Hd * Cin, *aW2 = ab1 + Hd, *ab2 = aW2 + (long)Hd * Hd, *aW3 = ab2 + Hd,
+         *ab3 = aW3 + Hd;
+    REAL* P = (REAL*)malloc(sizeof(REAL) * 16 * K);
+    REAL* f = (REAL*)malloc(sizeof(REAL) * Cin);
+    REAL* df = (REAL*)malloc(sizeof(REAL) * Cin);
+    REAL* z1 = (REAL*)malloc(sizeof(REAL) * Hd);
+    REAL* h1 = (REAL*)malloc(sizeof(REAL) * Hd);
+    REAL* z2 = (REAL*)malloc(sizeof(REAL) * Hd);
+    REAL* h2 = (REAL*)malloc(sizeof(REAL) * Hd);
+    REAL* dz1 = (REAL*)malloc(sizeof(REAL) * Hd);
+    REAL* dz2 = (REAL*)malloc(sizeof(REAL) * Hd);
+    REAL* tw = (REAL*)malloc(sizeof(REAL) * 4 * K);   /* tap weights, 0 for out-of-image taps */
+    long* ti = (long*)malloc(sizeof(long) * 4 * K);   /* tap texel index */
+    REAL* mk = (REAL*)malloc(sizeof(REAL) * K);
+    REAL* dcur = (REAL*)malloc(sizeof(REAL) * C);
+    const int o_cur = K * C, o_mask = o_cur + C, o_z = o_mask + K, o_d = o_z + K, o_dot = o_d + 1;
+    const int o_ang = o_dot + K, o_cray = o_ang + K, o_sray = o_cray + 3, o_pd = o_sray + 3 * K;
+    const int o_rm = o_pd + K, o_tm = o_rm + K;
+#pragma omp for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+      for (int y = 0; y < h; ++y) {
+        for (int k = 0; k < K; ++k)
+          FN(mat44_mul)(K_src + ((long)b * K + k) * 16, T_src_cur + ((long)b * K + k) * 16, P + 16 * k);
+        for (int x = 0; x < w; ++x) {
+          const long pix = (long)y * w + x;
+          for (int c = 0; c < C; ++c) { f[o_cur + c] = (REAL)cur[((long)b * C + c) * N + pix]; dcur[c] = 0; }
+          for (int k = 0; k < K; ++k) {
+            f[o_pd + k] = (REAL)pose_feats[((long)b * K + k) * 3 + 0];
+            f[o_rm + k] = (REAL)pose_feats[((long)b * K + k) * 3 + 1];
+            f[o_tm + k] = (REAL)pose_feats[((long)b * K + k) * 3 + 2];
+          }
+          for (int j = 0; j < D; ++j) {
+            const REAL d = (REAL)planes[b * ps_b + j * ps_d + y * ps_y + x * ps_x];
+            const REAL g = (REAL)grad_cv[((long)b * D + j) * N + pix];
+            f[o_d] = d;
+            /* ---- forward features, as in sr_oracle_mlp_volume, remembering the taps ---- */
+            for (int k = 0; k < K; ++k) {
+              FN(proj_t) pr;
+              FN(backproject_project)(invK_cur + (long)b * 16, P + 16 * k, x, y, d, &pr);
+              const REAL sx = (REAL)(float)(1.0 / (double)w), sy = (REAL)(float)(1.0 / (double)h);
+              const REAL u = (REAL)2 * pr.pix_x * sx - (REAL)1, v = (REAL)2 * pr.pix_y * sy - (REAL)1;
+              const REAL ix = ((u + (REAL)1) * (REAL)w - (REAL)1) / (REAL)2;
+              const REAL iy = ((v + (REAL)1) * (REAL)h - (REAL)1) / (REAL)2;
+              const REAL fx0 = FLOOR(ix), fy0 = FLOOR(iy);
+              const REAL fx1 = fx0 + 1, fy1 = fy0 + 1;
+              const REAL wt[4] = {(fx1 - ix) * (fy1 - iy), (ix - fx0) * (fy1 - iy), (fx1 - ix) * (iy - fy0),
+                                  (ix - fx0) * (iy - fy0)};
+              const REAL tx[4] = {fx0, fx1, fx0, fx1}, ty[4] = {fy0, fy0, fy1, fy1};
+              for (int c = 0; c < C; ++c) f[k * C + c] = 0;
+              for (int t = 0; t < 4; ++t) {
+                const int ok = (tx[t] >= 0 && tx[t] <= (REAL)(w - 1) && ty[t] >= 0 && ty[t] <= (REAL)(h - 1));
+                tw[4 * k + t] = ok ? wt[t] : (REAL)0;
+                ti[4 * k + t] = ok ? (long)ty[t] * w + (long)tx[t] : 0;
+                if (ok)
+                  for (int c = 0; c < C; ++c)
+                    f[k * C + c] += (REAL)src[(((long)b * K + k) * C + c) * N + ti[4 * k + t]] * wt[t];
+              }
+              REAL dot = 0;
+              for (int c = 0; c < C; ++c) dot += f[k * C + c] * f[o_cur + c];
+              const REAL m = pr.zp > 0 ? (REAL)1 : (REAL)0;
+              mk[k] = m;
+              f[o_mask + k] = m;
+              f[o_z + k] = pr.zp;
+              f[o_dot + k] = dot * m;
+              REAL cn = SQRT(pr.X[0] * pr.X[0] + pr.X[1] * pr.X[1] + pr.X[2] * pr.X[2]);
+              REAL cden = cn > (REAL)1e-12 ? cn : (REAL)1e-12;
+              REAL cr[3], sr[3], sv[3];
+              const float* Tcs = T_cur_src + ((long)b * K + k) * 16;
+              for (int i = 0; i < 3; ++i) { cr[i] = pr.X[i] / cden; sv[i] = pr.X[i] - (REAL)Tcs[i * 4 + 3]; }
+              REAL sn = SQRT(sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2]);
+              REAL sden = sn > (REAL)1e-12 ? sn : (REAL)1e-12;
+              for (int i = 0; i < 3; ++i) sr[i] = sv[i] / sden;
+              if (k == 0) for (int i = 0; i < 3; ++i) f[o_cray + i] = cr[i];
+              for (int i = 0; i < 3; ++i) f[o_sray + 3 * k + i] = sr[i];
+              REAL n1 = SQRT(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+              REAL n2 = SQRT(sr[0] * sr[0] + sr[1] * sr[1] + sr[2] * sr[2]);
+              n1 = n1 > (REAL)1e-5f ? n1 : (REAL)1e-5f;
+              n2 = n2 > (REAL)1e-5f ? n2 : (REAL)1e-5f;
+              f[o_ang + k] = (cr[0] / n1) * (sr[0] / n2) + (cr[1] / n1) * (sr[1] / n2) + (cr[2] / n1) * (sr[2] / n2);
+            }
+            /* ---- MLP forward keeping pre-activations ---- */
+            for (int o = 0; o < Hd; ++o) {
+              REAL s0 = (REAL)b1[o];
+              const float* wr = W1 + (long)o * Cin;
+              for (int i = 0; i < Cin; ++i) s0 += (REAL)wr[i] * f[i];
+              z1[o] = s0; h1[o] = FN(leaky)(s0, slope);
+            }
+            for (int o = 0; o < Hd; ++o) {
+              REAL s0 = (REAL)b2[o];
+              const float* wr = W2 + (long)o * Hd;
+              for (int i = 0; i < Hd; ++i) s0 += (REAL)wr[i] * h1[i];
+              z2[o] = s0; h2[o] = FN(leaky)(s0, slope);
+            }
+            /* ---- MLP backward ---- */
+            ab3[0] += g;
+            for (int i = 0; i < Hd; ++i) {
+              aW3[i] += g * h2[i];
+              dz2[i] = g * (REAL)W3[i] * (z2[i] > 0 ? (REAL)1 : slope);
+              ab2[i] += dz2[i];
+            }
+            for (int i = 0; i < Hd; ++i) dz1[i] = 0;
+            for (int o = 0; o < Hd; ++o) {
+              const float* wr = W2 + (long)o * Hd;
+              REAL* ar = aW2 + (long)o * Hd;
+              for (int i = 0; i < Hd; ++i) { ar[i] += dz2[o] * h1[i]; dz1[i] += (REAL)wr[i] * dz2[o]; }
+            }
+            for (int i = 0; i < Hd; ++i) { dz1[i] *= (z1[i] > 0 ? (REAL)1 : slope); ab1[i] += dz1[i]; }
+            for (int i = 0; i < Cin; ++i) df[i] = 0;
+            for (int o = 0; o < Hd; ++o) {
+              const float* wr = W1 + (long)o * Cin;
+              REAL* ar = aW1 + (long)o * Cin;
+              for (int i = 0; i < Cin; ++i) { ar[i] += dz1[o] * f[i]; df[i] += (REAL)wr[i] * dz1[o]; }
+            }
+            /* ---- features -> matching features ---- */
+            for (int c = 0; c < C; ++c) dcur[c] += df[o_cur + c];
+            for (int k = 0; k < K; ++k) {
+              const REAL ddot = df[o_dot + k] * mk[k];
+              for (int c = 0; c < C; ++c) {
+                const REAL dwarp = df[k * C + c] + ddot * f[o_cur + c];
+                dcur[c] += ddot * f[k * C + c];
+                for (int t = 0; t < 4; ++t) {
+                  if (tw[4 * k + t] == 0) continue;
+                  const OUT_T add = (OUT_T)(tw[4 * k + t] * dwarp);
+#pragma omp atomic
+                  d_src[(((long)b * K + k) * C + c) * N + ti[4 * k + t]] += add;
+                }
+              }
+            }
+          }
+          for (int c = 0; c < C; ++c) d_cur[((long)b * C + c) * N + pix] = (OUT_T)dcur[c];
+        }
+      }
+#pragma omp critical
+    for (long i = 0; i < nW; ++i) total[i] += acc[i];
+    free(acc); free(P); free(f); free(df); free(z1); free(h1); free(z2); free(h2); free(dz1); free(dz2);
+    free(tw); free(ti); free(mk); free(dcur);
+  }
+  {
+    const REAL* t = total;
+    for (long i = 0; i < (long)Hd * Cin; ++i) dW1[i] = (OUT_T)t[i];
+    t += (long)Hd * Cin;
+    for (int i = 0; i < Hd; ++i) db1[i] = (OUT_T)t[i];
+    t += Hd;
+    for (long i = 0; i < (long)Hd * Hd; ++i) dW2[i] = (OUT_T)t[i];
+    t += (long)Hd * Hd;
+    for (int i = 0; i < Hd; ++i) db2[i] = (OUT_T)t[i];
+    t += Hd;
+    for (int i = 0; i < Hd; ++i) dW3[i] = (OUT_T)t[i];
+    t += Hd;
+    db3[0] = (OUT_T)t[0];
+  }
+  free(total);
+  return 0;
+}
+
 /* ---- dumps of the MLP input vector (debug/parity aid) -------------------- */
 
 /* Writes the Cin-vector the MLP sees at (b, j, y, x); same code path as above,
