@@ -344,6 +344,22 @@ int sr_dot_volume_bwd(const float* grad_cv, int64_t g_sb, int64_t g_sd, int64_t 
                       int64_t ps_x, int B, int K, int C, int h, int w, int D, float* d_cur, float* d_src,
                       void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Backward of sr_mlp_volume_sweep (reference: autograd through FeatureVolumeManager.build_cost_volume + MLP,
+ * modules/cost_volume.py:451-736, modules/networks.py:129-147): d_cur [B,C,h,w], d_src [B,K,C,h,w] and the gradients
+ * of the six MLP tensors in their nn.Linear layouts (dW1 [hidden][Cin], db1, dW2 [hidden][hidden], db2, dW3 [1][hidden],
+ * db3 [1]; all written, not accumulated).  W1..W3 are the UNPACKED nn.Linear weights.  `workspace` must have been filled
+ * by sr_volume_prepare WITH T_cur_src (pose features) for the same sources; `scratch`
+ * (sr_mlp_volume_bwd_scratch_bytes, 256-byte aligned) holds the channels-last d_src image and weight transposes.
+ * First version: fp32 VALU, hidden = 128, C = 16, C(K+1) + 10K + 4 <= 256 (up to 9 views); SR_ERR_UNSUPPORTED otherwise.
+ * Feature-map and weight gradients are accumulated with hardware fp32 atomics (summation order not fixed). */
+size_t sr_mlp_volume_bwd_scratch_bytes(int B, int K, int C, int h, int w, int hidden);
+int sr_mlp_volume_bwd(const float* grad_cv, int64_t g_sb, int64_t g_sd, int64_t g_sp, const float* cur,
+                      const float* invK_cur, const float* planes, int64_t ps_b, int64_t ps_d, int64_t ps_y,
+                      int64_t ps_x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                      float leaky_slope, int B, int K, int C, int h, int w, int D, int hidden, float* d_cur,
+                      float* d_src, float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
+                      void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ------------------------------------------------------ image-prior encoder ------------
  *
  * timm `tf_efficientnetv2_s` feature pyramid (reference modules/depth_model.py:110-116: the `encoder` of

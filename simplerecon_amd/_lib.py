@@ -55,6 +55,9 @@ SIGNATURES = {
     "sr_dot_volume_bwd_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sr_dot_volume_bwd": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _p, _p,
                                _p, _sz, _p, _sz, _p]),
+    "sr_mlp_volume_bwd_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "sr_mlp_volume_bwd": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _f, _i, _i,
+                               _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _sz, _p]),
     "sr_conv_splitk_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_conv2d_splitk_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i,
                                        _f, _p, _sz, _p]),

@@ -9,9 +9,11 @@ parameter/buffer names as the reference (cost_volume.py:13-380 `CostVolumeManage
 works exactly like the reference's own `to_fast()` seam (reference test.py:196-198) and a
 reference checkpoint loads with strict=True.  The arithmetic runs in hand-written gfx950
 kernels reached through the C ABI of include/simplerecon_hip.h; there is no torch/CPU
-fallback (inputs must be fp32 device tensors).  Inference everywhere; in addition the dot-product
-`CostVolumeManager` is differentiable w.r.t. the matching features (HIP backward kernel,
-`_DotVolumeFunction`) -- the first piece of the training path (SURVEY.md §8f "next" #3).
+fallback (inputs must be fp32 device tensors).  Inference everywhere; in addition both cost volumes have HIP
+backward kernels behind torch.autograd.Functions -- the first piece of the training path (SURVEY.md §8f "next" #3):
+the dot-product `CostVolumeManager` w.r.t. the matching features (`_DotVolumeFunction`), and, opt-in through
+`manager.differentiable = True`, the metadata-MLP `FeatureVolumeManager` w.r.t. the matching features and the six
+MLP tensors (`_MlpVolumeFunction`).
 """
 import ctypes as C
 
@@ -66,6 +68,61 @@ class _DotVolumeFunction(torch.autograd.Function):
                                        _lib.ptr(d_src), _lib.ptr(ws), ws.numel(), _lib.ptr(scratch), nscratch, st)
         _lib.check(rc, "sr_dot_volume_bwd")
         return None, d_cur, d_src, None, None, None, None
+
+
+class _MlpVolumeFunction(torch.autograd.Function):
+    """cost_volume, lowest_cost, mask = metadata-MLP sweep with the HIP backward (csrc/sr_mlp_volume_bwd.hip) for the two
+    feature tensors and the six MLP tensors; geometry is data, `lowest_cost` / mask carry no gradient (as in the
+    reference, cost_volume.py:360-372)."""
+
+    @staticmethod
+    def forward(ctx, mgr, return_mask, cur, src, Ks, T, Tp, invK, planes, W1, b1, W2, b2, W3, b3):
+        vol, lowest, mask = mgr._launch_sweep(cur, src, Ks, T, Tp, invK, planes, (W1, b1, W2, b2, W3, b3), return_mask)
+        ctx.save_for_backward(cur, src, Ks, T, Tp, invK, planes, W1, b1, W2, b2, W3, b3)
+        if mask is not None:
+            ctx.mark_non_differentiable(lowest, mask)   # one call: a second one would replace the first
+            return vol, lowest, mask
+        ctx.mark_non_differentiable(lowest)
+        return vol, lowest, None
+
+    @staticmethod
+    def backward(ctx, g_vol, _g_lowest, _g_mask):
+        cur, src, Ks, T, Tp, invK, planes, W1, b1, W2, b2, W3, b3 = ctx.saved_tensors
+        if any(ctx.needs_input_grad[4:9]):
+            raise NotImplementedError("the cost volume is not differentiated w.r.t. poses / intrinsics / depth planes "
+                                      "(they are data in the reference's training too)")
+        b, k, c, h, w = src.shape
+        d = planes.shape[1]
+        hidden = W1.shape[0]
+        dev = src.device
+        lib = _lib.lib()
+        g = g_vol if g_vol.dtype == torch.float32 else g_vol.float()
+        if g.stride(2) != w * g.stride(3):
+            g = g.contiguous()
+        d_cur, d_src = torch.empty_like(cur), torch.empty_like(src)
+        grads = [torch.empty_like(t) for t in (W1, b1, W2, b2, W3, b3)]
+        if b == 0:
+            for t in grads:
+                t.zero_()
+        else:
+            ws = torch.empty(lib.sr_volume_workspace_bytes(b, k, c, h, w), dtype=torch.uint8, device=dev)
+            scratch = torch.empty(lib.sr_mlp_volume_bwd_scratch_bytes(b, k, c, h, w, hidden), dtype=torch.uint8,
+                                  device=dev)
+            st = _lib.stream_ptr(dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.sr_volume_prepare(_lib.ptr(src), _lib.ptr(Ks), _lib.ptr(T), _lib.ptr(Tp), b, k, c, h, w,
+                                                 _lib.ptr(ws), ws.numel(), st), "sr_volume_prepare")
+                rc = lib.sr_mlp_volume_bwd(_lib.ptr(g), g.stride(0), g.stride(1), g.stride(3), _lib.ptr(cur),
+                                           _lib.ptr(invK), _lib.ptr(planes), *planes.stride(),
+                                           *[_lib.ptr(t.detach()) for t in (W1, b1, W2, b2, W3)], C.c_float(0.01), b, k, c,
+                                           h, w, d, hidden, _lib.ptr(d_cur), _lib.ptr(d_src),
+                                           *[_lib.ptr(t) for t in grads], _lib.ptr(ws), ws.numel(), _lib.ptr(scratch),
+                                           scratch.numel(), st)
+            _lib.check(rc, "sr_mlp_volume_bwd")
+        need = ctx.needs_input_grad
+        out = [None, None, d_cur if need[2] else None, d_src if need[3] else None, None, None, None, None, None]
+        out += [gr if need[9 + i] else None for i, gr in enumerate(grads)]
+        return tuple(out)
 
 
 class CostVolumeManager(nn.Module):
@@ -265,7 +322,10 @@ class FeatureVolumeManager(CostVolumeManager):
     `mlp_channels` is taken BY VALUE (the reference mutates a shared default list,
     cost_volume.py:402, 429 -- harmless there, not replicated)."""
 
-    differentiable = False   # inference only: the fused MLP sweep has no backward kernel yet (SURVEY.md §8f #3)
+    # The MLP sweep has a HIP backward (csrc/sr_mlp_volume_bwd.hip, gradients = the reference's autograd) but it is
+    # OPT-IN for now (`manager.differentiable = True`): nn.Parameters require grad by default, so turning it on makes
+    # every grad-enabled call build an autograd graph, and the conv stack / encoders around it are inference-only.
+    differentiable = False
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=(202, 128, 128, 1),
                  matching_dim_size=16, num_source_views=7):
@@ -296,19 +356,32 @@ class FeatureVolumeManager(CostVolumeManager):
             raise ValueError(f"MLP expects {lin[0].in_features} input channels but {k} views x {c} channels "
                              f"give {mlp_input_channels(c, k)}")
         planes = self._planes(b, min_depth, max_depth, depth_planes_bdhw)
-        dev = src_feats.device
-        lib = _lib.lib()
-        vol, lowest, mask = self._alloc_outputs(b, h, w, dev, return_mask)
-        if b == 0:
-            return vol, lowest, planes, (mask.bool() if return_mask else None)
         cur, src = cur_feats.contiguous(), src_feats.contiguous()
         Ks, T, Tp, invK = (src_Ks.contiguous(), src_extrinsics.contiguous(), src_poses.contiguous(),
                            cur_invK.contiguous())
-        params = [t.detach().contiguous() for t in (lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
-                                                    lin[2].weight, lin[2].bias)]
-        for i, t in enumerate(params):
+        weights = (lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias)
+        for i, t in enumerate(weights):
             _lib.require_device_f32(f"mlp parameter {i}", t)
-        hidden = lin[0].out_features
+        wants_grad = self.differentiable and torch.is_grad_enabled() and \
+            any(t.requires_grad for t in (cur, src) + weights)
+        if wants_grad:
+            _lib.refuse_autograd(planes)
+            vol, lowest, mask = _MlpVolumeFunction.apply(self, bool(return_mask), cur, src, Ks, T, Tp, invK, planes,
+                                                         *[t.contiguous() for t in weights])
+        else:
+            vol, lowest, mask = self._launch_sweep(cur, src, Ks, T, Tp, invK, planes,
+                                                   [t.detach().contiguous() for t in weights], return_mask)
+        return vol, lowest, planes, (mask.bool() if mask is not None else None)
+
+    def _launch_sweep(self, cur, src, Ks, T, Tp, invK, planes, params, return_mask):
+        b, k, c, h, w = src.shape
+        dev = src.device
+        lib = _lib.lib()
+        vol, lowest, mask = self._alloc_outputs(b, h, w, dev, return_mask)
+        if b == 0:
+            return vol, lowest, mask
+        params = [t.detach() for t in params]
+        hidden = params[0].shape[0]
         nws = lib.sr_mlp_volume_workspace_bytes(b, k, c, h, w, hidden)
         ws = self._get_workspace(nws, dev)
         sb, sd, sp = self._volume_strides(vol)
@@ -320,7 +393,7 @@ class FeatureVolumeManager(CostVolumeManager):
                 b, k, c, h, w, self.num_depth_bins, _lib.ptr(vol), sb, sd, sp, _lib.ptr(lowest),
                 _lib.ptr(mask), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "sr_mlp_volume_fwd")
-        return vol, lowest, planes, (mask.bool() if return_mask else None)
+        return vol, lowest, mask
 
     def to_fast(self) -> "FastFeatureVolumeManager":
         """Same seam as the reference (cost_volume.py:739-746): shares the MLP."""

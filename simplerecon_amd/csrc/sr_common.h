@@ -118,5 +118,7 @@ int sr_launch_argmax_planes(const float* cv, int64_t sb, int64_t sd, int64_t sp,
 int sr_launch_splitk_reduce(const float* part, int ksplit, int64_t part_stride, const float* bias, const float* res,
                             int64_t res_sb, int res_sp, float* out, int64_t out_sb, int out_sp, int B, int HW, int Cout,
                             float slope, hipStream_t stream);
+// [images, npix, C] -> [images, C, npix] (C % 4 == 0); defined in sr_dot_volume_bwd.hip
+int sr_launch_unpack_nhwc(const float* src_nhwc, float* dst_nchw, int images, int C, int npix, hipStream_t stream);
 int sr_launch_pack_nhwc(const float* src_nchw, float* dst_nhwc, int images, int C, int npix,
                         hipStream_t stream);

@@ -126,6 +126,13 @@ __global__ __launch_bounds__(256) void sr_unpack_nhwc_kernel(const float* __rest
 
 }  // namespace
 
+int sr_launch_unpack_nhwc(const float* src_nhwc, float* dst_nchw, int images, int C, int npix, hipStream_t stream) {
+  if (images == 0 || npix == 0) return SR_OK;
+  hipLaunchKernelGGL(sr_unpack_nhwc_kernel, dim3((npix + 255) / 256, images), dim3(256), 0, stream, src_nhwc, dst_nchw,
+                     C, npix);
+  return sr_hip_rc(hipGetLastError());
+}
+
 extern "C" size_t sr_dot_volume_bwd_scratch_bytes(int B, int K, int C, int h, int w) {
   if (B < 0 || K < 0 || C < 0 || h < 0 || w < 0) return 0;
   return (size_t)B * K * h * w * C * sizeof(float);
@@ -169,7 +176,5 @@ extern "C" int sr_dot_volume_bwd(const float* grad_cv, int64_t g_sb, int64_t g_s
   }
   int rc = sr_hip_rc(hipGetLastError());
   if (rc != SR_OK || !d_src) return rc;
-  hipLaunchKernelGGL(sr_unpack_nhwc_kernel, dim3((N + 255) / 256, B * K), dim3(256), 0, stream,
-                     (const float*)scratch, d_src, C, N);
-  return sr_hip_rc(hipGetLastError());
+  return sr_launch_unpack_nhwc((const float*)scratch, d_src, B * K, C, N, stream);
 }
