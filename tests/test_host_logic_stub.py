@@ -1,0 +1,143 @@
+"""Host-side logic of the cost-volume managers and of the whole DepthModel on CPU: the C-ABI library is replaced by a stub that checks every call
+against the ctypes signature table (argument count and kinds) and returns success, so the Python control flow --
+argument packing, output allocation, mask handling, the autograd seams and their bookkeeping -- runs without a GPU.
+No numerics here: the kernels themselves are covered by the `-m gpu` tests."""
+import contextlib
+import ctypes
+
+import pytest
+import torch
+
+from simplerecon_amd import _lib, synthetic
+from simplerecon_amd import cost_volume as cv
+
+B, K, C, H, W, D = 2, 3, 16, 8, 12, 4
+
+
+@pytest.fixture
+def stub(monkeypatch):
+    class Calls(list):
+        prefer_wino = False
+    calls = Calls()
+
+    class Stream:
+        cuda_stream = 0
+
+    class Fn:
+        def __init__(self, name):
+            self.name = name
+
+        def __call__(self, *args):
+            res, argtypes = _lib.SIGNATURES[self.name]
+            assert len(args) == len(argtypes), (self.name, len(args), len(argtypes))
+            for v, t in zip(args, argtypes):
+                if t is ctypes.c_void_p:
+                    assert v is None or isinstance(v, (ctypes.c_void_p, int)), (self.name, type(v))
+                elif t is ctypes.c_float:
+                    assert isinstance(v, (float, ctypes.c_float)), (self.name, type(v))
+                else:
+                    assert isinstance(v, int), (self.name, type(v), v)
+            calls.append(self.name)
+            if self.name == "sr_conv_prefers_wino":
+                return int(calls.prefer_wino)
+            if res is ctypes.c_char_p:
+                return b"stub_kernel"
+            return 4096 if res is ctypes.c_size_t else 0
+
+    class Lib:
+        def __getattr__(self, name):
+            return Fn(name)
+
+    monkeypatch.setattr(_lib, "lib", lambda: Lib())
+    monkeypatch.setattr(_lib, "require_device_f32", lambda *a, **k: None)
+    monkeypatch.setattr(_lib, "stream_ptr", lambda dev=None: ctypes.c_void_p(0))
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: Stream())
+    return calls
+
+
+@pytest.mark.parametrize("cls,kw,fwd", [(cv.CostVolumeManager, {}, "sr_dot_volume_fwd"),
+                                        (cv.FeatureVolumeManager, dict(num_source_views=K), "sr_mlp_volume_fwd"),
+                                        (cv.FastFeatureVolumeManager, dict(num_source_views=K), "sr_mlp_volume_fwd")])
+def test_inference_paths(stub, cls, kw, fwd):
+    inp = synthetic.cost_volume_inputs(B, K, C, H, W, seed=1)
+    mgr = cls(H, W, num_depth_bins=D, **kw)
+    for return_mask in (False, True):
+        del stub[:]
+        with torch.inference_mode():
+            vol, lowest, planes, mask = mgr(return_mask=return_mask, **inp)
+        assert vol.shape == (B, D, H, W) and lowest.shape == (B, H, W) and planes.shape == (B, D, H, W)
+        # the dot model ignores return_mask (reference cost_volume.py:286, 335)
+        assert (mask is None) == (not return_mask or cls is cv.CostVolumeManager)
+        assert mask is None or mask.dtype == torch.bool
+        assert stub[-1] == fwd
+    # grad mode on, parameters require grad, features do not: still the plain path, no autograd graph
+    assert not mgr(**inp)[0].requires_grad
+    # empty batch: nothing is launched
+    empty = {k: (v[:0] if v.dim() > 0 and v.shape[0] == B and k not in ("min_depth", "max_depth") else v)
+             for k, v in inp.items()}
+    del stub[:]
+    with torch.inference_mode():
+        vol = mgr(**empty)[0]
+    assert vol.shape == (0, D, H, W) and not [c for c in stub if c.endswith("_fwd")]
+
+
+def test_autograd_seams(stub):
+    inp = synthetic.cost_volume_inputs(B, K, C, H, W, seed=1)
+    # dot model: differentiable w.r.t. the features out of the box
+    dot = cv.CostVolumeManager(H, W, num_depth_bins=D)
+    cur, src = inp["cur_feats"].clone().requires_grad_(), inp["src_feats"].clone().requires_grad_()
+    vol, lowest, _, _ = dot(**dict(inp, cur_feats=cur, src_feats=src))
+    assert vol.requires_grad and not lowest.requires_grad
+    vol.sum().backward()
+    assert stub[-2:] == ["sr_volume_prepare", "sr_dot_volume_bwd"] and cur.grad.shape == cur.shape
+    assert src.grad.shape == src.shape
+    with pytest.raises(NotImplementedError):
+        dot(**dict(inp, src_Ks=inp["src_Ks"].clone().requires_grad_()))
+    # MLP model: refuses feature gradients until opted in
+    hero = cv.FeatureVolumeManager(H, W, num_depth_bins=D, num_source_views=K)
+    with pytest.raises(NotImplementedError):
+        hero(**dict(inp, cur_feats=cur))
+    hero.differentiable = True
+    cur.grad = None
+    vol, lowest, _, mask = hero(**dict(inp, cur_feats=cur), return_mask=True)
+    assert vol.requires_grad and not lowest.requires_grad and mask.dtype == torch.bool and not mask.requires_grad
+    vol.sum().backward()
+    assert stub[-2:] == ["sr_volume_prepare", "sr_mlp_volume_bwd"]
+    assert cur.grad is not None and all(p.grad is not None and p.grad.shape == p.shape for p in hero.mlp.parameters())
+    with torch.no_grad():
+        assert not hero(**dict(inp, cur_feats=cur))[0].requires_grad
+
+
+@pytest.mark.parametrize("prefer_wino", [False, True])
+@pytest.mark.parametrize("fvt", ["mlp_feature_volume", "simple_cost_volume"])
+def test_whole_model_control_flow(stub, prefer_wino, fvt):
+    """DepthModel.forward end to end through the stub: every stage reaches its entry point with a well-formed call and
+    the output dict has the reference's keys and shapes (depth_model.py:388-405)."""
+    from simplerecon_amd import depth_model as dm
+    stub.prefer_wino = prefer_wino
+    b, k, h, w, d = 1, 2, 96, 128, 8
+    opts = dm.default_options(image_width=w, image_height=h, model_num_views=k + 1, matching_num_depth_bins=d,
+                              feature_volume_type=fvt)
+    model = dm.DepthModel(opts).eval()
+    inp = synthetic.cost_volume_inputs(b, k, 16, h // 4, w // 4, seed=2)
+    eye = torch.eye(4).expand(b, 4, 4).contiguous()
+    cur = {"image_b3hw": torch.randn(b, 3, h, w), "invK_s1_b44": inp["cur_invK"], "cam_T_world_b44": eye,
+           "world_T_cam_b44": eye}
+    src = {"image_b3hw": torch.randn(b, k, 3, h, w), "K_s1_b44": inp["src_Ks"],
+           "cam_T_world_b44": inp["src_extrinsics"], "world_T_cam_b44": inp["src_poses"]}
+    with torch.inference_mode():
+        out = model("test", cur, src, return_mask=True)
+    for i in range(4):
+        assert out[f"log_depth_pred_s{i}_b1hw"].shape == (b, 1, (h // 2) >> i, (w // 2) >> i)
+        assert out[f"depth_pred_s{i}_b1hw"].shape == (b, 1, (h // 2) >> i, (w // 2) >> i)
+    assert out["lowest_cost_bhw"].shape == (b, h // 4, w // 4)
+    assert (out["overall_mask_bhw"] is None) == (fvt == "simple_cost_volume")
+    seen = set(stub)
+    sweep = "sr_mlp_volume_fwd" if fvt == "mlp_feature_volume" else "sr_dot_volume_fwd"
+    for name in (sweep, "sr_stem7x7_fwd", "sr_maxblurpool_nhwc_fwd", "sr_instance_norm_stats_nhwc", "sr_conv3x3_c16_nhwc_fwd",
+                 "sr_conv2d_padded_nhwc_fwd", "sr_dwconv3x3_nhwc_fwd", "sr_se_scale_nhwc_fwd", "sr_add_nhwc_fwd",
+                 "sr_upsample2x_nhwc_fwd", "sr_exp_fwd",
+                 "sr_conv3x3_wino_splitk_nhwc_fwd" if prefer_wino else "sr_conv2d_splitk_nhwc_fwd"):
+        assert name in seen, name
+    assert stub.count("sr_dwconv3x3_nhwc_fwd") == 30 and stub.count("sr_upsample2x_nhwc_fwd") == 16
