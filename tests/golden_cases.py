@@ -61,6 +61,8 @@ def volume_inputs(case, device="cpu"):
 GRAD_CASES = {
     "dot": dict(model="dot", B=1, K=2, C=16, D=4, h=12, w=16, seed=51),
     "hero": dict(model="hero", B=1, K=2, C=16, D=3, h=10, w=12, seed=52),
+    # K = 7: the 202-channel MLP of hero_model.yaml (channel layout of the backward chain)
+    "hero_k7": dict(model="hero", B=1, K=7, C=16, D=2, h=6, w=8, seed=53),
 }
 
 
