@@ -226,6 +226,55 @@ def basic_block(x, sd, prefix, stride=1, precision="f32"):
                   precision=precision)
 
 
+# Backward of the conv stack -- groundwork for SURVEY.md §8f "next" #3 beyond the cost volumes: what autograd computes
+# through nn.Conv2d (+ bias), LeakyReLU and the residual add of BasicBlock (modules/layers.py:68-85).  numpy, fp64
+# accumulation inside einsum; pinned to the reference's autograd in tests/golden/grad_block_*.npz.
+
+def conv2d_backward(x, wgt, gy, stride=1, pad=None):
+    """(dx, dw, db) of y = conv2d(x, wgt) + bias for upstream gradient gy (zero padding, square kernel)."""
+    x, wgt, gy = (np.asarray(a, dtype=np.float64) for a in (x, wgt, gy))
+    Co, Ci, k, _ = wgt.shape
+    if pad is None:
+        pad = k // 2
+    B, _, H, W = x.shape
+    Ho, Wo = gy.shape[2:]
+    xp = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    dxp = np.zeros_like(xp)
+    dw = np.zeros_like(wgt)
+    for ky in range(k):
+        for kx in range(k):
+            ys, xs = slice(ky, ky + stride * Ho, stride), slice(kx, kx + stride * Wo, stride)
+            dw[:, :, ky, kx] = np.einsum("bohw,bihw->oi", gy, xp[:, :, ys, xs])
+            dxp[:, :, ys, xs] += np.einsum("bohw,oi->bihw", gy, wgt[:, :, ky, kx])
+    dx = dxp[:, :, pad:pad + H, pad:pad + W]
+    return dx, dw, gy.sum(axis=(0, 2, 3))
+
+
+def basic_block_backward(x, sd, prefix, gy, stride=1):
+    """Gradients of BasicBlock.forward (norm_layer=Identity, LeakyReLU(0.2)) w.r.t. its input and parameters:
+    returns {"x": dx, "conv1.weight": ..., "conv1.bias": ..., "conv2.*", ["downsample.0.*"]} (float64)."""
+    slope = 0.2
+    z1 = conv2d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], stride=stride, precision="f64")
+    a1 = np.where(z1 > 0, z1, z1 * slope)
+    has_ds = (prefix + "downsample.0.weight") in sd
+    ident = conv2d(x, sd[prefix + "downsample.0.weight"], sd[prefix + "downsample.0.bias"], stride=stride,
+                   precision="f64") if has_ds else np.asarray(x, dtype=np.float64)
+    z2 = conv2d(a1, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], precision="f64") + ident
+    g2 = np.asarray(gy, dtype=np.float64) * np.where(z2 > 0, 1.0, slope)          # through the final LeakyReLU
+    out = {}
+    da1, out["conv2.weight"], out["conv2.bias"] = conv2d_backward(a1, sd[prefix + "conv2.weight"], g2)
+    g1 = da1 * np.where(z1 > 0, 1.0, slope)
+    dx, out["conv1.weight"], out["conv1.bias"] = conv2d_backward(x, sd[prefix + "conv1.weight"], g1, stride=stride)
+    if has_ds:
+        dxi, out["downsample.0.weight"], out["downsample.0.bias"] = conv2d_backward(
+            x, sd[prefix + "downsample.0.weight"], g2, stride=stride)
+        dx = dx + dxi
+    else:
+        dx = dx + g2
+    out["x"] = dx
+    return out
+
+
 def cv_encoder(x, img_feats, sd, precision="f32"):
     """CVEncoder.forward (modules/networks.py:120-127)."""
     outs = []

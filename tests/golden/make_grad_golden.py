@@ -26,7 +26,20 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 def main():
     torch.set_num_threads(8)
-    cv = refshim.import_reference()[0]
+    cv, _nets, layers = refshim.import_reference()[:3]
+    # ---- BasicBlock (conv stack) ---------------------------------------------------------------------
+    for name in gc.GRAD_BLOCK_CASES:
+        case = gc.BLOCK_CASES[name]
+        blk = layers.BasicBlock(case["cin"], case["cout"], stride=case["stride"])
+        synthetic.seeded_fill_(blk, seed=case["seed"])
+        x = gc.block_input(case).requires_grad_()
+        y = blk(x)
+        R = torch.from_numpy(gc.block_cotangent(case, tuple(y.shape)))
+        (y * R).sum().backward()
+        out = {"out": y.detach().numpy(), "d_x": x.grad.numpy()}
+        out.update({"d_" + k: p.grad.numpy() for k, p in blk.named_parameters()})
+        np.savez_compressed(os.path.join(OUT, f"grad_block_{name}.npz"), **out)
+        print("block", name, {k: v.shape for k, v in out.items()})
     for name, case in gc.GRAD_CASES.items():
         inp = gc.volume_inputs(case)
         h, w, D, K, C = case["h"], case["w"], case["D"], case["K"], case["C"]

@@ -93,6 +93,14 @@ def block_input(case, device="cpu"):
     return torch.from_numpy(x).to(device)
 
 
+GRAD_BLOCK_CASES = ("same", "widen", "down", "down_odd")   # BasicBlock backward goldens (reference autograd)
+
+
+def block_cotangent(case, shape):
+    rng = np.random.default_rng(8000 + case["seed"])
+    return rng.standard_normal(shape, dtype=np.float32)
+
+
 def upsample_input(device="cpu"):
     rng = np.random.default_rng(21)
     return torch.from_numpy(rng.standard_normal((2, 5, 7, 9), dtype=np.float32)).to(device)
