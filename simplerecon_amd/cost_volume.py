@@ -25,6 +25,20 @@ from .geometry import BackprojectDepth, Project3D
 from .networks import MLP
 
 
+def _autocast_to_f32(*tensors):
+    """Inside a torch.autocast region the matching features reach the cost volume in fp16 / bf16 -- the reference trains
+    with 16-bit autocast (options.py:100-101, train.py:132), where its grid_sample runs in fp32 and its MLP in half.
+    The HIP kernels are fp32: upcast there (a differentiable torch cast, so gradients return in the caller's dtype).
+    Outside autocast, non-fp32 inputs still fail loudly."""
+    out = []
+    for t in tensors:
+        if isinstance(t, Tensor) and t.dtype in (torch.float16, torch.bfloat16) and \
+                torch.is_autocast_enabled(t.device.type):
+            t = t.float()
+        out.append(t)
+    return out
+
+
 class _DotVolumeFunction(torch.autograd.Function):
     """cost_volume, lowest_cost = sweep(cur_feats, src_feats; geometry) with the HIP backward
     (csrc/sr_dot_volume_bwd.hip) for the two feature tensors.  Geometry (poses, intrinsics, depth planes) is data, as
@@ -223,6 +237,8 @@ class CostVolumeManager(nn.Module):
 
     def _sweep(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
                depth_planes_bdhw, return_mask):
+        cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK = _autocast_to_f32(
+            cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
         b, k, c, h, w = self._check_inputs(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
         planes = self._planes(b, min_depth, max_depth, depth_planes_bdhw)
         cur, src = cur_feats.contiguous(), src_feats.contiguous()
@@ -347,6 +363,8 @@ class FeatureVolumeManager(CostVolumeManager):
 
     def _sweep(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
                depth_planes_bdhw, return_mask):
+        cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK = _autocast_to_f32(
+            cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
         b, k, c, h, w = self._check_inputs(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
         _lib.require_device_f32("src_poses", src_poses)
         if tuple(src_poses.shape) != (b, k, 4, 4):

@@ -141,3 +141,18 @@ def test_whole_model_control_flow(stub, prefer_wino, fvt):
                  "sr_conv3x3_wino_splitk_nhwc_fwd" if prefer_wino else "sr_conv2d_splitk_nhwc_fwd"):
         assert name in seen, name
     assert stub.count("sr_dwconv3x3_nhwc_fwd") == 30 and stub.count("sr_upsample2x_nhwc_fwd") == 16
+
+
+def test_autocast_region_upcasts_half_features(stub):
+    """Reference training runs under 16-bit autocast (options.py:100-101): inside an autocast region half-precision
+    matching features are upcast to fp32 for the HIP kernels and the gradients come back in the caller's dtype."""
+    inp = synthetic.cost_volume_inputs(B, K, C, H, W, seed=1)
+    dot = cv.CostVolumeManager(H, W, num_depth_bins=D)
+    cur = inp["cur_feats"].bfloat16().requires_grad_()
+    src = inp["src_feats"].bfloat16().requires_grad_()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        vol = dot(**dict(inp, cur_feats=cur, src_feats=src))[0]
+    assert vol.dtype == torch.float32 and vol.requires_grad
+    vol.sum().backward()
+    assert cur.grad.dtype == torch.bfloat16 and src.grad.dtype == torch.bfloat16
+    assert stub[-1] == "sr_dot_volume_bwd"
