@@ -287,6 +287,35 @@ def cv_encoder(x, img_feats, sd, precision="f32"):
     return outs
 
 
+def cv_encoder_backward(x, img_feats, sd, gouts):
+    """Backward of CVEncoder.forward for upstream gradients gouts[i] = dL/d outs[i]: returns (dx, [d img_feats[i]],
+    {parameter name: gradient}) in float64.  Level i's output feeds level i+1, so its gradient is gouts[i] plus what
+    flows back from the next level."""
+    acts = []                      # (ds input, ds output = concat part, concat, conv_i.0 output)
+    h = np.asarray(x, dtype=np.float64)
+    for i in range(len(img_feats)):
+        a = basic_block(h, sd, f"convs.ds_conv_{i}.", stride=1 if i == 0 else 2, precision="f64")
+        c = np.concatenate([a, np.asarray(img_feats[i], dtype=np.float64)], axis=1)
+        m = basic_block(c, sd, f"convs.conv_{i}.0.", precision="f64")
+        o = basic_block(m, sd, f"convs.conv_{i}.1.", precision="f64")
+        acts.append((h, a, c, m))
+        h = o
+    grads, dfeats = {}, [None] * len(img_feats)
+    g = np.zeros_like(h)
+    for i in reversed(range(len(img_feats))):
+        hin, a, c, m = acts[i]
+        g = g + np.asarray(gouts[i], dtype=np.float64)
+        for prefix, inp, stride in ((f"convs.conv_{i}.1.", m, 1), (f"convs.conv_{i}.0.", c, 1)):
+            r = basic_block_backward(inp, sd, prefix, g, stride=stride)
+            g = r.pop("x")
+            grads.update({prefix + k: v for k, v in r.items()})
+        dfeats[i] = g[:, a.shape[1]:]
+        r = basic_block_backward(hin, sd, f"convs.ds_conv_{i}.", g[:, :a.shape[1]], stride=1 if i == 0 else 2)
+        g = r.pop("x")
+        grads.update({f"convs.ds_conv_{i}." + k: v for k, v in r.items()})
+    return g, dfeats, grads
+
+
 def depth_decoder_pp(feats, sd, precision="f32"):
     """DepthDecoderPP.forward (modules/networks.py:75-96); double_basic_block naming
     (networks.py:13-17): Sequential(0: BasicBlock, conv_0: BasicBlock)."""

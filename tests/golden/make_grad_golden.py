@@ -26,7 +26,25 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 def main():
     torch.set_num_threads(8)
-    cv, _nets, layers = refshim.import_reference()[:3]
+    cv, nets, layers = refshim.import_reference()[:3]
+    # ---- CVEncoder (concat, stride-2 levels, chained blocks) --------------------------------------------
+    case = gc.NET_CASES["narrow"]
+    enc = nets.CVEncoder(num_ch_cv=case["D"], num_ch_enc=case["enc_ch"][1:], num_ch_outs=case["cv_outs"])
+    synthetic.seeded_fill_(enc, seed=case["seed"])
+    vol, feats = gc.net_inputs(case)
+    vol.requires_grad_()
+    feats = [f.requires_grad_() for f in feats]
+    outs = enc(vol, feats[1:])
+    cot = gc.cv_encoder_cotangents(case, [tuple(o.shape) for o in outs])
+    sum((o * torch.from_numpy(c)).sum() for o, c in zip(outs, cot)).backward()
+    save = {"d_x": vol.grad.numpy()}
+    save.update({f"d_feat_{i + 1}": f.grad.numpy() for i, f in enumerate(feats[1:])})
+    keep = ("convs.ds_conv_0.conv1.weight", "convs.ds_conv_1.downsample.0.weight", "convs.conv_0.0.downsample.0.weight",
+            "convs.conv_1.1.conv2.bias", "convs.conv_3.1.conv2.bias", "convs.ds_conv_3.conv1.bias")
+    prm = dict(enc.named_parameters())
+    save.update({"d_" + k: prm[k].grad.numpy() for k in keep})
+    np.savez_compressed(os.path.join(OUT, "grad_cv_encoder_narrow.npz"), **save)
+    print("cv_encoder", {k: v.shape for k, v in save.items()})
     # ---- BasicBlock (conv stack) ---------------------------------------------------------------------
     for name in gc.GRAD_BLOCK_CASES:
         case = gc.BLOCK_CASES[name]

@@ -122,6 +122,11 @@ def net_inputs(case, device="cpu"):
     return vol.to(device), [f.to(device) for f in feats]
 
 
+def cv_encoder_cotangents(case, shapes):
+    rng = np.random.default_rng(8100 + case["seed"])
+    return [rng.standard_normal(s, dtype=np.float32) for s in shapes]
+
+
 # ------------------------------------------------------------ matching encoder (a16)
 
 MATCHING_CASES = {
