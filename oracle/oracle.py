@@ -343,6 +343,127 @@ def depth_decoder_pp(feats, sd, precision="f32"):
     return depth_outputs
 
 
+# Backward of DepthDecoderPP: the UNet++ graph re-uses nodes along several paths, so instead of a hand-reversed loop
+# the forward is replayed on a tiny tape (float64) whose entries know their own backward (basic_block_backward /
+# conv2d_backward above, the transposes of bilinear x2 and of the channel concat); pinned to the reference's autograd.
+
+class _Node:
+    __slots__ = ("v", "g", "back")
+
+    def __init__(self, v, back=None):
+        self.v, self.g, self.back = np.asarray(v, dtype=np.float64), None, back
+
+    def accum(self, g):
+        self.g = g if self.g is None else self.g + g
+
+
+def _up2_axis_weights(n):
+    """Taps of nn.Upsample(scale 2, bilinear, align_corners=False) along one axis: out[o] = w0 in[i0] + w1 in[i1]."""
+    o = np.arange(2 * n)
+    src = (o + 0.5) / 2.0 - 0.5
+    src = np.maximum(src, 0.0)                    # ATen clamps negative source coordinates to 0
+    i0 = np.minimum(np.floor(src).astype(np.int64), n - 1)
+    i1 = np.minimum(i0 + 1, n - 1)
+    w1 = src - i0
+    return i0, i1, 1.0 - w1, w1
+
+
+def _up2_axis(x, axis, transpose=False):
+    n = x.shape[axis] // 2 if transpose else x.shape[axis]
+    i0, i1, w0, w1 = _up2_axis_weights(n)
+    shp = [1] * x.ndim
+    shp[axis] = -1
+    if not transpose:
+        return np.take(x, i0, axis=axis) * w0.reshape(shp) + np.take(x, i1, axis=axis) * w1.reshape(shp)
+    out = np.zeros(x.shape[:axis] + (n,) + x.shape[axis + 1:], dtype=x.dtype)
+    xm = np.moveaxis(x, axis, 0)
+    om = np.moveaxis(out, axis, 0)
+    np.add.at(om, i0, xm * w0.reshape((-1,) + (1,) * (x.ndim - 1)))
+    np.add.at(om, i1, xm * w1.reshape((-1,) + (1,) * (x.ndim - 1)))
+    return out
+
+
+def upsample2x_backward(gy):
+    """Transpose of upsample2x (bilinear x2, align_corners=False) applied to gy [B,C,2H,2W] -> [B,C,H,W]."""
+    return _up2_axis(_up2_axis(np.asarray(gy, dtype=np.float64), 3, True), 2, True)
+
+
+def depth_decoder_pp_backward(feats, sd, gouts):
+    """Backward of DepthDecoderPP.forward for gouts = {"log_depth_pred_s{i}_b1hw": dL/d output}: returns
+    ([d feats[i]], {parameter name: gradient}) in float64."""
+    tape, grads = [], {}
+
+    def add_grad(name, g):
+        grads[name] = grads[name] + g if name in grads else g
+
+    def leaf(v):
+        return _Node(v)
+
+    def bb(x, prefix, stride=1):
+        node = _Node(basic_block(x.v, sd, prefix, stride=stride, precision="f64"))
+
+        def back():
+            r = basic_block_backward(x.v, sd, prefix, node.g, stride=stride)
+            x.accum(r.pop("x"))
+            for k, v in r.items():
+                add_grad(prefix + k, v)
+        node.back = back
+        tape.append(node)
+        return node
+
+    def up(x):
+        node = _Node(_up2_axis(_up2_axis(x.v, 2), 3))
+        node.back = lambda: x.accum(upsample2x_backward(node.g))
+        tape.append(node)
+        return node
+
+    def cat(xs):
+        node = _Node(np.concatenate([x.v for x in xs], axis=1))
+
+        def back():
+            c0 = 0
+            for x in xs:
+                x.accum(node.g[:, c0:c0 + x.v.shape[1]])
+                c0 += x.v.shape[1]
+        node.back = back
+        tape.append(node)
+        return node
+
+    def head(x, name):
+        w, b = sd[name + ".weight"], sd[name + ".bias"]
+        node = _Node(conv2d(x.v, w, b, precision="f64"))
+
+        def back():
+            dx, dw, db = conv2d_backward(x.v, w, node.g)
+            x.accum(dx)
+            add_grad(name + ".weight", dw)
+            add_grad(name + ".bias", db)
+        node.back = back
+        tape.append(node)
+        return node
+
+    inputs = [leaf(f) for f in feats]
+    prev, outputs, final = list(inputs), [], {}
+    for j in range(1, 5):
+        for i in range(4 - j, -1, -1):
+            parts = [bb(prev[i], f"convs.right_conv_{i}{j-1}."), up(bb(prev[i + 1], f"convs.diag_conv_{i+1}{j-1}."))]
+            if i + j != 4:
+                parts.append(up(bb(outputs[-1], f"convs.up_conv_{i+1}{j}.")))
+            o = bb(bb(cat(parts), f"convs.in_conv_{i}{j}.0."), f"convs.in_conv_{i}{j}.conv_0.")
+            outputs.append(o)
+            hd = bb(o, f"convs.output_{i}.0.") if i != 0 else o
+            # the reference recomputes output_i at every node and the last one wins (networks.py:92): only that
+            # evaluation reaches the returned dict, the earlier ones are dead branches with zero gradient
+            final[f"log_depth_pred_s{i}_b1hw"] = (hd, f"convs.output_{i}.1")
+        prev = outputs[::-1]
+    for key, (hd, name) in final.items():
+        head(hd, name).accum(np.asarray(gouts[key], dtype=np.float64))
+    for node in reversed(tape):
+        if node.g is not None:
+            node.back()
+    return [n.g if n.g is not None else np.zeros_like(n.v) for n in inputs], grads
+
+
 # ------------------------------------------------------- matching encoder (a16) --
 # ResnetMatchingEncoder (reference modules/networks.py:149-205).  Its ResNet-18 stem/layer1 come from
 # the third-party `antialiased_cnns` package (simplerecon_env.yml:20, unpinned, NOT under

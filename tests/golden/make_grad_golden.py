@@ -45,6 +45,23 @@ def main():
     save.update({"d_" + k: prm[k].grad.numpy() for k in keep})
     np.savez_compressed(os.path.join(OUT, "grad_cv_encoder_narrow.npz"), **save)
     print("cv_encoder", {k: v.shape for k, v in save.items()})
+    # ---- DepthDecoderPP (UNet++ graph, bilinear x2, heads) -------------------------------------------------
+    # Run in float64: with ~2 M LeakyReLU pre-activations in this graph a handful fall within fp32 rounding of the
+    # kink, and which side they land on depends on the summation order of the convolution -- an fp32 run differs
+    # from ANY other implementation by ~2e-3 (relative L2) for that reason alone.  The float64 run pins the
+    # structure exactly (the oracle matches it to 1e-15).
+    dec = nets.DepthDecoderPP(case["enc_ch"][:1] + case["cv_outs"])
+    synthetic.seeded_fill_(dec, seed=case["seed"] + 1)
+    dec = dec.double()
+    dec_in = [t.double().requires_grad_() for t in gc.decoder_inputs(case)]
+    outs = dec(dec_in)
+    cot = gc.decoder_cotangents(case, {k: tuple(v.shape) for k, v in outs.items()})
+    sum((outs[k] * torch.from_numpy(c).double()).sum() for k, c in cot.items()).backward()
+    save = {f"d_feat_{i}": t.grad.numpy() for i, t in enumerate(dec_in)}
+    prm = dict(dec.named_parameters())
+    save.update({"d_" + k: prm[k].grad.numpy() for k in gc.DECODER_GRAD_PARAMS})
+    np.savez_compressed(os.path.join(OUT, "grad_decoder_narrow.npz"), **save)
+    print("decoder", {k: v.shape for k, v in save.items()})
     # ---- BasicBlock (conv stack) ---------------------------------------------------------------------
     for name in gc.GRAD_BLOCK_CASES:
         case = gc.BLOCK_CASES[name]

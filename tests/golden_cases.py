@@ -122,6 +122,26 @@ def net_inputs(case, device="cpu"):
     return vol.to(device), [f.to(device) for f in feats]
 
 
+DECODER_GRAD_PARAMS = ("convs.output_0.1.weight", "convs.output_3.0.conv1.bias", "convs.in_conv_04.0.conv1.bias",
+                       "convs.right_conv_00.conv1.weight", "convs.diag_conv_40.conv2.bias", "convs.up_conv_12.conv1.weight",
+                       "convs.in_conv_31.conv_0.conv2.bias")
+
+
+def decoder_inputs(case):
+    """Five feature maps with the decoder's input widths ([enc_ch[0]] + cv_outs) at strides 1, 1, 2, 4, 8 of the
+    matching resolution x2 pyramid used by the forward goldens (seeded)."""
+    rng = np.random.default_rng(8200 + case["seed"])
+    chans = case["enc_ch"][:1] + case["cv_outs"]
+    h, w = 2 * case["h"], 2 * case["w"]
+    return [torch.from_numpy(rng.standard_normal((case["B"], c, h >> i, w >> i), dtype=np.float32))
+            for i, c in enumerate(chans)]
+
+
+def decoder_cotangents(case, shapes):
+    rng = np.random.default_rng(8300 + case["seed"])
+    return {k: rng.standard_normal(shapes[k], dtype=np.float32) for k in sorted(shapes)}
+
+
 def cv_encoder_cotangents(case, shapes):
     rng = np.random.default_rng(8100 + case["seed"])
     return [rng.standard_normal(s, dtype=np.float32) for s in shapes]
