@@ -119,6 +119,32 @@ class KeyframeBuffer:
         return [candidates[i] for i in chosen]
 
 
+def default_dvmvs_tuples(scan, poses, dists_to_last_valid, n_measurement_frames):
+    """The reference's default ("online") test tuples for one scan -- the list its evaluation runs on
+    (data_scripts/generate_test_tuples.py:159-212): every pose is offered to a KeyframeBuffer with the DVMVS test
+    settings; each accepted keyframe yields {"scan": scan, "indices": [keyframe, source, ...]} with up to
+    n_measurement_frames earlier keyframes chosen by baseline penalty.  `dists_to_last_valid[i]` = frames since the
+    last valid pose (None to let the buffer handle invalid poses itself)."""
+    cfg = DVMVS_Config
+    buf = KeyframeBuffer(cfg.test_keyframe_buffer_size, cfg.test_keyframe_pose_distance, cfg.test_optimal_t_measure,
+                         cfg.test_optimal_R_measure, store_return_indices=True)
+    samples = []
+    for i, pose in enumerate(poses):
+        if buf.try_new_keyframe(np.array(pose, copy=True), None, dists_to_last_valid[i], index=i) != buf.ADDED:
+            continue
+        sources = [frame[2] for frame in buf.get_best_measurement_frames(n_measurement_frames)]
+        samples.append({"scan": scan, "indices": [i] + sources})
+    return samples
+
+
+def write_tuple_file(path, samples):
+    """One line per tuple, `scan frame_id_0 frame_id_1 ...` with the reference frame first -- the file format the
+    reference's datasets read (generate_test_tuples.py:1-8)."""
+    with open(path, "w") as f:
+        for s in samples:
+            f.write(" ".join([str(s["scan"])] + [str(i) for i in s["indices"]]) + "\n")
+
+
 def sort_sources_by_pose_penalty(cur_cam_T_world, src_world_T_cam):
     """Order of the source views as the reference's dataset feeds them to the model: ascending combined pose
     distance of cur_cam_T_src_cam (generic_mvs_dataset.py:643-659 with utils/geometry_utils.pose_distance :178-191).

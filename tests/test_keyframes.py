@@ -26,6 +26,19 @@ def test_keyframe_buffer_matches_reference_stream():
     assert set(np.unique(gold["codes"])) == {0, 1, 2, 3, 4, 5}   # the stream exercises every branch
 
 
+def test_default_tuples_match_reference_stream(tmp_path):
+    """default_dvmvs_tuples = the per-scan loop of the reference's tuple generator: same tuples as the golden stream."""
+    gold = dict(np.load(gc.GOLDEN_DIR + "/keyframes.npz"))
+    poses, dist = gc.keyframe_stream()
+    samples = kf.default_dvmvs_tuples("scene0000_00", poses, dist, 7)
+    want = [[int(v) for v in row if v >= 0] for row in gold["tuples"]]
+    assert [s["indices"] for s in samples] == want and all(s["scan"] == "scene0000_00" for s in samples)
+    path = tmp_path / "tuples.txt"
+    kf.write_tuple_file(str(path), samples)
+    lines = path.read_text().splitlines()
+    assert len(lines) == len(want) and lines[0].split() == ["scene0000_00"] + [str(i) for i in want[0]]
+
+
 def test_pose_distance_and_pair_validity():
     a = np.eye(4)
     b = np.eye(4)
