@@ -92,6 +92,8 @@ def main():
         with torch.inference_mode():
             if not args.no_roofline:
                 out["roofline"] = wl.roofline(args.steps)
+                if hasattr(wl, "roofline_hbm"):
+                    out["roofline_hbm"] = wl.roofline_hbm(args.steps)
                 extra = wl.extra_kernels(args.steps)
                 if extra:
                     out["kernels"] = extra

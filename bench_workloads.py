@@ -32,6 +32,18 @@ def _mlp_kernel_name(K):
     return "sr_mlp_volume_kernel<false, true>"
 
 
+def _dot_kernel_name(B, h, w, D):
+    """Which sr_dot_volume_lds_kernel<CAP, WPS, G> sr_dot_volume_sweep dispatches for C = 16 (mirrors
+    sr_launch_dot_volume_lds in csrc/sr_dot_volume_lds.hip); the L1-gather kernel when SR_DOT_LDS=0."""
+    if os.environ.get("SR_DOT_LDS", "1") == "0":
+        return "sr_dot_volume_kernel16q"
+    cap = 770 if os.environ.get("SR_DOT_LDS_CAP") == "770" else 634
+    g = int(os.environ.get("SR_DOT_LDS_G", "0"))
+    if g not in (2, 4, 8):
+        g = 2 if B * ((w + 31) // 32) * ((h + 7) // 8) * ((D + 3) // 4) < 2048 else 4
+    return f"sr_dot_volume_lds_kernel<{cap}, {3 if cap == 770 else 4}, {g}>"
+
+
 def _time_launches(fn, n):
     """Average device time of fn() over n launches, HIP events on the launch stream."""
     fn()
@@ -45,12 +57,23 @@ def _time_launches(fn, n):
     return start.elapsed_time(end) * 1e-3 / n
 
 
+def _pmc_algorithmic_bytes(tag):
+    """Algorithmic bytes per launch recorded next to the PMC traffic of the same kernel (profiles/traffic.json)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        v = json.load(open(path)).get(tag)
+        return v.get("algorithmic_bytes") if isinstance(v, dict) else None
+    except Exception:
+        return None
+
+
 def _pmc_traffic(tag):
     """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(path):
         try:
-            return json.load(open(path)).get(tag)
+            v = json.load(open(path)).get(tag)
+            return v.get("bytes") if isinstance(v, dict) else v
         except Exception:
             return None
     return None
@@ -114,13 +137,21 @@ class DotCfg2:
                                          _lib.ptr(lowest), None, _lib.ptr(ws), ws.numel(), st)
             _lib.check(rc, "sr_dot_volume_sweep")
         t = _time_launches(sweep, max(n, 20))
+        # the launch = [memset of the argmax keys] + sweep kernel + [key -> depth kernel]; the sweep kernel alone is timed
+        # by rocprofv3 (profiles/): subtract nothing here, report both
         nbytes = self.algorithmic_bytes()
         achieved = nbytes / t / 1e9
         N = h * w
-        return {"kernel": "sr_dot_volume_kernel16q", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(self.name),
+        traffic = _pmc_traffic(self.name)
+        return {"kernel": _dot_kernel_name(B, h, w, D), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_over_algorithmic": (traffic / nbytes) if traffic else None,
                 "avg_launch_us": t * 1e6, "algorithmic_bytes_per_launch": nbytes,
-                "onchip_gather_GBps": B * D * K * N * 4 * Cc * 4 / t / 1e9}
+                "lds_tap_GBps": B * D * K * N * 4 * Cc * 4 / t / 1e9,
+                "note": "achieved = algorithmic (compulsory) bytes / time of one sr_dot_volume_sweep call (keys memset + "
+                        "LDS-staged sweep kernel + key-to-depth kernel), HIP events on the launch stream; the sweep is "
+                        "bound by instruction issue + LDS tap reads (4 taps x 64 B per (pixel, plane, view) sample = "
+                        "lds_tap_GBps if no view were culled), not by HBM: see DESIGN.md 3.1"}
 
     def extra_kernels(self, n):
         return None
@@ -242,7 +273,9 @@ class HeroCfg3:
                             f"random-init weights; {skipped}"
                             + (" (BASELINE.json configs[2]: hero_model.yaml, batch 8)" if self.B == 8 and
                                self.feature_volume_type == "mlp_feature_volume" else ""),
-                "frames_per_step_per_gpu": self.B, "hip_streams_per_gpu": self.streams,
+                "frames_per_step_per_gpu": self.B,
+                "hip_streams_per_gpu": self.streams + (1 if (self.prior and getattr(self.model, "prior_on_side_stream", True))
+                                                       else 0),
                 "submission": "one HIP graph replay per step" if self.use_graph else "eager (one launch per kernel)",
                 "parallelism": f"replica x{world} (keyframes sharded)"}
 
@@ -302,29 +335,59 @@ class HeroCfg3:
     def roofline(self, n):
         n = max(3, min(n, 10))
         agg = self._profile_convs(n)
-        self._conv_agg = agg
+        self._conv_agg, self._prof_n = agg, n
         name = max(agg, key=lambda k: agg[k][2])
         calls, flops, t, executed = agg[name]
-        achieved = flops / t / 1e12
+        wino = "wino" in name
+        # `achieved` counts the FLOPs the kernel EXECUTES on the matrix cores (Winograd F(2x2,3x3) issues 16 instead of
+        # 36 multiplies per 2x2 tile and channel pair), so frac = MFMA utilisation <= 1; the direct-convolution
+        # (algorithmic) count is reported beside it
+        achieved = (executed if wino else flops) / t / 1e12
+        traffic = _pmc_traffic(self.name)
         out = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-               "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": _pmc_traffic(self.name),
+               "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": traffic,
+               "algorithmic_bytes_per_launch": _pmc_algorithmic_bytes(self.name),
                "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // n,
+               "executed_flops_per_launch": (executed if wino else flops) / calls,
                "algorithmic_flops_per_launch": flops / calls,
-               "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_32x32x2_f32); algorithmic FLOPs = 2*B*Ho*Wo*Cout*Cin*k*k (the "
-                       "direct-convolution count) summed over the launches of this kernel in one step"}
-        if "wino" in name:
-            out["executed_tflops"] = executed / t / 1e12
-            out["mfma_utilisation"] = executed / t / 1e12 / FP32_MFMA_PEAK_TF
-            out["note"] += ("; this kernel is Winograd F(2x2,3x3): it issues 16 instead of 36 multiplies per 2x2 tile and "
-                            "channel pair (executed_tflops = FLOPs actually issued / time, mfma_utilisation = that / "
-                            "peak), so `achieved` on the algorithmic count may exceed the direct-conv MFMA bound")
+               "algorithmic_tflops": flops / t / 1e12,
+               "algorithmic_speed_vs_direct_peak": flops / t / 1e12 / FP32_MFMA_PEAK_TF,
+               "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_32x32x2_f32).  achieved / frac = FLOPs actually issued on the "
+                       "matrix pipe / time / peak (MFMA utilisation); algorithmic_* = the direct-convolution count "
+                       "2*B*Ho*Wo*Cout*Cin*k*k over the launches of this kernel in one step (Winograd needs 16/36 of "
+                       "them, so algorithmic_speed_vs_direct_peak may exceed 1: a speed-up over direct convolution, not "
+                       "a roofline fraction)"}
+        return out
+
+    def roofline_hbm(self, n):
+        """North star: 'achieved HBM GB/s on the warp/reduce kernel': the fused plane-sweep kernel this workload runs
+        (metadata-MLP sweep for the hero model) on its algorithmic bytes, plus the dot-product sweep kernel at the
+        same shapes (BASELINE.json configs[1] batched) for comparison."""
+        B, K, Cc, h, w, D = self.B, self.K, self.Cc, self.h, self.w, self.D
+        N = h * w
+        nbytes = B * (4 * ((K + 1) * Cc * N + D * N + N) + 4 * (32 * K + 16 + D))
+        out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": nbytes}
+        if self.feature_volume_type == "mlp_feature_volume":
+            t = self._mlp_sweep_time(max(3, min(n, 10)))
+            out.update({"kernel": _mlp_kernel_name(K), "achieved": nbytes / t / 1e9, "frac": nbytes / t / 1e9 / HBM_PEAK_GBS,
+                        "avg_launch_us": t * 1e6, "traffic": _pmc_traffic(self.name + ":mlp_sweep"),
+                        "note": "the hero model's sweep is MFMA-bound (see kernels[]): its HBM fraction is what the "
+                                "compulsory bytes amount to at that speed"})
+        dot = DotCfg2(self.dev, 0, B=B, D=D, name=f"dot_b{B}")
+        r = dot.roofline(max(n, 10))
+        out["dot_sweep"] = {k: r[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch",
+                                              "traffic", "traffic_over_algorithmic")}
+        if "kernel" not in out:
+            out.update(out.pop("dot_sweep"))
         return out
 
     def extra_kernels(self, n):
         out = []
         for name, (calls, flops, t, executed) in sorted(self._conv_agg.items(), key=lambda kv: -kv[1][2])[1:]:
-            out.append({"kernel": name, "bound": "mfma", "achieved": flops / t / 1e12, "peak": FP32_MFMA_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF, "avg_launch_us": t / calls * 1e6})
+            ex = executed if "wino" in name else flops
+            out.append({"kernel": name, "bound": "mfma", "achieved": ex / t / 1e12, "peak": FP32_MFMA_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": ex / t / 1e12 / FP32_MFMA_PEAK_TF, "algorithmic_tflops": flops / t / 1e12,
+                        "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // self._prof_n})
         if self.feature_volume_type == "mlp_feature_volume":
             t = self._mlp_sweep_time(max(3, min(n, 10)))
             N = self.h * self.w

@@ -70,6 +70,12 @@ int sr_dot_volume_sweep(const float* cur, const float* invK_cur, const float* pl
                         float* out_lowest, uint8_t* out_mask, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* Self-test of the LDS-staged sweep's packed reciprocal (csrc/sr_dot_volume_lds.hip): out_fast[i] = that reciprocal of
+ * x[i], out_div[i] = the IEEE division 1.0f / x[i] every other kernel uses; they must agree bit for bit for
+ * 2^-60 <= |x| <= 2^60 (outside that range the sweep itself takes the division).  No reference counterpart: the
+ * reference divides in ATen (utils/geometry_utils.py:85). */
+int sr_selftest_rcp(const float* x, float* out_fast, float* out_div, int n, void* stream);
+
 /* Fused plane sweep of the dot-product model (= sr_volume_prepare + sr_dot_volume_sweep): replaces
  *   CostVolumeManager.build_cost_volume + forward      (cost_volume.py:237-380)
  *   = BackprojectDepth (utils/geometry_utils.py:51-59) + Project3D (:72-89)

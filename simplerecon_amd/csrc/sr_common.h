@@ -43,11 +43,46 @@ struct SrSample {
 
 typedef float sr_f2v __attribute__((ext_vector_type(2)));
 
+// Integer tap origin (floats, unclamped) and the four bilinear weights of the unnormalised sampling position (ix, iy)
+// (grid_sample, bilinear, zeros padding, align_corners=False): weights of out-of-image taps are zero.
+__device__ __forceinline__ void sr_bilinear_taps(float ix, float iy, int h, int w, float& fx0, float& fy0, float& w_nw,
+                                                 float& w_ne, float& w_sw, float& w_se) {
+#pragma clang fp contract(off)
+  const sr_f2v ixy = {ix, iy};
+  fx0 = floorf(ix);
+  fy0 = floorf(iy);
+  const sr_f2v f0 = {fx0, fy0};
+  const sr_f2v f1 = f0 + 1.0f;
+  const float fx1 = f1.x, fy1 = f1.y;
+  const float wm = (float)(w - 1), hm = (float)(h - 1);
+  // (bitwise & on purpose: short-circuit && makes hipcc emit divergent branches that split the
+  // scheduling region the callers want to interleave with MFMAs)
+  const bool vx0 = (fx0 >= 0.0f) & (fx0 <= wm), vx1 = (fx1 >= 0.0f) & (fx1 <= wm);
+  const bool vy0 = (fy0 >= 0.0f) & (fy0 <= hm), vy1 = (fy1 >= 0.0f) & (fy1 <= hm);
+  const sr_f2v a1 = f1 - ixy, a0 = ixy - f0;            // (ax1, ay1), (ax0, ay0)
+  const sr_f2v wtop = sr_f2v{a1.x, a0.x} * a1.y;        // (ax1*ay1, ax0*ay1)
+  const sr_f2v wbot = sr_f2v{a1.x, a0.x} * a0.y;        // (ax1*ay0, ax0*ay0)
+  w_nw = (vx0 & vy0) ? wtop.x : 0.0f;
+  w_ne = (vx1 & vy0) ? wtop.y : 0.0f;
+  w_sw = (vx0 & vy1) ? wbot.x : 0.0f;
+  w_se = (vx1 & vy1) ? wbot.y : 0.0f;
+}
+
+// Core of the projection: everything up to the bilinear weights, with the UNCLAMPED integer tap origin (fx0, fy0) as
+// floats.  sr_project_sample (clamped global texel offsets) and the LDS-staged sweep (tile footprints) both build on it,
+// so their geometry is the same instruction sequence.
 // x / y components run as packed fp32 pairs (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, FP contraction off, so
 // every value is bit-identical to the scalar formulation) -- half the VALU instructions of the projection.
-__device__ __forceinline__ void sr_project_sample(const float* __restrict__ g /*geom record*/,
-                                                  float X0, float X1, float X2, int h, int w,
-                                                  float inv_w, float inv_h, SrSample& s) {
+struct SrSampleXY {
+  float zp, pix_x, pix_y;
+  float ix, iy;                  // unnormalised sampling position (texel units; may be anything, incl. NaN)
+  float fx0, fy0;                // its floor = the NW tap
+  float w_nw, w_ne, w_sw, w_se;  // bilinear weights, already zeroed for out-of-image taps
+};
+
+__device__ __forceinline__ void sr_project_sample_xy(const float* __restrict__ g /*geom record*/,
+                                                     float X0, float X1, float X2, int h, int w,
+                                                     float inv_w, float inv_h, SrSampleXY& s) {
 #pragma clang fp contract(off)
   const float eps = 1e-8f;
   const sr_f2v q01 = sr_f2v{g[0], g[4]} * X0 + sr_f2v{g[1], g[5]} * X1 + sr_f2v{g[2], g[6]} * X2 + sr_f2v{g[3], g[7]};
@@ -61,26 +96,23 @@ __device__ __forceinline__ void sr_project_sample(const float* __restrict__ g /*
   const sr_f2v uv = 2.0f * pix * sr_f2v{inv_w, inv_h} - 1.0f;
   const sr_f2v size = {(float)w, (float)h};
   const sr_f2v ixy = ((uv + 1.0f) * size - 1.0f) / 2.0f;
-  const float ix = ixy.x, iy = ixy.y;
-  const float fx0 = floorf(ix), fy0 = floorf(iy);
-  const sr_f2v f0 = {fx0, fy0};
-  const sr_f2v f1 = f0 + 1.0f;
-  const float fx1 = f1.x, fy1 = f1.y;
+  s.ix = ixy.x;
+  s.iy = ixy.y;
+  sr_bilinear_taps(s.ix, s.iy, h, w, s.fx0, s.fy0, s.w_nw, s.w_ne, s.w_sw, s.w_se);
+}
+
+__device__ __forceinline__ void sr_project_sample(const float* __restrict__ g /*geom record*/,
+                                                  float X0, float X1, float X2, int h, int w,
+                                                  float inv_w, float inv_h, SrSample& s) {
+  SrSampleXY c;
+  sr_project_sample_xy(g, X0, X1, X2, h, w, inv_w, inv_h, c);
+  s.zp = c.zp; s.pix_x = c.pix_x; s.pix_y = c.pix_y;
+  s.w_nw = c.w_nw; s.w_ne = c.w_ne; s.w_sw = c.w_sw; s.w_se = c.w_se;
   const float wm = (float)(w - 1), hm = (float)(h - 1);
-  // (bitwise & on purpose: short-circuit && makes hipcc emit divergent branches that split the
-  // scheduling region the callers want to interleave with MFMAs)
-  const bool vx0 = (fx0 >= 0.0f) & (fx0 <= wm), vx1 = (fx1 >= 0.0f) & (fx1 <= wm);
-  const bool vy0 = (fy0 >= 0.0f) & (fy0 <= hm), vy1 = (fy1 >= 0.0f) & (fy1 <= hm);
-  const sr_f2v a1 = f1 - ixy, a0 = ixy - f0;            // (ax1, ay1), (ax0, ay0)
-  const sr_f2v wtop = sr_f2v{a1.x, a0.x} * a1.y;        // (ax1*ay1, ax0*ay1)
-  const sr_f2v wbot = sr_f2v{a1.x, a0.x} * a0.y;        // (ax1*ay0, ax0*ay0)
-  s.w_nw = (vx0 & vy0) ? wtop.x : 0.0f;
-  s.w_ne = (vx1 & vy0) ? wtop.y : 0.0f;
-  s.w_sw = (vx0 & vy1) ? wbot.x : 0.0f;
-  s.w_se = (vx1 & vy1) ? wbot.y : 0.0f;
+  const float fx1 = c.fx0 + 1.0f, fy1 = c.fy0 + 1.0f;
   // clamp (NaN-safe: fmaxf(NaN, 0) = 0) so every tap address is in-image; weight 0 kills it
-  const int x0 = (int)fminf(fmaxf(fx0, 0.0f), wm), x1 = (int)fminf(fmaxf(fx1, 0.0f), wm);
-  const int y0 = (int)fminf(fmaxf(fy0, 0.0f), hm), y1 = (int)fminf(fmaxf(fy1, 0.0f), hm);
+  const int x0 = (int)fminf(fmaxf(c.fx0, 0.0f), wm), x1 = (int)fminf(fmaxf(fx1, 0.0f), wm);
+  const int y0 = (int)fminf(fmaxf(c.fy0, 0.0f), hm), y1 = (int)fminf(fmaxf(fy1, 0.0f), hm);
   s.o_nw = y0 * w + x0;
   s.o_ne = y0 * w + x1;
   s.o_sw = y1 * w + x0;
@@ -102,13 +134,35 @@ __device__ __forceinline__ float sr_activate(float v, float slope) {
 }
 #endif
 
-// workspace carving: [geom records | channels-last source features]
+// launch parameters of the dot-product sweeps (sr_dot_volume.hip, sr_dot_volume_lds.hip)
+struct SrDotParams {
+  const float* cur;       // [B,C,h,w]
+  const float* src_nhwc;  // [B*K, h*w, C]
+  const float* invK;      // [B,16]
+  const float* geom;      // [B*K, SR_GEOM_STRIDE]
+  SrPlanes planes;
+  SrVolumeOut out;
+  int B, K, h, w, D;
+  float inv_w, inv_h;
+};
+
+// workspace carving: [geom records | channels-last source features | per-pixel argmax keys of the LDS-staged sweep]
 static inline float* sr_ws_geom(void* workspace) { return (float*)sr_align_up((size_t)workspace, 256); }
 static inline float* sr_ws_src_nhwc(void* workspace, int B, int K) {
   return (float*)((char*)sr_ws_geom(workspace) + sr_align_up((size_t)B * K * SR_GEOM_STRIDE * sizeof(float), 256));
 }
 
+static inline size_t sr_ws_nhwc_bytes(int B, int K, int C, int h, int w) {
+  return sr_align_up((size_t)B * K * h * w * C * sizeof(float), 256);
+}
+static inline unsigned long long* sr_ws_keys(void* workspace, int B, int K, int C, int h, int w) {
+  return (unsigned long long*)((char*)sr_ws_src_nhwc(workspace, B, K) + sr_ws_nhwc_bytes(B, K, C, h, w));
+}
+
 // internal launchers shared between translation units
+// LDS-staged 16-channel dot-product sweep (sr_dot_volume_lds.hip); SR_ERR_UNSUPPORTED when the shape is outside its
+// range (the caller then takes the L1-gather kernels)
+int sr_launch_dot_volume_lds(const SrDotParams& p, unsigned long long* keys, hipStream_t stream);
 int sr_launch_geom(const float* K_src, const float* T_src_cur, const float* T_cur_src, float* geom,
                    int n, hipStream_t stream);
 int sr_launch_argmax_planes(const float* cv, int64_t sb, int64_t sd, int64_t sp, SrPlanes planes, int B, int h, int w,

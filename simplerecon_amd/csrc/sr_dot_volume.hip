@@ -88,17 +88,6 @@ int sr_launch_pack_nhwc(const float* src_nchw, float* dst_nhwc, int images, int 
 
 // ------------------------------------------------------------------------ the sweep ---
 
-struct SrDotParams {
-  const float* cur;       // [B,C,h,w]
-  const float* src_nhwc;  // [B*K, h*w, C]
-  const float* invK;      // [B,16]
-  const float* geom;      // [B*K, SR_GEOM_STRIDE]
-  SrPlanes planes;
-  SrVolumeOut out;
-  int B, K, h, w, D;
-  float inv_w, inv_h;
-};
-
 // dot of one C-channel texel with the reference feature vector (C/4 x 16-byte loads)
 template <int C>
 __device__ __forceinline__ float sr_tap_dot(const float* __restrict__ img, int texel, const float (&cur)[C]) {
@@ -189,7 +178,7 @@ __global__ __launch_bounds__(1024) void sr_dot_volume_kernel(SrDotParams p) {
       any_bounds |= sr_in_bounds(s, p.h, p.w);
     }
     if (active) out[j * p.out.sd] = cost;
-    if (!have || cost > best) { best = cost; best_d = d; have = true; }  // first max wins
+    if (!have || cost > best || (cost != cost && best == best)) { best = cost; best_d = d; have = true; }  // first max wins; NaN = max (torch.argmax)
     if (j == p.D - 1 && p.out.mask && active)
       p.out.mask[(size_t)b * N + pix] = (uint8_t)(any_depth && any_bounds);
   }
@@ -210,7 +199,8 @@ __global__ __launch_bounds__(1024) void sr_dot_volume_kernel(SrDotParams p) {
       if (grp == 0 && active) {
         float bb = best, bd = best_d;  // group 0 always owns plane 0
         for (int g = 1; g < S; ++g)
-          if (s_have[g * 64 + lane] != 0.0f && s_best[g * 64 + lane] > bb) {
+          if (s_have[g * 64 + lane] != 0.0f &&
+              (s_best[g * 64 + lane] > bb || (s_best[g * 64 + lane] != s_best[g * 64 + lane] && bb == bb))) {
             bb = s_best[g * 64 + lane];
             bd = s_d[g * 64 + lane];
           }
@@ -336,7 +326,7 @@ __global__ __launch_bounds__(1024) void sr_dot_volume_kernel16q(SrDotParams p) {
       cost = (lane >> 4) == r ? v : cost;
     }
     if (active) out[j * p.out.sd] = cost;
-    if (!have || cost > best) { best = cost; best_d = d; have = true; }  // first max wins
+    if (!have || cost > best || (cost != cost && best == best)) { best = cost; best_d = d; have = true; }  // first max wins; NaN = max (torch.argmax)
     if (j == p.D - 1 && p.out.mask && active)
       p.out.mask[(size_t)b * N + pix] = (uint8_t)(any_depth && any_bounds);
   }
@@ -357,7 +347,8 @@ __global__ __launch_bounds__(1024) void sr_dot_volume_kernel16q(SrDotParams p) {
       if (grp == 0 && active) {
         float bb = best, bd = best_d;  // group 0 always owns plane 0
         for (int g = 1; g < S; ++g)
-          if (s_have[g * 64 + lane] != 0.0f && s_best[g * 64 + lane] > bb) {
+          if (s_have[g * 64 + lane] != 0.0f &&
+              (s_best[g * 64 + lane] > bb || (s_best[g * 64 + lane] != s_best[g * 64 + lane] && bb == bb))) {
             bb = s_best[g * 64 + lane];
             bd = s_d[g * 64 + lane];
           }
@@ -375,8 +366,9 @@ extern "C" const char* sr_target_arch(void) { return "gfx950"; }
 extern "C" size_t sr_volume_workspace_bytes(int B, int K, int C, int h, int w) {
   if (B < 0 || K < 0 || C < 0 || h < 0 || w < 0) return 0;
   const size_t geom = sr_align_up((size_t)B * K * SR_GEOM_STRIDE * sizeof(float), 256);
-  const size_t nhwc = sr_align_up((size_t)B * K * h * w * C * sizeof(float), 256);
-  return geom + nhwc + 256;
+  const size_t nhwc = sr_ws_nhwc_bytes(B, K, C, h, w);
+  const size_t keys = sr_align_up((size_t)B * h * w * sizeof(unsigned long long), 256);  // LDS-staged sweep's argmax keys
+  return geom + nhwc + keys + 256;
 }
 
 static int sr_pick_plane_split(int B, int N, int D) {
@@ -423,6 +415,16 @@ extern "C" int sr_dot_volume_sweep(const float* cur, const float* invK_cur, cons
   p.inv_w = (float)(1.0 / (double)w);
   p.inv_h = (float)(1.0 / (double)h);
 
+  if (C == 16) {
+    // default: footprints of 8x32-pixel tiles staged in LDS (sr_dot_volume_lds.hip); SR_DOT_LDS=0 selects the
+    // L1-gather kernels below (ablation), which also take the shapes the staged kernel refuses
+    const char* e = getenv("SR_DOT_LDS");
+    const int use_lds = e ? atoi(e) : 1;
+    if (use_lds) {
+      const int rc = sr_launch_dot_volume_lds(p, sr_ws_keys(workspace, B, K, C, h, w), stream);
+      if (rc != SR_ERR_UNSUPPORTED) return rc;
+    }
+  }
   const int S = sr_pick_plane_split(B, N, D);
   // With few pixel tiles (batch 1: 300 workgroups of 16 waves on 256 CUs) whole-workgroup granularity leaves CUs
   // idle: spread the plane groups over grid z as single-wave workgroups and take the lowest cost in a second launch.

@@ -476,11 +476,11 @@ __global__ void sr_argmax_planes_kernel(const float* __restrict__ cv, int64_t sb
     for (int u = 0; u < 8; ++u) v[u] = c[(int64_t)(j + u) * sd];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (v[u] > best) { best = v[u]; bj = j + u; }
+      if (v[u] > best || (v[u] != v[u] && best == best)) { best = v[u]; bj = j + u; }  // NaN = max, like torch.argmax
   }
   for (; j < D; ++j) {
     const float v = c[(int64_t)j * sd];
-    if (v > best) { best = v; bj = j; }
+    if (v > best || (v != v && best == best)) { best = v; bj = j; }
   }
   lowest[(size_t)b * N + pix] = planes.ptr[b * planes.sb + bj * planes.sd + y * planes.sy + x * planes.sx];
 }
