@@ -589,7 +589,7 @@ WORKLOADS = {
     "hero_cfg3_volume": lambda dev, rank: HeroVolumeOnly(dev, rank, B=8, K=7, D=64, h=120, w=160),
     "tsdf_fuse": lambda dev, rank: TsdfFuse(dev, rank),
     "dot_cfg2": lambda dev, rank: DotCfg2(dev, rank),
-    "dot_b8": lambda dev, rank: DotCfg2(dev, rank, B=8),
+    "dot_b8": lambda dev, rank: DotCfg2(dev, rank, B=8, name="dot_b8"),
     # evidence for "the sweep is HBM-bound only when there are few planes": 2 planes, batch 64 (not a BASELINE config)
     "dot_d2_b64": lambda dev, rank: DotCfg2(dev, rank, B=64, D=2, name="dot_d2_b64"),
 }
