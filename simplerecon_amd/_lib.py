@@ -141,6 +141,11 @@ def stream_ptr(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def capturing():
+    """True while torch's current stream is being captured into a HIP graph (False on a machine without a GPU)."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def refuse_autograd(*tensors):
     if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
         raise NotImplementedError(

@@ -25,6 +25,13 @@ from .geometry import BackprojectDepth, Project3D
 from .networks import MLP
 
 
+def _autocast_on(device_type):
+    try:
+        return torch.is_autocast_enabled(device_type)
+    except TypeError:   # torch < 2.4: no device_type argument (the flag of the CUDA / HIP device)
+        return torch.is_autocast_enabled()
+
+
 def _autocast_to_f32(*tensors):
     """Inside a torch.autocast region the matching features reach the cost volume in fp16 / bf16 -- the reference trains
     with 16-bit autocast (options.py:100-101, train.py:132), where its grid_sample runs in fp32 and its MLP in half.
@@ -32,8 +39,7 @@ def _autocast_to_f32(*tensors):
     Outside autocast, non-fp32 inputs still fail loudly."""
     out = []
     for t in tensors:
-        if isinstance(t, Tensor) and t.dtype in (torch.float16, torch.bfloat16) and \
-                torch.is_autocast_enabled(t.device.type):
+        if isinstance(t, Tensor) and t.dtype in (torch.float16, torch.bfloat16) and _autocast_on(t.device.type):
             t = t.float()
         out.append(t)
     return out
@@ -214,10 +220,20 @@ class CostVolumeManager(nn.Module):
         return depth_planes_bdhw
 
     def _get_workspace(self, nbytes, device):
-        ws = self._workspace
-        if ws is None or ws.numel() < nbytes or ws.device != device:
+        """Sweep workspace (geometry records, channels-last source features, packed MLP weights, argmax keys).  One
+        buffer per (device, HIP stream): sub-batches on different streams (DepthModel.hot_path, num_streams > 1) must
+        not share it.  Inside a HIP-graph capture a FRESH buffer is allocated from the graph's private pool instead:
+        the graph bakes the pointer in and owns the memory, so later eager calls that grow (and drop) the cached
+        buffer cannot leave a replay writing into freed memory."""
+        if _lib.capturing():
+            return torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if self._workspace is None:
+            self._workspace = {}
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._workspace = ws
+            self._workspace[key] = ws
         return ws
 
     def _alloc_outputs(self, b, h, w, device, return_mask):

@@ -18,6 +18,39 @@ PROFILE = None
 
 _PACKED = weakref.WeakKeyDictionary()  # nn.Conv2d -> (weight version, data_ptr, packed tensor)
 
+# Packed weights are produced by a kernel on whichever stream made the first call; a consumer on ANOTHER stream (the
+# sub-batch streams of DepthModel.hot_path, the image-prior side stream) must not start before that kernel finished.
+# (module, cache tag) -> (event recorded behind the pack kernel, its stream); the entry is dropped once the event completed.
+_PACK_EVENTS = {}
+
+
+def _packed_here(mod, tag, device):
+    if device.type != "cuda" or not torch.cuda.is_available():
+        return
+    st = torch.cuda.current_stream(device)
+    if _lib.capturing():
+        return  # weights are packed during warm-up, never inside a capture (graph.GraphedCallable warms up first)
+    ev = torch.cuda.Event()
+    ev.record(st)
+    _PACK_EVENTS[(id(mod), tag)] = (ev, st.cuda_stream, weakref.ref(mod))
+
+
+def _await_packed(mod, tag, device):
+    if not _PACK_EVENTS:
+        return
+    hit = _PACK_EVENTS.get((id(mod), tag))
+    if hit is None or hit[2]() is not mod:
+        return
+    if _lib.capturing():
+        return
+    ev, stream_ptr, _ = hit
+    if ev.query():
+        del _PACK_EVENTS[(id(mod), tag)]
+        return
+    st = torch.cuda.current_stream(device)
+    if st.cuda_stream != stream_ptr:
+        st.wait_event(ev)
+
 
 def empty_nhwc(b, c, h, w, device):
     return torch.empty((b, c, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last)
@@ -125,6 +158,7 @@ def packed_weight(conv: nn.Conv2d, bn=None):
     key = _state_key(conv, bn)
     hit = _PACKED.get(conv)
     if hit is not None and hit[0] == key:
+        _await_packed(conv, "direct", conv.weight.device)
         return hit[1], hit[2]
     lib = _lib.lib()
     w, bias = _effective_weight(conv, bn)
@@ -133,6 +167,7 @@ def packed_weight(conv: nn.Conv2d, bn=None):
     with torch.cuda.device(w.device):
         rc = lib.sr_conv_pack_weights(_lib.ptr(w), co, ci, k, _lib.ptr(packed), _lib.stream_ptr(w.device))
     _lib.check(rc, "sr_conv_pack_weights")
+    _packed_here(conv, "direct", w.device)
     _PACKED[conv] = (key, packed, bias)
     return packed, bias
 
@@ -158,11 +193,13 @@ def linear(x, lin: nn.Linear, leaky=None):
     lib = _lib.lib()
     if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
         wp = hit[2]
+        _await_packed(lin, "linear", w.device)
     else:
         wp = torch.empty(lib.sr_conv_packed_weight_floats(cout, cin, 1), dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
             _lib.check(lib.sr_conv_pack_weights(_lib.ptr(w.detach().contiguous()), cout, cin, 1, _lib.ptr(wp),
                                                 _lib.stream_ptr(w.device)), "sr_conv_pack_weights")
+        _packed_here(lin, "linear", w.device)
         _PACKED_LIN[lin] = (w._version, w.data_ptr(), wp)
     bias = lin.bias.detach() if lin.bias is not None else None
     with torch.cuda.device(x.device):
@@ -182,6 +219,7 @@ def packed_wino_weight(conv: nn.Conv2d, bn=None):
     key = _state_key(conv, bn)
     hit = _PACKED_WINO.get(conv)
     if hit is not None and hit[0] == key:
+        _await_packed(conv, "wino", conv.weight.device)
         return hit[1], hit[2]
     lib = _lib.lib()
     w, bias = _effective_weight(conv, bn)
@@ -190,6 +228,7 @@ def packed_wino_weight(conv: nn.Conv2d, bn=None):
     with torch.cuda.device(w.device):
         rc = lib.sr_wino_pack_weights(_lib.ptr(w), co, ci, _lib.ptr(packed), _lib.stream_ptr(w.device))
     _lib.check(rc, "sr_wino_pack_weights")
+    _packed_here(conv, "wino", w.device)
     _PACKED_WINO[conv] = (key, packed, bias)
     return packed, bias
 
@@ -346,6 +385,10 @@ _WORKSPACES = {}                            # (device, tag) -> scratch tensor (g
 
 def _workspace(device, tag, nbytes):
     # one scratch buffer per (device, purpose, stream): launches on a stream are ordered, different streams must not share
+    if _lib.capturing():
+        # a HIP graph bakes the pointer in: give it memory from its own pool, never a cached buffer that a later eager
+        # call may grow and drop
+        return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
     key = (device, tag, torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
@@ -383,7 +426,10 @@ def stem7x7(image, conv: nn.Conv2d, bn=None, leaky=0.0, out=None):
             shift = (cb if scale is None else cb * scale) + (0 if shift is None else shift)
             shift = shift.contiguous()
         hit = (key, wp, scale, shift)
+        _packed_here(conv, "stem", conv.weight.device)
         _PACKED_STEM[conv] = hit
+    else:
+        _await_packed(conv, "stem", conv.weight.device)
     _, wp, scale, shift = hit
     b, _, h, w = image.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
@@ -490,7 +536,10 @@ def conv3x3_c16(x, conv: nn.Conv2d, in_stats=None, in_leaky=None, leaky=None):
             _lib.check(lib.sr_conv3x3_c16_pack_weights(_lib.ptr(conv.weight.detach().contiguous()), co, ci, _lib.ptr(wp),
                                                        _lib.stream_ptr(conv.weight.device)), "sr_conv3x3_c16_pack_weights")
         hit = (key, wp, conv.bias.detach() if conv.bias is not None else None)
+        _packed_here(conv, "c16", conv.weight.device)
         _PACKED_C16[conv] = hit
+    else:
+        _await_packed(conv, "c16", conv.weight.device)
     _, wp, bias = hit
     if in_stats is not None and (tuple(in_stats.shape) != (b, 2, ci) or not in_stats.is_contiguous()):
         raise ValueError(f"in_stats must be a contiguous [{b}, 2, {ci}] tensor")

@@ -1,8 +1,9 @@
 """Parity metrics.  The bar (BASELINE.json north_star): 1e-4 relative, fp32.
 
-`rel_err` is max|a-b| / max|b| (error relative to the tensor's dynamic range), the
-metric the reference's own "<10^-4" repeatability statement (reference test.py:16-20)
-is about.  Discrete outputs (masks, argmax planes) are compared exactly, with a
+`rel_err` is max|a-b| / max|b| (error relative to the tensor's dynamic range -- RANGE-relative,
+not element-wise), the metric the reference's own "<10^-4" repeatability statement (reference
+test.py:16-20) is about; every "1e-4" / "2e-5" / "2e-6" bound in tests/ is in that metric unless it
+says otherwise.  `elementwise_rel_percentiles` is the element-wise companion used on depth maps.  Discrete outputs (masks, argmax planes) are compared exactly, with a
 tiny allowance for ties that fp32 reassociation can flip (SURVEY.md §7 hard parts)."""
 import numpy as np
 
@@ -31,6 +32,17 @@ def assert_close(a, b, tol=TOL, what=""):
     assert np.isfinite(to_np(a)).all(), f"{what}: non-finite values"
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
     return e
+
+
+def elementwise_rel_percentiles(a, b, floor=1e-6):
+    """Element-wise |a-b| / max(|b|, floor) at the 50th / 99th / 99.9th percentile and its maximum -- stricter than
+    `rel_err` (which is relative to the tensor's dynamic range, the metric of the reference's own "<1e-4" statement,
+    test.py:16-20): used for positive quantities such as depth_pred, where every element has a meaningful scale."""
+    a, b = to_np(a).astype(np.float64), to_np(b).astype(np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    e = (np.abs(a - b) / np.maximum(np.abs(b), floor)).ravel()
+    return {"p50": float(np.percentile(e, 50)), "p99": float(np.percentile(e, 99)),
+            "p99.9": float(np.percentile(e, 99.9)), "max": float(e.max())}
 
 
 def mismatch_fraction(a, b):

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import oracle
-from parity import assert_close, mismatch_fraction
+from parity import elementwise_rel_percentiles, assert_close, mismatch_fraction
 from simplerecon_amd import depth_model as dm
 from simplerecon_amd import synthetic
 
@@ -105,6 +105,9 @@ def test_forward_all_native_matches_oracle_chain():
         assert_close(out[k], ref[k], what=k)
         assert_close(out[k.replace("log_", "")], np.exp(ref[k]), what="depth " + k)
         assert_close(unb[k], ref[k], what=k + " (unbatched matching encoder)")
+    # element-wise (not range-relative) error of the metric depth map: every element has a meaningful scale
+    pct = elementwise_rel_percentiles(out["depth_pred_s0_b1hw"], np.exp(ref["log_depth_pred_s0_b1hw"]))
+    assert pct["p99"] < 1e-4 and pct["max"] < 1e-3, pct
 
 
 def test_forward_api_signature_and_output_keys():

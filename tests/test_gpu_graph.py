@@ -76,3 +76,47 @@ def test_whole_model_graph_with_side_stream_prior_encoder():
         torch.cuda.synchronize()
         for k in ref:
             assert torch.equal(out[k], ref[k]), k
+
+
+def test_sub_batch_streams_equal_single_stream():
+    """DepthModel.hot_path with num_streams > 1 runs sub-batches on separate HIP streams through ONE cost-volume
+    manager: each stream must get its own sweep workspace (geometry records, channels-last sources, packed MLP) and
+    must wait for weights that another stream packed."""
+    B, K, D, h, w = 4, 3, 8, 24, 32
+    a = _inputs(B, K, h, w, 5)
+    outs = []
+    for streams in (1, 2, 4):
+        model = _model(h, w, K, D)          # fresh model: weight packing happens inside the multi-stream call
+        model.num_streams = streams
+        with torch.inference_mode():
+            for _ in range(3):              # repeated calls: workspaces are reused while other streams still read theirs
+                mc, ms = model.compute_matching_feats(a[0], a[1], False)
+                out = model.hot_path(list(a[2]), mc, ms, *a[3:], return_mask=True)
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in out.items() if v is not None})
+    for other in outs[1:]:
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], other[k]), k
+
+
+def test_graph_replay_survives_larger_eager_calls():
+    """A captured graph owns its sweep workspace: eager calls with a larger batch afterwards (which grow and replace
+    the manager's cached workspace) must not disturb a later replay."""
+    K, D, h, w = 3, 8, 24, 32
+    model = _model(h, w, K, D)
+    a = _inputs(1, K, h, w, 6)
+    big = _inputs(6, K, h, w, 7)
+    with torch.inference_mode():
+        mc, ms = model.compute_matching_feats(a[0], a[1], False)
+        ref = {k: v.clone() for k, v in model.hot_path(list(a[2]), mc, ms, *a[3:], return_mask=True).items()}
+    graphed = model.graphed(*a, return_mask=True)
+    junk = []
+    with torch.inference_mode():
+        for _ in range(2):
+            mc, ms = model.compute_matching_feats(big[0], big[1], False)
+            model.hot_path(list(big[2]), mc, ms, *big[3:], return_mask=True)
+            junk.append(torch.full((1 << 22,), float("nan"), device=DEV))   # recycle freed blocks with poison
+    out = graphed(*a)
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k

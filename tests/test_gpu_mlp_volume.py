@@ -131,3 +131,49 @@ def test_mlp_volume_other_view_counts(K):
     cv_o, low_o, mask_o = _oracle(mgr, inp, planes_np)
     assert_close(vol, cv_o, tol=2e-5, what=f"K={K} vs oracle")
     assert mismatch_fraction(mask, mask_o) == 0.0
+
+
+def test_cfg3_batch8_full_size_all_frames():
+    """BASELINE.json configs[2] at the BENCHMARKED batch: 8 frames, 7 views, 64 planes, 120x160, 202-channel MLP; all 8
+    frames against the oracle on a plane subset (the oracle's cost is per (pixel, plane)), masks of all frames exactly."""
+    B = 8
+    case = dict(B=B, K=7, C=16, D=64, h=120, w=160, seed=58)
+    inp = synthetic.cost_volume_inputs(B, 7, 16, 120, 160, seed=case["seed"])
+    mgr = _manager(case)
+    mgr.volume_memory_format = torch.channels_last      # what DepthModel uses
+    vol, lowest, planes, mask = _run(mgr, inp)
+    planes_np = planes[:, :, 0, 0].cpu().numpy()
+    sub = [0, 31, 63]
+    cv_o, _, mask_o = _oracle(mgr, inp, planes_np[:, sub])
+    for b in range(B):
+        assert_close(vol[b:b + 1, sub], cv_o[b:b + 1], tol=2e-5, what=f"cfg3 B=8 frame {b} vs oracle")
+    assert mismatch_fraction(mask, mask_o) == 0.0
+    assert_lowest_cost(lowest, vol, planes_np, lowest.cpu().numpy(), "cfg3 B=8 self-consistency")
+
+
+def test_cfg5_full_size_stress_config():
+    """BASELINE.json configs[4] at FULL size: 15 source views (410-input MLP, W1 streamed from L2), 96 planes, 960x720
+    images -> 180x240 matching maps, batch 4; metadata-MLP sweep against the oracle on a plane subset (all pixels, all 4
+    frames), dot-product sweep against the oracle on all 96 planes of one frame."""
+    B, K, C, D, h, w = 4, 15, 16, 96, 180, 240
+    inp = synthetic.cost_volume_inputs(B, K, C, h, w, seed=91)
+    mgr = _manager(dict(h=h, w=w, D=D, C=C, K=K, seed=17))
+    assert mgr.mlp.net[0].in_features == 410
+    vol, lowest, planes, mask = _run(mgr, inp)
+    planes_np = planes[:, :, 0, 0].cpu().numpy()
+    sub = [0, 47, 95]
+    cv_o, _, mask_o = _oracle(mgr, inp, planes_np[:, sub])
+    assert_close(vol[:, sub], cv_o, tol=2e-5, what="cfg5 full size vs oracle (planes 0, 47, 95)")
+    assert mismatch_fraction(mask, mask_o) == 0.0
+    assert_lowest_cost(lowest, vol, planes_np, lowest.cpu().numpy(), "cfg5 self-consistency")
+    del vol
+    from simplerecon_amd.cost_volume import CostVolumeManager
+    one = {k: (v[:1].contiguous() if v.dim() > 0 and v.shape[0] == B else v) for k, v in inp.items()}
+    dmgr = CostVolumeManager(h, w, num_depth_bins=D).to(DEV)
+    with torch.inference_mode():
+        dv, dlow, _, _ = dmgr(**{k: v.to(DEV) for k, v in one.items()})
+    n = {k: v.numpy() for k, v in one.items()}
+    dv_o, dlow_o, _ = oracle.dot_volume(n["cur_feats"], n["src_feats"], n["src_Ks"], n["src_extrinsics"], n["cur_invK"],
+                                        planes_np[:1])
+    assert_close(dv, dv_o, tol=2e-6, what="cfg5 dot sweep vs oracle")
+    assert_lowest_cost(dlow, dv, planes_np[:1], dlow_o, "cfg5 dot sweep")
