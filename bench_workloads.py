@@ -15,7 +15,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from simplerecon_amd import _lib, synthetic  # noqa: E402
+from simplerecon_amd import _lib, sharding, synthetic  # noqa: E402
 from simplerecon_amd.cost_volume import CostVolumeManager  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
@@ -102,10 +102,8 @@ class DotCfg2:
         self.last = self.mgr(**self.inp)
 
     def finish(self, world):
-        if world > 1:
-            lowest = self.last[1].contiguous()
-            out = [torch.empty_like(lowest) for _ in range(world)] if dist.get_rank() == 0 else None
-            dist.gather(lowest, out, dst=0)
+        # the job's only exchange: this step's results to rank 0 (keyframe i lives on rank i mod world)
+        sharding.gather_results(self.last[1], world * self.last[1].shape[0], dst=0)
 
     def config(self, world):
         return {"workload": f"{self.name}: CostVolumeManager (dot-product plane sweep), batch {self.B}/GPU, "
@@ -157,24 +155,28 @@ class DotCfg2:
         return None
 
     def cpu_baseline(self):
-        import oracle
-        n = {k: v.cpu().numpy() for k, v in self.inp.items()}
-        planes = self.mgr.generate_depth_planes(1, self.inp["min_depth"], self.inp["max_depth"])[:, :, 0, 0].cpu().numpy()
-        one = {k: (v[:1] if v.ndim > 0 and v.shape[0] == self.B and k not in ("min_depth", "max_depth") else v)
-               for k, v in n.items()}
+        """The reference's CPU PyTorch path for this workload = the ATen operator sequence of CostVolumeManager
+        (bench_cpu_aten.dot_volume) on all host cores, 1 frame, repeated for ~10 s."""
+        import bench_cpu_aten as aten
+        torch.set_num_threads(os.cpu_count())
+        c = {k: (v[:1].cpu() if v.dim() > 0 and v.shape[0] == self.B and k not in ("min_depth", "max_depth") else v.cpu())
+             for k, v in self.inp.items()}
+        planes = self.mgr.generate_depth_planes(1, self.inp["min_depth"], self.inp["max_depth"])[:, :, 0, 0].cpu().contiguous()
 
         def run():
-            oracle.dot_volume(one["cur_feats"], one["src_feats"], one["src_Ks"], one["src_extrinsics"],
-                              one["cur_invK"], planes)
+            with torch.inference_mode():
+                aten.dot_volume(c["cur_feats"], c["src_feats"], c["src_Ks"], c["src_extrinsics"], c["cur_invK"], planes)
         run()
         reps, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < 10.0 or reps < 3:
             run()
             reps += 1
         dt = (time.perf_counter() - t0) / reps
-        return {"value": 1.0 / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
-                "sample": f"{reps} repetitions of 1 frame of {self.name} through oracle/sr_oracle_dot_volume_f32 "
-                          f"(plain C + OpenMP, {oracle.num_threads()} threads of {os.cpu_count()} host CPUs)"}
+        return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{reps} repetitions of 1 frame of {self.name} through bench_cpu_aten.dot_volume: the ATen "
+                          f"(PyTorch {torch.__version__} CPU, fp32) operator sequence of the reference's "
+                          f"CostVolumeManager (matmul projection, F.grid_sample, mul / sum per plane), "
+                          f"torch.set_num_threads({torch.get_num_threads()}) of {os.cpu_count()} host CPUs"}
 
 
 class HeroCfg3:
@@ -253,10 +255,10 @@ class HeroCfg3:
             self.last = self._eager(*args)
 
     def finish(self, world):
-        if world > 1:
-            depth = self.last["depth_pred_s0_b1hw"].contiguous()
-            out = [torch.empty_like(depth) for _ in range(world)] if dist.get_rank() == 0 else None
-            dist.gather(depth, out, dst=0)
+        # the job's only exchange: the depth maps of the last batch to rank 0 (keyframe i lives on rank i mod world);
+        # hero_cfg4_stream gathers EVERY depth map of the run instead
+        depth = self.last["depth_pred_s0_b1hw"]
+        sharding.gather_results(depth, world * depth.shape[0], dst=0)
 
     def config(self, world):
         kind = "FeatureVolumeManager (metadata-MLP matching)" if self.feature_volume_type == "mlp_feature_volume" \
@@ -400,41 +402,35 @@ class HeroCfg3:
         return out
 
     def cpu_baseline(self):
-        import oracle
-        inp = {k: v[:1].cpu().numpy() if (v.dim() > 0 and v.shape[0] == self.B and k not in ("min_depth", "max_depth"))
-               else v.cpu().numpy() for k, v in self.inp.items()}
-        pyr = [f[:1].contiguous().cpu().numpy() for f in self.pyramid]
-        m = self.model
-        planes = m.cost_volume.generate_depth_planes(1, self.inp["min_depth"], self.inp["max_depth"])[:, :, 0, 0].cpu().numpy()
-        esd = {k: v.cpu().numpy() for k, v in m.cost_volume_net.state_dict().items()}
-        dsd = {k: v.cpu().numpy() for k, v in m.depth_decoder.state_dict().items()}
-        if self.feature_volume_type == "mlp_feature_volume":
-            sd = {k: v.cpu().numpy() for k, v in m.cost_volume.mlp.state_dict().items()}
-            mlp = dict(W1=sd["net.0.weight"], b1=sd["net.0.bias"], W2=sd["net.2.weight"], b2=sd["net.2.bias"],
-                       W3=sd["net.4.weight"], b3=sd["net.4.bias"])
-
-        if self.with_encoder:
-            msd = {k: v.cpu().numpy() for k, v in m.matching_model.state_dict().items()}
-            images = torch.cat([self.cur_image[:1].unsqueeze(1), self.src_image[:1]], dim=1)[0].cpu().numpy()
-        if self.prior:
-            psd = {k: v.cpu().numpy() for k, v in m.encoder.state_dict().items()}
+        """The reference's CPU PyTorch path for this workload = the same ATen operator sequence (bench_cpu_aten.py:
+        F.grid_sample / F.normalize / torch.cat / F.linear per plane, F.conv2d BasicBlocks, F.interpolate) on all host
+        cores; 1 frame (the GPU step is a batch of B), repeated until ~12 s have passed."""
+        import copy
+        import bench_cpu_aten as aten
+        torch.set_num_threads(os.cpu_count())
+        import types
+        m = self.model   # CPU copies of the parameter-holding sub-modules only (no streams / workspaces)
+        cpu_model = types.SimpleNamespace(
+            encoder=copy.deepcopy(m.encoder).cpu() if self.prior else None,
+            matching_model=copy.deepcopy(m.matching_model).cpu() if self.with_encoder else None,
+            cost_volume=types.SimpleNamespace(mlp=copy.deepcopy(m.cost_volume.mlp).cpu()
+                                              if hasattr(m.cost_volume, "mlp") else None),
+            cost_volume_net=copy.deepcopy(m.cost_volume_net).cpu(), depth_decoder=copy.deepcopy(m.depth_decoder).cpu())
+        c = {k: (v[:1].cpu() if v.dim() > 0 and v.shape[0] == self.B and k not in ("min_depth", "max_depth") else v.cpu())
+             for k, v in self.inp.items()}
+        planes = self.model.cost_volume.generate_depth_planes(1, self.inp["min_depth"], self.inp["max_depth"])
+        planes = planes[:, :, 0, 0].cpu().contiguous()
+        pyr = [f[:1].cpu().contiguous() for f in self.pyramid]
+        cur_img = self.cur_image[:1].cpu() if self.with_encoder else None
+        src_img = self.src_image[:1].cpu() if self.with_encoder else None
+        mlp = self.feature_volume_type == "mlp_feature_volume"
 
         def run():
-            nonlocal pyr
-            cur_f, src_f = inp["cur_feats"], inp["src_feats"]
-            if self.prior:
-                pyr = oracle.efficientnetv2_s_features(images[:1], psd)
-            if self.with_encoder:
-                f = oracle.resnet_matching_encoder(images, msd)
-                cur_f, src_f = f[None, 0], f[None, 1:]
-            if self.feature_volume_type == "mlp_feature_volume":
-                vol = oracle.mlp_volume(cur_f, src_f, inp["src_Ks"], inp["src_extrinsics"],
-                                        inp["src_poses"], inp["cur_invK"], planes, mlp)[0]
-            else:
-                vol = oracle.dot_volume(cur_f, src_f, inp["src_Ks"], inp["src_extrinsics"],
-                                        inp["cur_invK"], planes)[0]
-            feats = oracle.cv_encoder(vol, pyr[1:], esd)
-            return oracle.depth_decoder_pp([pyr[0]] + feats, dsd)
+            with torch.inference_mode():
+                aten.hero_forward(cpu_model, cur_img, src_img, c["src_extrinsics"], c["src_poses"], c["src_Ks"],
+                                  c["cur_invK"], c["min_depth"], c["max_depth"], planes, with_prior=self.prior,
+                                  with_encoder=self.with_encoder, pyramid=pyr, feats=(c["cur_feats"], c["src_feats"]),
+                                  mlp=mlp)
         t0 = time.perf_counter()
         run()
         reps, first = 1, time.perf_counter() - t0
@@ -442,13 +438,84 @@ class HeroCfg3:
             run()
             reps += 1
         dt = (time.perf_counter() - t0) / reps
-        return {"value": 1.0 / dt, "unit": "frames/s", "cores": oracle.num_threads(), "kind": "port",
+        return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": f"{reps} repetition(s) of 1 frame of {self.name} ("
                           f"{'image-prior encoder on 1 image + ' if self.prior else ''}"
                           f"{'matching encoder on 8 images + ' if self.with_encoder else ''}"
-                          f"cost volume + CVEncoder + DepthDecoderPP) "
-                          f"through oracle/ (plain C + OpenMP restatement, {oracle.num_threads()} threads of "
-                          f"{os.cpu_count()} host CPUs)"}
+                          f"cost volume + CVEncoder + DepthDecoderPP) through bench_cpu_aten.hero_forward: the ATen "
+                          f"(PyTorch {torch.__version__} CPU, fp32) operator sequence the reference runs on CPU -- "
+                          f"per-plane F.grid_sample / F.normalize / torch.cat / F.linear (looped FeatureVolumeManager), "
+                          f"F.conv2d BasicBlocks, F.interpolate -- torch.set_num_threads({torch.get_num_threads()}) of "
+                          f"{os.cpu_count()} host CPUs; first repetition {first:.2f} s"}
+
+
+def stream_batch_ids(rank, world, batch, max_batches, step):
+    """Global keyframe ids of rank `rank`'s batch `step`: its round-robin shard of a stream of world x max_batches x
+    batch keyframes (sharding.shard_indices), cut into batches (sharding.batches)."""
+    shard = sharding.shard_indices(world * max_batches * batch, rank, world)
+    return sharding.batches(shard, batch)[step % max_batches]
+
+
+class HeroCfg4Stream(HeroCfg3):
+    """BASELINE.json configs[3]: hero_model.yaml on a synthetic ScanNet-shaped STREAM of keyframes sharded round-robin
+    over the GPUs (keyframe i -> rank i mod world, sharding.shard_indices; reference loop test.py:257-280), batches of 8,
+    and the depth map of EVERY keyframe gathered to rank 0 over RCCL (sharding.gather_results) inside the timed region.
+    The stream has world x steps x 8 keyframes (2048 = the BASELINE config at 8 GPUs x 32 steps); keyframe i's images are
+    generated on the device from a generator seeded with i, its poses are the seeded DVMVS-like layout of
+    synthetic.poses with batch seed i // 8."""
+    name = "hero_cfg4_stream"
+
+    def __init__(self, dev, rank, max_batches=256):
+        super().__init__(dev, rank, name="hero_cfg4_stream")
+        self.rank, self.max_batches = rank, max_batches
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        Kmat, invK = synthetic.intrinsics(self.h, self.w)
+        self.src_Ks = torch.from_numpy(np.broadcast_to(Kmat, (self.B, self.K, 4, 4)).copy()).to(dev)
+        self.cur_invK = torch.from_numpy(np.broadcast_to(invK, (self.B, 4, 4)).copy()).to(dev)
+        self._pose_cache = {}
+        self.results = []
+        self.gathered = None
+
+    def _batch_ids(self, step):
+        return stream_batch_ids(self.rank, self.world, self.B, self.max_batches, step)
+
+    def _poses(self, ids):
+        key = ids[0]
+        hit = self._pose_cache.get(key)
+        if hit is None:
+            poses, extr = synthetic.poses(self.B, self.K, seed=key)
+            hit = (torch.from_numpy(poses).to(self.dev), torch.from_numpy(extr).to(self.dev))
+            self._pose_cache[key] = hit
+        return hit
+
+    def step(self, i=None):
+        if i == 0 or i is None:
+            self.results = []          # warm-up steps and the start of the timed region
+        ids = self._batch_ids(0 if i is None else i)
+        g = torch.Generator(device=self.dev).manual_seed(ids[0])
+        cur = torch.randn((self.B, 3, 4 * self.h, 4 * self.w), generator=g, device=self.dev)
+        src = torch.randn((self.B, self.K, 3, 4 * self.h, 4 * self.w), generator=g, device=self.dev)
+        poses, extr = self._poses(ids)
+        out = self.model.forward_tensors(cur, src, extr, poses, self.src_Ks, self.cur_invK, return_mask=True)
+        self.last = out
+        self.results.append(out["depth_pred_s0_b1hw"])
+
+    def finish(self, world):
+        local = torch.cat(self.results, 0)
+        self.gathered = sharding.gather_results(local, world * local.shape[0], dst=0)
+
+    def config(self, world):
+        c = super().config(world)
+        c["workload"] = (f"{self.name}: stream of world x steps x {self.B} synthetic keyframes (generated on-device, seeded "
+                         f"per keyframe), sharded round-robin over {world} GPU(s) in batches of {self.B}; whole "
+                         f"DepthModel.forward per batch (hero_model.yaml: {self.K} source views, {self.D} planes, 640x480, "
+                         f"fp32, random-init weights); every depth map gathered to rank 0 inside the timed region "
+                         f"(BASELINE.json configs[3]: 2048 keyframes = 8 GPUs x 32 steps)")
+        return c
+
+    def cpu_baseline(self):
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
+                "sample": "not run for this workload (same per-frame work as hero_cfg3)"}
 
 
 class HeroVolumeOnly:
@@ -473,10 +540,8 @@ class HeroVolumeOnly:
         self.last = self.mgr(return_mask=True, **self.inp)
 
     def finish(self, world):
-        if world > 1:
-            lowest = self.last[1].contiguous()
-            out = [torch.empty_like(lowest) for _ in range(world)] if dist.get_rank() == 0 else None
-            dist.gather(lowest, out, dst=0)
+        # the job's only exchange: this step's results to rank 0 (keyframe i lives on rank i mod world)
+        sharding.gather_results(self.last[1], world * self.last[1].shape[0], dst=0)
 
     def config(self, world):
         return {"workload": f"{self.name}: FeatureVolumeManager (metadata-MLP sweep) only, batch {self.B}/GPU, {self.K} "
@@ -585,6 +650,7 @@ WORKLOADS = {
     "hero_cfg3_s2": lambda dev, rank: HeroCfg3(dev, rank, streams=2),
     "hero_cfg3_s4": lambda dev, rank: HeroCfg3(dev, rank, streams=4),
     "dot_full": lambda dev, rank: DotFull(dev, rank),
+    "hero_cfg4_stream": lambda dev, rank: HeroCfg4Stream(dev, rank),
     "hero_cfg5_volume": lambda dev, rank: HeroVolumeOnly(dev, rank),
     "hero_cfg3_volume": lambda dev, rank: HeroVolumeOnly(dev, rank, B=8, K=7, D=64, h=120, w=160),
     "tsdf_fuse": lambda dev, rank: TsdfFuse(dev, rank),

@@ -60,3 +60,17 @@ def test_shard_indices_partition():
     assert sharding.batches(list(range(10)), 4) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
     with pytest.raises(ValueError):
         sharding.shard_indices(4, 2, 2)
+
+
+def test_bench_stream_batches_partition_the_stream():
+    """bench.py --workload hero_cfg4_stream: every keyframe of the world x steps x 8 stream is processed exactly once,
+    by rank id mod world (BASELINE.json configs[3]: 2048 keyframes over 8 GPUs = 32 batches of 8 per rank)."""
+    import bench_workloads as bw
+    world, batch, steps = 8, 8, 32
+    seen = []
+    for rank in range(world):
+        for step in range(steps):
+            ids = bw.stream_batch_ids(rank, world, batch, steps, step)
+            assert len(ids) == batch and all(i % world == rank for i in ids)
+            seen += ids
+    assert sorted(seen) == list(range(2048))
