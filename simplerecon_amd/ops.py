@@ -322,7 +322,8 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
             if use_wino:  # multiplies actually issued: 16 per 2x2 tile and (ci, co) pair, on padded regions / channels
                 regions = ((h + 7) // 8) * ((w + 15) // 16)
                 executed = 2.0 * b * regions * 32 * 16 * ((ci + 15) // 16 * 16) * ((co + 31) // 32 * 32)
-            prof.append((name, 2.0 * b * ho * wo * co * ci * k * k, ev0, ev1, (b, ci, h, w, co, k, s), executed))
+            prof.append((name, 2.0 * b * ho * wo * co * ci * k * k, ev0, ev1,
+                         (b, ci, h, w, co, k, s, ho, wo, residual is not None), executed))
     _lib.check(rc, "sr_conv3x3_wino_nhwc_fwd" if use_wino else "sr_conv2d_nhwc_fwd")
     return out
 
