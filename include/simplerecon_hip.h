@@ -70,6 +70,20 @@ int sr_dot_volume_sweep(const float* cur, const float* invK_cur, const float* pl
                         float* out_lowest, uint8_t* out_mask, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* Standalone forms of the reference's small geometry helpers (utils/geometry_utils.py) for callers outside the fused
+ * sweeps; same operation order as the sweeps' internal arithmetic (FP contraction off).
+ *  sr_backproject_fwd   BackprojectDepth.forward (:51-59): depth [B,h*w], invK [B,16] -> points [B,4,h*w]
+ *  sr_project3d_fwd     Project3D.forward (:72-89): points [B,4,N], K [B,16], T = cam_T_world [B,16] -> [B,3,N]
+ *                       (pixel x, pixel y, depth + eps)
+ *  sr_pose_distance_fwd pose_distance (:178-191): T [n,16] -> [n,3] = (combined, R_measure, t_measure)
+ *  sr_camera_rays_fwd   get_camera_rays (:143-175): points [B,3,N], T [B,16] (world_T_cam, or cam_T_world when
+ *                       in_camera_frame) -> unit rays [B,3,N] */
+int sr_backproject_fwd(const float* depth, const float* invK, float* out_points, int B, int h, int w, void* stream);
+int sr_project3d_fwd(const float* points, const float* K, const float* T, float* out, int B, int N, float eps,
+                     void* stream);
+int sr_pose_distance_fwd(const float* T, float* out, int n, void* stream);
+int sr_camera_rays_fwd(const float* points, const float* T, float* out, int B, int N, int in_camera_frame, void* stream);
+
 /* Self-test of the LDS-staged sweep's packed reciprocal (csrc/sr_dot_volume_lds.hip): out_fast[i] = that reciprocal of
  * x[i], out_div[i] = the IEEE division 1.0f / x[i] every other kernel uses; they must agree bit for bit for
  * 2^-60 <= |x| <= 2^60 (outside that range the sweep itself takes the division).  No reference counterpart: the

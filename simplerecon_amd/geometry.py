@@ -1,10 +1,21 @@
 """Geometry helpers of the hot path, API-compatible with reference utils/geometry_utils.py.
 
-Only state (buffers with the reference's names, so checkpoints load with strict=True) and
-the tiny host-side helpers live here; the per-pixel arithmetic of BackprojectDepth /
-Project3D (reference geometry_utils.py:51-59, 72-89) is fused into the HIP sweep kernels."""
+The modules hold the reference's buffers (`pix_coords_13N`, `eps`: checkpoints load with strict=True).  Inside the plane
+sweeps their arithmetic is fused into the HIP kernels (csrc/sr_common.h: sr_project_sample_xy); called on their own they
+run the standalone kernels of csrc/sr_geometry.hip, which use the same operation order -- there is no torch / CPU
+fallback (device fp32 tensors only, like the rest of the package)."""
+import ctypes as C
+
 import torch
 from torch import nn
+
+from . import _lib
+
+
+def _f32c(name, t):
+    _lib.require_device_f32(name, t)
+    _lib.refuse_autograd(t)
+    return t.contiguous()
 
 
 class BackprojectDepth(nn.Module):
@@ -18,11 +29,17 @@ class BackprojectDepth(nn.Module):
         self.register_buffer("pix_coords_13N", pix.unsqueeze(0).float())
 
     def forward(self, depth_b1hw, invK_b44):
-        """Reference-semantics back-projection (geometry_utils.py:51-59) -- used by callers outside
-        the fused kernels (it is plain torch; works on any device)."""
-        cam = torch.matmul(invK_b44[:, :3, :3], self.pix_coords_13N)
-        cam = depth_b1hw.flatten(start_dim=2) * cam
-        return torch.cat([cam, torch.ones_like(cam[:, :1])], 1)
+        """depth [B,1,h,w], invK [B,4,4] -> homogeneous camera points [B,4,h*w] (reference geometry_utils.py:51-59)."""
+        depth, invK = _f32c("depth_b1hw", depth_b1hw), _f32c("invK_b44", invK_b44)
+        b = depth.shape[0]
+        if tuple(depth.shape[-2:]) != (self.height, self.width) or depth.numel() != b * self.height * self.width:
+            raise ValueError(f"depth map {tuple(depth.shape)} does not match {self.height}x{self.width}")
+        out = torch.empty((b, 4, self.height * self.width), dtype=torch.float32, device=depth.device)
+        with torch.cuda.device(depth.device):
+            rc = _lib.lib().sr_backproject_fwd(_lib.ptr(depth), _lib.ptr(invK), _lib.ptr(out), b, self.height, self.width,
+                                               _lib.stream_ptr(depth.device))
+        _lib.check(rc, "sr_backproject_fwd")
+        return out
 
 
 class Project3D(nn.Module):
@@ -31,33 +48,45 @@ class Project3D(nn.Module):
     def __init__(self, eps: float = 1e-8):
         super().__init__()
         self.register_buffer("eps", torch.tensor(eps).view(1, 1, 1))
+        self._eps = float(eps)
 
     def forward(self, points_b4N, K_b44, cam_T_world_b44):
-        """Reference-semantics projection (geometry_utils.py:72-89), plain torch."""
-        P = K_b44 @ cam_T_world_b44
-        cam = P[:, :3] @ points_b4N
-        z = cam[:, 2:]
-        depth = z + self.eps
-        scale = torch.where(z.abs() > self.eps, 1.0 / depth, torch.ones_like(depth))
-        return torch.cat([cam[:, :2] * scale, depth], 1)
+        """points [B,4,N] -> [B,3,N] = (pixel x, pixel y, depth + eps) (reference geometry_utils.py:72-89)."""
+        pts, K, T = _f32c("points_b4N", points_b4N), _f32c("K_b44", K_b44), _f32c("cam_T_world_b44", cam_T_world_b44)
+        b, four, n = pts.shape
+        if four != 4 or tuple(K.shape) != (b, 4, 4) or tuple(T.shape) != (b, 4, 4):
+            raise ValueError("expected points [B,4,N], K [B,4,4], cam_T_world [B,4,4]")
+        out = torch.empty((b, 3, n), dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            rc = _lib.lib().sr_project3d_fwd(_lib.ptr(pts), _lib.ptr(K), _lib.ptr(T), _lib.ptr(out), b, n,
+                                             C.c_float(self._eps), _lib.stream_ptr(pts.device))
+        _lib.check(rc, "sr_project3d_fwd")
+        return out
 
 
 def pose_distance(pose_b44):
-    """DVMVS pose distance (reference geometry_utils.py:178-191): (combined, R_measure, t_measure)."""
-    R = pose_b44[:, :3, :3]
-    t = pose_b44[:, :3, 3]
-    tr = R.diagonal(offset=0, dim1=-1, dim2=-2).sum(-1)
-    r_m = torch.sqrt(2 * (1 - torch.minimum(torch.ones_like(tr) * 3.0, tr) / 3))
-    t_m = torch.norm(t, dim=1)
-    return torch.sqrt(t_m ** 2 + r_m ** 2), r_m, t_m
+    """DVMVS pose distance (reference geometry_utils.py:178-191): (combined, R_measure, t_measure), each [B] -- the very
+    values the metadata-MLP sweep computes for its pose channels (csrc/sr_dot_volume.hip: sr_geom_kernel)."""
+    T = _f32c("pose_b44", pose_b44)
+    n = T.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=T.device)
+    with torch.cuda.device(T.device):
+        rc = _lib.lib().sr_pose_distance_fwd(_lib.ptr(T), _lib.ptr(out), n, _lib.stream_ptr(T.device))
+    _lib.check(rc, "sr_pose_distance_fwd")
+    return out[:, 0], out[:, 1], out[:, 2]
 
 
 def get_camera_rays(world_T_cam_b44, world_points_b3N, in_camera_frame, cam_T_world_b44=None, eps=1e-4):
-    """Unit rays from the camera centre to the points (reference geometry_utils.py:143-175); plain torch
-    helper kept for API parity -- inside the feature volume the rays are computed in the HIP sweep."""
-    if in_camera_frame:
-        ones = torch.ones_like(world_points_b3N[:, :1])
-        rays = torch.matmul(cam_T_world_b44[:, :3, :4], torch.cat([world_points_b3N, ones], 1))
-    else:
-        rays = world_points_b3N - world_T_cam_b44[:, 0:3, 3][:, :, None]
-    return torch.nn.functional.normalize(rays, dim=1)
+    """Unit rays from the camera centre to the points (reference geometry_utils.py:143-175; `eps` is unused there too)."""
+    pts = _f32c("world_points_b3N", world_points_b3N)
+    T = _f32c("cam_T_world_b44" if in_camera_frame else "world_T_cam_b44",
+              cam_T_world_b44 if in_camera_frame else world_T_cam_b44)
+    b, three, n = pts.shape
+    if three != 3 or tuple(T.shape) != (b, 4, 4):
+        raise ValueError("expected points [B,3,N] and a [B,4,4] pose")
+    out = torch.empty_like(pts)
+    with torch.cuda.device(pts.device):
+        rc = _lib.lib().sr_camera_rays_fwd(_lib.ptr(pts), _lib.ptr(T), _lib.ptr(out), b, n, int(bool(in_camera_frame)),
+                                           _lib.stream_ptr(pts.device))
+    _lib.check(rc, "sr_camera_rays_fwd")
+    return out

@@ -149,9 +149,10 @@ def sort_sources_by_pose_penalty(cur_cam_T_world, src_world_T_cam):
     """Order of the source views as the reference's dataset feeds them to the model: ascending combined pose
     distance of cur_cam_T_src_cam (generic_mvs_dataset.py:643-659 with utils/geometry_utils.pose_distance :178-191).
     cur_cam_T_world [4,4], src_world_T_cam [K,4,4] (numpy or torch, fp32) -> list of K indices."""
-    import torch
-    from .geometry import pose_distance as pose_distance_b44
-    cur = torch.as_tensor(cur_cam_T_world)
-    src = torch.as_tensor(src_world_T_cam)
-    penalty_k, _, _ = pose_distance_b44(cur.unsqueeze(0) @ src)
-    return torch.argsort(penalty_k).tolist()
+    cur = np.asarray(cur_cam_T_world, dtype=np.float32)
+    src = np.asarray(src_world_T_cam, dtype=np.float32)
+    rel = cur[None] @ src                                        # cur_cam_T_src_cam, fp32 like the dataset's tensors
+    tr = np.trace(rel[:, :3, :3], axis1=1, axis2=2)
+    r_m = np.sqrt(2 * (1 - np.minimum(np.float32(3.0), tr) / 3))
+    t_m = np.linalg.norm(rel[:, :3, 3], axis=1)
+    return np.argsort(np.sqrt(t_m ** 2 + r_m ** 2), kind="stable").tolist()

@@ -16,12 +16,58 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _torch_backproject(depth_b1hw, invK, h, w):
+    """ATen statement of BackprojectDepth.forward (test-side reference)."""
+    ys, xs = torch.meshgrid(torch.arange(h, device=DEV), torch.arange(w, device=DEV), indexing="ij")
+    pix = torch.stack([xs.flatten() + 0.5, ys.flatten() + 0.5, torch.ones(h * w, device=DEV)], 0).unsqueeze(0).float()
+    cam = depth_b1hw.flatten(start_dim=2) * torch.matmul(invK[:, :3, :3], pix)
+    return torch.cat([cam, torch.ones_like(cam[:, :1])], 1)
+
+
+def _torch_project(points_b4N, K, T, eps=1e-8):
+    """ATen statement of Project3D.forward (test-side reference)."""
+    cam = (K @ T)[:, :3] @ points_b4N
+    z = cam[:, 2:]
+    depth = z + eps
+    scale = torch.where(z.abs() > eps, 1.0 / depth, torch.ones_like(depth))
+    return torch.cat([cam[:, :2] * scale, depth], 1)
+
+
+def test_geometry_helpers_on_hip():
+    """BackprojectDepth / Project3D / pose_distance / get_camera_rays as standalone HIP calls (csrc/sr_geometry.hip)."""
+    B, K, h, w = 2, 3, 10, 14
+    inp = {k: v.to(DEV) for k, v in synthetic.cost_volume_inputs(B, K, 16, h, w, seed=4).items()}
+    depth = 0.5 + 3.0 * torch.rand((B, 1, h, w), device=DEV)
+    pts = geometry.BackprojectDepth(h, w).to(DEV)(depth, inp["cur_invK"])
+    assert_close(pts, _torch_backproject(depth, inp["cur_invK"], h, w), tol=1e-6, what="BackprojectDepth")
+    Ks, T = inp["src_Ks"][:, 0].contiguous(), inp["src_extrinsics"][:, 0].contiguous()
+    cam = geometry.Project3D().to(DEV)(pts, Ks, T)
+    assert_close(cam, _torch_project(pts, Ks, T), tol=1e-5, what="Project3D")
+    poses = inp["src_poses"].view(-1, 4, 4)
+    dist, rm, tm = geometry.pose_distance(poses)
+    R, t = poses[:, :3, :3], poses[:, :3, 3]
+    tr = R.diagonal(dim1=-2, dim2=-1).sum(-1)
+    rm_r = torch.sqrt(2 * (1 - torch.clamp(tr, max=3.0) / 3))
+    tm_r = t.norm(dim=1)
+    # R_measure = sqrt(2 (1 - tr/3)) cancels catastrophically near the identity: compare squared values
+    assert torch.allclose(tm, tm_r, rtol=1e-6) and torch.allclose(rm ** 2, rm_r ** 2, atol=2e-7)
+    assert torch.allclose(dist ** 2, tm_r ** 2 + rm_r ** 2, rtol=1e-5, atol=2e-7)
+    wpts = pts[:, :3].contiguous()
+    rays = geometry.get_camera_rays(inp["src_poses"][:, 0].contiguous(), wpts, in_camera_frame=False)
+    ref = F.normalize(wpts - inp["src_poses"][:, 0, :3, 3][:, :, None], dim=1)
+    assert_close(rays, ref, tol=1e-6, what="get_camera_rays (world frame)")
+    rays_c = geometry.get_camera_rays(None, wpts, in_camera_frame=True, cam_T_world_b44=T)
+    ref_c = F.normalize(torch.matmul(T[:, :3, :4], torch.cat([wpts, torch.ones_like(wpts[:, :1])], 1)), dim=1)
+    assert_close(rays_c, ref_c, tol=1e-6, what="get_camera_rays (camera frame)")
+    with pytest.raises(Exception):
+        geometry.pose_distance(poses.cpu())   # no CPU fallback
+
+
 def _torch_warp(inp, planes_b1hw, h, w):
     """Plain PyTorch fp32 reference of the op (same composition as reference cost_volume.py:139-234)."""
     b, k, c = inp["src_feats"].shape[:3]
-    bp, pr = geometry.BackprojectDepth(h, w).to(DEV), geometry.Project3D().to(DEV)
-    wp = bp(planes_b1hw, inp["cur_invK"]).repeat_interleave(k, dim=0)
-    cam = pr(wp, inp["src_Ks"].view(-1, 4, 4), inp["src_extrinsics"].view(-1, 4, 4)).view(-1, 3, h, w)
+    wp = _torch_backproject(planes_b1hw, inp["cur_invK"], h, w).repeat_interleave(k, dim=0)
+    cam = _torch_project(wp, inp["src_Ks"].view(-1, 4, 4), inp["src_extrinsics"].view(-1, 4, 4)).view(-1, 3, h, w)
     scale = torch.tensor([1 / w, 1 / h], device=DEV).view(1, 1, 1, 2)
     uv = 2 * cam[:, :2].permute(0, 2, 3, 1) * scale - 1
     warped = F.grid_sample(inp["src_feats"].view(-1, c, h, w), uv, padding_mode="zeros", mode="bilinear",
