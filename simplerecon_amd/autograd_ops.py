@@ -1,0 +1,219 @@
+"""Differentiable conv-stack operators: the training path of BasicBlock / CVEncoder / DepthDecoderPP (reference
+train.py:126-145 runs autograd through modules/layers.py:24-85 and modules/networks.py:20-127).
+
+torch.autograd is the tape (plumbing); every arithmetic step, forward and backward, is a HIP kernel:
+  forward        the same MFMA kernels as inference (direct / Winograd), weights packed per call (they change every step);
+  data gradient  the forward kernels on the flipped, transposed weight (stride 2: on the zero-stuffed output gradient);
+  weight / bias  csrc/sr_conv_bwd.hip (MFMA split over pixels, fp32 atomics);
+  LeakyReLU      from the saved output; bilinear x2: its adjoint kernel.
+Gradients are pinned to the reference's own autograd (tests/golden/grad_block_*.npz, grad_cv_encoder_narrow.npz,
+grad_decoder_narrow.npz).  Not covered yet: the two encoders (no BatchNorm / InstanceNorm backward) -- DepthModel treats
+their outputs as constants."""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+from .ops import _is_nhwc_view, _strides, as_nhwc, empty_nhwc
+
+
+def grad_wanted(*tensors_or_modules):
+    """True when autograd is recording and any tensor / module parameter asks for a gradient."""
+    if not torch.is_grad_enabled():
+        return False
+    for t in tensors_or_modules:
+        if isinstance(t, torch.Tensor):
+            if t.requires_grad:
+                return True
+        elif isinstance(t, nn.Module):
+            if any(p.requires_grad for p in t.parameters()):
+                return True
+        elif isinstance(t, (list, tuple)):
+            if grad_wanted(*t):
+                return True
+    return False
+
+
+def _dense_nhwc(t):
+    """Channels-last, dense (pixel stride = C): what the elementwise backward kernels and the wgrad staging expect."""
+    t = as_nhwc(t, "gradient")
+    if t.stride(1) != 1 or t.stride(3) != t.shape[1] or t.stride(2) != t.shape[3] * t.shape[1]:
+        t = t.contiguous(memory_format=torch.channels_last)
+    return t
+
+
+def _conv_raw(x, weight, bias, stride, residual=None, slope=None):
+    """act(conv(x, weight) + bias [+ residual]) on the inference kernels with a weight TENSOR [Co, Ci, k, k]
+    (packed on the fly; padding k // 2)."""
+    lib = _lib.lib()
+    x = as_nhwc(x, "conv input")
+    b, ci, h, w = x.shape
+    co, ci_w, k, _ = weight.shape
+    if ci_w != ci:
+        raise ValueError(f"conv weight expects {ci_w} input channels, got {ci}")
+    ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+    out = empty_nhwc(b, co, ho, wo, x.device)
+    if b == 0:
+        return out
+    wd = weight.detach().contiguous()
+    use_wino = stride == 1 and k == 3 and bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, stride))
+    st = _lib.stream_ptr(x.device)
+    with torch.cuda.device(x.device):
+        if use_wino:
+            wp = torch.empty(lib.sr_wino_packed_weight_floats(co, ci), dtype=torch.float32, device=x.device)
+            _lib.check(lib.sr_wino_pack_weights(_lib.ptr(wd), co, ci, _lib.ptr(wp), st), "sr_wino_pack_weights")
+        else:
+            wp = torch.empty(lib.sr_conv_packed_weight_floats(co, ci, k), dtype=torch.float32, device=x.device)
+            _lib.check(lib.sr_conv_pack_weights(_lib.ptr(wd), co, ci, k, _lib.ptr(wp), st), "sr_conv_pack_weights")
+        isb, isp = _strides(x)
+        osb, osp = _strides(out)
+        if residual is not None:
+            residual = as_nhwc(residual, "residual")
+        rsb, rsp = _strides(residual) if residual is not None else (0, 0)
+        bd = bias.detach().contiguous() if bias is not None else None
+        sl = C.c_float(-1.0 if slope is None else float(slope))
+        if use_wino:
+            rc = lib.sr_conv3x3_wino_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bd), _lib.ptr(residual), rsb,
+                                              rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, sl, st)
+        else:
+            rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bd), _lib.ptr(residual), rsb, rsp,
+                                        _lib.ptr(out), osb, osp, b, h, w, ci, co, k, stride, sl, st)
+    _lib.check(rc, "conv forward")
+    return out
+
+
+class _ConvBiasAct(torch.autograd.Function):
+    """y = act(conv(x, W, stride, pad = k // 2) + b [+ residual]), act = LeakyReLU(slope) or identity (slope None)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride, slope):
+        for name, t in (("conv input", x), ("conv weight", weight)):
+            _lib.require_device_f32(name, t)
+        x = as_nhwc(x, "conv input")
+        out = _conv_raw(x, weight, bias, stride, residual, slope)
+        ctx.stride, ctx.slope = stride, slope
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.save_for_backward(x, weight, out if slope is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, out = ctx.saved_tensors
+        lib = _lib.lib()
+        dev = x.device
+        b, ci, h, w = x.shape
+        co, _, k, _ = weight.shape
+        s = ctx.stride
+        ho, wo = g.shape[2], g.shape[3]
+        g = _dense_nhwc(g if g.dtype == torch.float32 else g.float())
+        st = _lib.stream_ptr(dev)
+        need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
+        with torch.cuda.device(dev):
+            if ctx.slope is not None:
+                gp = torch.empty_like(g)
+                _lib.check(lib.sr_act_bwd(_lib.ptr(g), _lib.ptr(_dense_nhwc(out)), _lib.ptr(gp), g.numel(),
+                                          C.c_float(float(ctx.slope)), st), "sr_act_bwd")
+            else:
+                gp = g
+            d_x = d_w = d_b = None
+            gsb, gsp = _strides(gp)
+            if need_w and b > 0:
+                d_w = torch.empty_like(weight)
+                xsb, xsp = _strides(x)
+                _lib.check(lib.sr_conv_wgrad_nhwc(_lib.ptr(x), xsb, xsp, _lib.ptr(gp), gsb, gsp, _lib.ptr(d_w), b, h, w, ci,
+                                                  co, k, s, st), "sr_conv_wgrad_nhwc")
+            elif need_w:
+                d_w = torch.zeros_like(weight)
+            if ctx.has_bias and need_b:
+                d_b = torch.empty((co,), dtype=torch.float32, device=dev)
+                _lib.check(lib.sr_bias_grad_nhwc(_lib.ptr(gp), gsb, gsp, _lib.ptr(d_b), b, ho, wo, co, st),
+                           "sr_bias_grad_nhwc")
+            if need_x:
+                wt = torch.empty((ci, co, k, k), dtype=torch.float32, device=dev)
+                _lib.check(lib.sr_conv_flip_transpose_weights(_lib.ptr(weight.detach().contiguous()), co, ci, k,
+                                                              _lib.ptr(wt), st), "sr_conv_flip_transpose_weights")
+                if s == 1:
+                    src = gp
+                else:  # stride 2: dL/dx = conv_s1(zero-stuffed dL/dy, flip(W)^T) on the input's grid
+                    src = empty_nhwc(b, co, h, w, dev)
+                    if b > 0:
+                        _lib.check(lib.sr_zero_stuff2x_nhwc(_lib.ptr(gp), gsb, gsp, _lib.ptr(src), b, ho, wo, h, w, co, st),
+                                   "sr_zero_stuff2x_nhwc")
+                d_x = _conv_raw(src, wt, None, 1)
+        return d_x, d_w, d_b, (gp if (ctx.has_res and need_r) else None), None, None
+
+
+class _Upsample2x(torch.autograd.Function):
+    """Bilinear x2, align_corners=False (reference generic_utils.py:96-105) with its adjoint as backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import ops
+        with torch.no_grad():
+            return ops.upsample2x(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dense_nhwc(g)
+        b, c, h2, w2 = g.shape
+        h, w = h2 // 2, w2 // 2
+        out = empty_nhwc(b, c, h, w, g.device)
+        if b > 0:
+            gsb, gsp = _strides(g)
+            osb, osp = _strides(out)
+            with torch.cuda.device(g.device):
+                rc = _lib.lib().sr_upsample2x_bwd_nhwc(_lib.ptr(g), gsb, gsp, _lib.ptr(out), osb, osp, b, h, w, c,
+                                                       _lib.stream_ptr(g.device))
+            _lib.check(rc, "sr_upsample2x_bwd_nhwc")
+        return out
+
+
+class _Exp(torch.autograd.Function):
+    """depth = exp(log_depth) (reference depth_model.py:392-400); backward = grad * depth."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import ops
+        with torch.no_grad():
+            y = ops.exp(x.detach())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous() if y.is_contiguous() else g.contiguous(memory_format=torch.channels_last)
+        if g.stride() != y.stride():
+            g = g.contiguous()
+            y = y.contiguous()
+        out = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            rc = _lib.lib().sr_mul_fwd(_lib.ptr(g), _lib.ptr(y), _lib.ptr(out), y.numel(), _lib.stream_ptr(y.device))
+        _lib.check(rc, "sr_mul_fwd")
+        return out
+
+
+def conv_bias_act(x, conv: nn.Conv2d, residual=None, slope=None):
+    if conv.padding_mode != "zeros" or conv.groups != 1 or conv.dilation != (1, 1) or \
+            tuple(conv.padding) != (conv.kernel_size[0] // 2,) * 2 or conv.kernel_size[0] not in (1, 3):
+        raise _lib.HipLibraryError(f"unsupported Conv2d configuration for the HIP training path: {conv}")
+    return _ConvBiasAct.apply(x, conv.weight, conv.bias, residual, conv.stride[0], slope)
+
+
+def basic_block(block, x):
+    """Differentiable BasicBlock.forward (reference layers.py:68-85), norm_layer = Identity."""
+    if not isinstance(block.bn1, nn.Identity) or not isinstance(block.bn2, nn.Identity):
+        raise _lib.HipLibraryError("the HIP BasicBlock implements norm_layer=nn.Identity only (what SimpleRecon uses)")
+    slope = block.relu.negative_slope
+    t = conv_bias_act(x, block.conv1, slope=slope)
+    identity = x if block.downsample is None else conv_bias_act(x, block.downsample[0])
+    return conv_bias_act(t, block.conv2, residual=identity, slope=slope)
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+def exp(x):
+    return _Exp.apply(x)

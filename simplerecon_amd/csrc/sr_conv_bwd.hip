@@ -1,0 +1,327 @@
+// sr_conv_bwd.hip -- backward pieces of the conv stack (BasicBlock / CVEncoder / DepthDecoderPP training path; reference
+// train.py:126-145 differentiates modules/layers.py:24-85 and modules/networks.py:20-127 through autograd) for gfx950.
+//
+//   data gradient   = the FORWARD kernels (sr_conv.hip / sr_wino.hip) on the flipped, transposed weight
+//                     (sr_conv_flip_transpose_weights); for a stride-2 conv on the zero-stuffed output gradient
+//                     (sr_zero_stuff2x_nhwc): dL/dx = conv3x3_s1(stuff(dL/dy), flip(W)^T)
+//   weight gradient = sr_conv_wgrad_nhwc: dW[co,ci,ky,kx] = sum_{b,y,x} dL/dy[b,co,y,x] * x[b,ci,s*y+ky-p,s*x+kx-p], a
+//                     [Cout] x [pixels] x [Cin*k*k] product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, M = co,
+//                     N = ci, K = 2 output pixels per step).  A workgroup owns a 64 x 64 (co, ci) block and a strided
+//                     share of the (image, output row, 32-pixel segment) items: gradient rows and the k input rows of a
+//                     segment are staged in LDS, wave (co half, ci half) keeps its k*k accumulator tiles (144 registers
+//                     for 3x3) over ALL its items and adds them to dW once, with hardware fp32 atomics (summation order
+//                     not fixed, like torch's cuDNN / MIOpen wgrad);
+//   bias gradient   = sr_bias_grad_nhwc (column sums of dL/dy);
+//   activation      = sr_act_bwd_nhwc: g * act'(y) from the saved OUTPUT (LeakyReLU with slope > 0 preserves the sign);
+//   bilinear x2     = sr_upsample2x_bwd_nhwc, the exact adjoint of sr_upsample2x_nhwc_fwd (same clamped taps).
+#include "sr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------ weight gradient ----
+
+#define WG_P 32        // output pixels of a segment
+#define WG_CT 64       // channels per block side
+
+struct SrWgradParams {
+  const float* x; int64_t x_sb; int x_sp;      // input  [B, H, W, Cin]  (channels-last view)
+  const float* g; int64_t g_sb; int g_sp;      // dL/dy  [B, Ho, Wo, Cout]
+  float* dw;                                    // [Cout, Cin, k, k], zero-initialised
+  int B, H, W, Cin, Cout, Ho, Wo, stride, pad;
+  int co_blocks, ci_blocks, items, wgs_per_block;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void sr_conv_wgrad_kernel(SrWgradParams p) {
+  constexpr int TAPS = KS * KS;
+  // LDS: gradient segment [WG_P][64 co] + input rows [KS][span][64 ci], span = stride*(WG_P-1) + KS (<= 65)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int span = p.stride * (WG_P - 1) + KS;
+  float* gs = lds;                       // [WG_P][WG_CT]
+  float* xs = lds + WG_P * WG_CT;        // [KS][span][WG_CT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, kk = lane >> 5;
+  const int blk = blockIdx.x / p.wgs_per_block, sub = blockIdx.x - blk * p.wgs_per_block;
+  const int cob = blk / p.ci_blocks, cib = blk - cob * p.ci_blocks;
+  const int co0 = cob * WG_CT, ci0 = cib * WG_CT;
+  const int coh = wave & 1, cih = wave >> 1;   // this wave's 32 x 32 quadrant of the block
+  const int segs = (p.Wo + WG_P - 1) / WG_P;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  for (int item = sub; item < p.items; item += p.wgs_per_block) {
+    int it = item;
+    const int seg = it % segs; it /= segs;
+    const int oy = it % p.Ho;
+    const int b = it / p.Ho;
+    const int ox0 = seg * WG_P;
+    __syncthreads();  // previous item's fragments are consumed
+    // stage dL/dy[b, oy, ox0 .. ox0+31, co0 .. co0+63] (zeros outside the map / the channel range)
+    for (int e = tid; e < WG_P * (WG_CT / 4); e += 256) {
+      const int px = e >> 4, q = e & 15;
+      const int ox = ox0 + px, c = co0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ox < p.Wo && c < p.Cout) {
+        const float* src = p.g + (int64_t)b * p.g_sb + ((int64_t)oy * p.Wo + ox) * p.g_sp + c;
+        v.x = src[0];
+        if (c + 1 < p.Cout) v.y = src[1];
+        if (c + 2 < p.Cout) v.z = src[2];
+        if (c + 3 < p.Cout) v.w = src[3];
+      }
+      *reinterpret_cast<float4*>(&gs[px * WG_CT + 4 * q]) = v;
+    }
+    // stage the KS input rows iy = stride*oy + ky - pad, columns stride*ox0 - pad .. (zero padding outside the image)
+    for (int e = tid; e < KS * span * (WG_CT / 4); e += 256) {
+      const int q = e & 15;
+      const int col = (e >> 4) % span, ky = (e >> 4) / span;
+      const int iy = p.stride * oy + ky - p.pad, ix = p.stride * ox0 + col - p.pad, c = ci0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin) {
+        const float* src = p.x + (int64_t)b * p.x_sb + ((int64_t)iy * p.W + ix) * p.x_sp + c;
+        v.x = src[0];
+        if (c + 1 < p.Cin) v.y = src[1];
+        if (c + 2 < p.Cin) v.z = src[2];
+        if (c + 3 < p.Cin) v.w = src[3];
+      }
+      *reinterpret_cast<float4*>(&xs[(ky * span + col) * WG_CT + 4 * q]) = v;
+    }
+    __syncthreads();
+    // K loop: two output pixels per MFMA step (lane half kk picks the pixel)
+#pragma unroll 4
+    for (int ps = 0; ps < WG_P; ps += 2) {
+      const float a = gs[(ps + kk) * WG_CT + 32 * coh + i];          // A[m = co][k = pixel]
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int ky = t / KS, kx = t - ky * KS;
+        const float bq = xs[(ky * span + p.stride * (ps + kk) + kx) * WG_CT + 32 * cih + i];   // B[k = pixel][n = ci]
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // flush: acc[t][r] = dW[co0 + 32*coh + (r&3) + 8*(r>>2) + 4*kk][ci0 + 32*cih + i][tap t]
+  const int ci = ci0 + 32 * cih + i;
+  if (ci < p.Cin) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * coh + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (co < p.Cout) atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * TAPS + t, acc[t][r]);
+      }
+  }
+}
+
+extern "C" int sr_conv_wgrad_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* grad_out,
+                                  int64_t g_batch_stride, int g_pix_stride, float* d_weight, int B, int H, int W, int Cin,
+                                  int Cout, int ksize, int stride, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return SR_ERR_UNSUPPORTED;
+  if (!d_weight) return SR_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(d_weight, 0, (size_t)Cout * Cin * ksize * ksize * sizeof(float), stream);
+  if (e != hipSuccess) return sr_hip_rc(e);
+  if (B == 0) return SR_OK;
+  if (!in || !grad_out) return SR_ERR_INVALID_ARGUMENT;
+  SrWgradParams p;
+  p.x = in; p.x_sb = in_batch_stride; p.x_sp = in_pix_stride;
+  p.g = grad_out; p.g_sb = g_batch_stride; p.g_sp = g_pix_stride;
+  p.dw = d_weight;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.pad = ksize / 2;
+  p.Ho = (H + 2 * p.pad - ksize) / stride + 1;
+  p.Wo = (W + 2 * p.pad - ksize) / stride + 1;
+  p.co_blocks = (Cout + WG_CT - 1) / WG_CT;
+  p.ci_blocks = (Cin + WG_CT - 1) / WG_CT;
+  p.items = B * p.Ho * ((p.Wo + WG_P - 1) / WG_P);
+  const int blocks = p.co_blocks * p.ci_blocks;
+  int per = (2 * 256 + blocks - 1) / blocks;   // ~2 workgroups per CU in total
+  if (per > p.items) per = p.items;
+  if (per < 1) per = 1;
+  p.wgs_per_block = per;
+  const int span = stride * (WG_P - 1) + ksize;
+  const size_t lds = (size_t)(WG_P * WG_CT + ksize * span * WG_CT) * sizeof(float);
+  if (ksize == 3) {
+    e = hipFuncSetAttribute((const void*)sr_conv_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return sr_hip_rc(e);
+    hipLaunchKernelGGL(sr_conv_wgrad_kernel<3>, dim3(blocks * per), dim3(256), lds, stream, p);
+  } else {
+    hipLaunchKernelGGL(sr_conv_wgrad_kernel<1>, dim3(blocks * per), dim3(256), lds, stream, p);
+  }
+  return sr_hip_rc(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ bias gradient ------
+
+__global__ __launch_bounds__(256) void sr_bias_grad_kernel(const float* __restrict__ g, int64_t g_sb, int g_sp, int B,
+                                                          int HW, int C, float* __restrict__ db) {
+  // block = 64 channels x 4 pixel lanes; grid.x = pixel chunks, grid.y = channel blocks
+  __shared__ float red[4][64];
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < C) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t px = (int64_t)blockIdx.x * 4 + part; px < total; px += (int64_t)gridDim.x * 4) {
+      const int b = (int)(px / HW);
+      s += g[(int64_t)b * g_sb + (px - (int64_t)b * HW) * g_sp + c];
+    }
+  }
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && c < C) atomicAdd(db + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+extern "C" int sr_bias_grad_nhwc(const float* grad_out, int64_t g_batch_stride, int g_pix_stride, float* d_bias, int B,
+                                 int H, int W, int C, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || !d_bias) return SR_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(d_bias, 0, (size_t)C * sizeof(float), stream);
+  if (e != hipSuccess) return sr_hip_rc(e);
+  if (B == 0) return SR_OK;
+  if (!grad_out) return SR_ERR_INVALID_ARGUMENT;
+  const long total = (long)B * H * W;
+  int chunks = (int)((total + 255) / 256);
+  if (chunks > 512) chunks = 512;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(sr_bias_grad_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, stream, grad_out, g_batch_stride,
+                     g_pix_stride, B, H * W, C, d_bias);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ elementwise --------
+
+// g_pre = g * act'(y) from the saved output y = act(pre): LeakyReLU slope >= 0 (y > 0 <=> pre > 0 for slope > 0;
+// for slope == 0, ReLU, y > 0 is the derivative's support as well).  Dense [n] arrays (same layout for g, y, out).
+__global__ __launch_bounds__(256) void sr_act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                        float* __restrict__ out, int64_t n, float slope) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = y[i] > 0.0f ? g[i] : g[i] * slope;
+}
+
+extern "C" int sr_act_bwd(const float* grad, const float* out_saved, float* grad_pre, int64_t n, float leaky_slope,
+                          void* stream_) {
+  if (n < 0 || leaky_slope < 0.0f) return SR_ERR_INVALID_ARGUMENT;
+  if (n == 0) return SR_OK;
+  if (!grad || !out_saved || !grad_pre) return SR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sr_act_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, grad,
+                     out_saved, grad_pre, n, leaky_slope);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// out[b, 2y, 2x, :] = in[b, y, x, :], zeros elsewhere (out is [B, Hs, Ws, C] with Hs >= 2*H-1, Ws >= 2*W-1): the
+// zero-stuffed output gradient on which a stride-1 convolution computes the data gradient of a stride-2 one.
+__global__ __launch_bounds__(256) void sr_zero_stuff2x_kernel(const float* __restrict__ in, int64_t in_sb, int in_sp,
+                                                             float* __restrict__ out, int H, int W, int Hs, int Ws, int C) {
+  const int b = blockIdx.y;
+  const int64_t total = (int64_t)Hs * Ws * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t px = e / C;
+    const int oy = (int)(px / Ws), ox = (int)(px - (int64_t)oy * Ws);
+    float v = 0.0f;
+    if (!(oy & 1) && !(ox & 1) && (oy >> 1) < H && (ox >> 1) < W)
+      v = in[(int64_t)b * in_sb + ((int64_t)(oy >> 1) * W + (ox >> 1)) * in_sp + c];
+    out[((int64_t)b * Hs * Ws + px) * C + c] = v;
+  }
+}
+
+extern "C" int sr_zero_stuff2x_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out, int B, int H,
+                                    int W, int Hs, int Ws, int C, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || Hs < 2 * H - 1 || Ws < 2 * W - 1) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!in || !out) return SR_ERR_INVALID_ARGUMENT;
+  const long total = (long)Hs * Ws * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sr_zero_stuff2x_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, in, in_batch_stride,
+                     in_pix_stride, out, H, W, Hs, Ws, C);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// Adjoint of sr_upsample2x_nhwc_fwd (bilinear x2, align_corners=False, reference generic_utils.py:96-105): every
+// input pixel gathers from the <= 4 x 4 output pixels whose (clamped) taps include it, with the forward's weights.
+__device__ __forceinline__ float sr_up_weight(int o, int src, int n) {
+  // weight of input index `src` in the interpolation of output index `o` along an axis of input length n
+  const float s = fmaxf(((float)o + 0.5f) * 0.5f - 0.5f, 0.0f);
+  const int i0 = (int)s, i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  const float l = s - (float)i0;
+  return (src == i0 ? 1.0f - l : 0.0f) + (src == i1 ? l : 0.0f);
+}
+
+__global__ __launch_bounds__(256) void sr_upsample2x_bwd_kernel(const float* __restrict__ g, int64_t g_sb, int g_sp,
+                                                               float* __restrict__ out, int64_t out_sb, int out_sp, int H,
+                                                               int W, int C) {
+  const int b = blockIdx.y;
+  const int64_t total = (int64_t)H * W * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t px = e / C;
+    const int y = (int)(px / W), x = (int)(px - (int64_t)y * W);
+    float s = 0.0f;
+    for (int oy = max(2 * y - 1, 0); oy <= min(2 * y + 2, 2 * H - 1); ++oy) {
+      const float wy = sr_up_weight(oy, y, H);
+      if (wy == 0.0f) continue;
+      float r = 0.0f;
+      for (int ox = max(2 * x - 1, 0); ox <= min(2 * x + 2, 2 * W - 1); ++ox) {
+        const float wx = sr_up_weight(ox, x, W);
+        if (wx != 0.0f) r += wx * g[(int64_t)b * g_sb + ((int64_t)oy * 2 * W + ox) * g_sp + c];
+      }
+      s += wy * r;
+    }
+    out[(int64_t)b * out_sb + px * out_sp + c] = s;
+  }
+}
+
+extern "C" int sr_upsample2x_bwd_nhwc(const float* grad_out, int64_t g_batch_stride, int g_pix_stride, float* grad_in,
+                                      int64_t in_batch_stride, int in_pix_stride, int B, int H, int W, int C,
+                                      void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!grad_out || !grad_in) return SR_ERR_INVALID_ARGUMENT;
+  const long total = (long)H * W * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sr_upsample2x_bwd_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, grad_out,
+                     g_batch_stride, g_pix_stride, grad_in, in_batch_stride, in_pix_stride, H, W, C);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// W'[ci, co, ky, kx] = W[co, ci, k-1-ky, k-1-kx]: the weight of the convolution that computes the data gradient.
+__global__ __launch_bounds__(256) void sr_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ out, int Co,
+                                                               int Ci, int KK, int k) {
+  const int64_t total = (int64_t)Co * Ci * KK;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(e % KK);
+    const int64_t r = e / KK;
+    const int co = (int)(r % Co), ci = (int)(r / Co);   // e indexes out[ci][co][t]
+    const int ky = t / k, kx = t - ky * k;
+    out[e] = w[((int64_t)co * Ci + ci) * KK + (k - 1 - ky) * k + (k - 1 - kx)];
+  }
+}
+
+extern "C" int sr_conv_flip_transpose_weights(const float* weight, int Cout, int Cin, int ksize, float* out, void* stream_) {
+  if (!weight || !out || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return SR_ERR_INVALID_ARGUMENT;
+  const long total = (long)Cout * Cin * ksize * ksize;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sr_flip_transpose_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, weight, out, Cout, Cin,
+                     ksize * ksize, ksize);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// out = a * b (dense arrays): backward of depth = exp(log_depth) (grad * depth), reference depth_model.py:392-400
+__global__ __launch_bounds__(256) void sr_mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] * b[i];
+}
+
+extern "C" int sr_mul_fwd(const float* a, const float* b, float* out, int64_t n, void* stream_) {
+  if (n < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (n == 0) return SR_OK;
+  if (!a || !b || !out) return SR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sr_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a, b, out, n);
+  return sr_hip_rc(hipGetLastError());
+}

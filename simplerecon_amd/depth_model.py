@@ -13,6 +13,8 @@ its public definition; timm's parameter names, so `encoder.*` checkpoint entries
 pluggable (`image_encoder=`, `matching_encoder=`); `timm_image_encoder()` builds the reference's own
 constructor call when timm is importable.  `hot_path()` starts from the encoders' outputs.
 """
+import contextlib
+import warnings
 from dataclasses import dataclass
 
 import torch
@@ -20,7 +22,7 @@ from torch import nn
 
 from .cost_volume import CostVolumeManager, FeatureVolumeManager
 from .layers import TensorFormatter
-from . import ops
+from . import autograd_ops, ops
 from .image_encoder import EfficientNetV2SFeatures
 from .networks import CVEncoder, DepthDecoderPP, ResnetMatchingEncoder
 
@@ -88,6 +90,8 @@ def timm_image_encoder(pretrained=True):
 
 
 class DepthModel(nn.Module):
+    _warned_frozen = False
+
     def __init__(self, opts, image_encoder=None, matching_encoder=None):
         super().__init__()
         self.run_opts = opts
@@ -250,7 +254,8 @@ class DepthModel(nn.Module):
             if flip:
                 log_depth = torch.flip(log_depth, (-1,))
             depth_outputs[k] = log_depth
-            depth_outputs[k.replace("log_", "")] = ops.exp(log_depth)
+            depth_outputs[k.replace("log_", "")] = autograd_ops.exp(log_depth) if log_depth.requires_grad \
+                else ops.exp(log_depth)
         depth_outputs["lowest_cost_bhw"] = lowest_cost
         depth_outputs["overall_mask_bhw"] = overall_mask_bhw
         return depth_outputs
@@ -291,9 +296,18 @@ class DepthModel(nn.Module):
                         unbatched_matching_encoder_forward=False, return_mask=False, flip=False):
         """DepthModel.forward after the dict unpacking / relative-pose step (reference depth_model.py:358-405):
         image-prior encoder, matching encoder, cost volume, CVEncoder, decoder, exp -- every stage on HIP kernels."""
-        cur_feats = self.image_prior_pyramid(cur_image)
-        matching_cur_feats, matching_src_feats = self.compute_matching_feats(
-            cur_image, src_image, unbatched_matching_encoder_forward)
+        # Training (grad mode): cost volume, CVEncoder and DepthDecoderPP are differentiable on HIP kernels
+        # (autograd_ops, cost_volume._*VolumeFunction); the two encoders have no backward kernels yet, so their outputs
+        # enter the graph as constants (a frozen-encoder fine-tune; stated once).
+        frozen = torch.is_grad_enabled()
+        if frozen and not DepthModel._warned_frozen:
+            DepthModel._warned_frozen = True
+            warnings.warn("simplerecon_amd: the image-prior and matching encoders are inference-only on the HIP path; "
+                          "under autograd their outputs are treated as constants (frozen encoders)")
+        with torch.no_grad() if frozen else contextlib.nullcontext():
+            cur_feats = self.image_prior_pyramid(cur_image)
+            matching_cur_feats, matching_src_feats = self.compute_matching_feats(
+                cur_image, src_image, unbatched_matching_encoder_forward)
         if flip:
             matching_cur_feats = torch.flip(matching_cur_feats, (-1,))
             matching_src_feats = torch.flip(matching_src_feats, (-1,))

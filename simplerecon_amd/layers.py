@@ -56,7 +56,13 @@ class BasicBlock(nn.Module):
     def forward(self, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
         """x: [B,C,H,W] (any memory format; channels_last avoids a repack).  `out` optionally names a preallocated
         (channel slice of a) channels_last tensor to write into, e.g. the consumer's concat buffer."""
-        from . import ops
+        from . import autograd_ops, ops
+        if autograd_ops.grad_wanted(x, self):   # training path: differentiable operators (HIP forward and backward)
+            y = autograd_ops.basic_block(self, x)
+            if out is not None:
+                out.copy_(y)                    # (autograd tracks the slice write; the training forwards avoid `out=`)
+                return out
+            return y
         return ops.basic_block(self, x, out=out)
 
 

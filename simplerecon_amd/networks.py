@@ -67,8 +67,20 @@ class CVEncoder(nn.Module):
             )
             self.num_ch_enc.append(num_ch_out)
 
+    def _forward_train(self, x, img_feats):
+        """Differentiable forward (reference networks.py:120-127 as written: concat with torch.cat, which autograd
+        splits again on the way back); every conv runs autograd_ops (HIP forward + backward)."""
+        outputs = []
+        for i in range(self.num_blocks):
+            x = self.convs[f"ds_conv_{i}"](x)
+            x = self.convs[f"conv_{i}"](torch.cat([x, img_feats[i]], dim=1))
+            outputs.append(x)
+        return outputs
+
     def forward(self, x, img_feats):
-        from . import ops
+        from . import autograd_ops, ops
+        if autograd_ops.grad_wanted(x, list(img_feats), self):
+            return self._forward_train(x, img_feats)
         outputs = []
         for i in range(self.num_blocks):
             ds = self.convs[f"ds_conv_{i}"]
@@ -134,8 +146,31 @@ class DepthDecoderPP(nn.Module):
             _SIDE_STREAMS[device] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         return _SIDE_STREAMS[device]
 
+    def _forward_train(self, input_features):
+        """Differentiable forward: the UNet++ graph of reference networks.py:75-96 on autograd_ops (torch.cat for the
+        concats, the HIP bilinear x2 with its adjoint); the head evaluations the reference overwrites are skipped
+        (they receive no gradient there either)."""
+        from . import autograd_ops
+        prev_outputs, outputs, depth_outputs = list(input_features), [], {}
+        for j in range(1, 5):
+            for i in range(4 - j, -1, -1):
+                parts = [self.convs[f"right_conv_{i}{j - 1}"](prev_outputs[i]),
+                         autograd_ops.upsample2x(self.convs[f"diag_conv_{i + 1}{j - 1}"](prev_outputs[i + 1]))]
+                if i + j != 4:
+                    parts.append(autograd_ops.upsample2x(self.convs[f"up_conv_{i + 1}{j}"](outputs[-1])))
+                output = self.convs[f"in_conv_{i}{j}"](torch.cat(parts, dim=1))
+                outputs.append(output)
+                if i + j == 4:
+                    head = self.convs[f"output_{i}"]
+                    hx = output if isinstance(head[0], nn.Identity) else head[0](output)
+                    depth_outputs[f"log_depth_pred_s{i}_b1hw"] = autograd_ops.conv_bias_act(hx, head[1])
+            prev_outputs = outputs[::-1]
+        return {k: depth_outputs[k] for k in sorted(depth_outputs, reverse=True)}
+
     def forward(self, input_features):
-        from . import ops
+        from . import autograd_ops, ops
+        if autograd_ops.grad_wanted(list(input_features), self):
+            return self._forward_train(input_features)
         prev_outputs = list(input_features)
         outputs = []
         depth_outputs = {}
