@@ -368,16 +368,18 @@ int sr_dot_volume_bwd(const float* grad_cv, int64_t g_sb, int64_t g_sd, int64_t 
  * 24-85, modules/networks.py:20-127; train.py:126-145).  Data gradients reuse the forward kernels on
  * sr_conv_flip_transpose_weights(W) (stride 2: on the sr_zero_stuff2x_nhwc'ed output gradient).
  *  sr_conv_wgrad_nhwc            d_weight [Cout,Cin,k,k] (written, not accumulated) = sum over pixels of grad_out x input
- *                                patches; fp32 MFMA, partial sums combined with fp32 atomics (order not fixed)
+ *                                patches; fp32 MFMA, per-workgroup partial slabs in `workspace`
+ *                                (sr_conv_wgrad_workspace_bytes) added in index order by a second kernel (deterministic)
  *  sr_bias_grad_nhwc             d_bias [C] = sum over pixels of grad_out
  *  sr_act_bwd                    grad * LeakyReLU'(saved output), dense arrays of n floats
  *  sr_zero_stuff2x_nhwc          out [B,Hs,Ws,C] dense: out[:, 2y, 2x] = in[:, y, x], zero elsewhere
  *  sr_upsample2x_bwd_nhwc        adjoint of sr_upsample2x_nhwc_fwd: grad_out [B,2H,2W,C] -> grad_in [B,H,W,C]
  *  sr_conv_flip_transpose_weights  out [Cin,Cout,k,k] = W[co,ci,k-1-ky,k-1-kx]
  *  sr_mul_fwd                    out = a * b (backward of depth = exp(log_depth)) */
+size_t sr_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 int sr_conv_wgrad_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* grad_out,
                        int64_t g_batch_stride, int g_pix_stride, float* d_weight, int B, int H, int W, int Cin, int Cout,
-                       int ksize, int stride, void* stream);
+                       int ksize, int stride, void* workspace, size_t workspace_bytes, void* stream);
 int sr_bias_grad_nhwc(const float* grad_out, int64_t g_batch_stride, int g_pix_stride, float* d_bias, int B, int H, int W,
                       int C, void* stream);
 int sr_act_bwd(const float* grad, const float* out_saved, float* grad_pre, int64_t n, float leaky_slope, void* stream);

@@ -63,7 +63,8 @@ SIGNATURES = {
     "sr_mlp_volume_bwd_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "sr_mlp_volume_bwd": (_i, [_p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _f, _i, _i,
                                _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _sz, _p]),
-    "sr_conv_wgrad_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "sr_conv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "sr_conv_wgrad_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "sr_bias_grad_nhwc": (_i, [_p, _i64, _i, _p, _i, _i, _i, _i, _p]),
     "sr_act_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
     "sr_zero_stuff2x_nhwc": (_i, [_p, _i64, _i, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -4,7 +4,7 @@ train.py:126-145 runs autograd through modules/layers.py:24-85 and modules/netwo
 torch.autograd is the tape (plumbing); every arithmetic step, forward and backward, is a HIP kernel:
   forward        the same MFMA kernels as inference (direct / Winograd), weights packed per call (they change every step);
   data gradient  the forward kernels on the flipped, transposed weight (stride 2: on the zero-stuffed output gradient);
-  weight / bias  csrc/sr_conv_bwd.hip (MFMA split over pixels, fp32 atomics);
+  weight / bias  csrc/sr_conv_bwd.hip (MFMA split over pixels, partial slabs + ordered reduce: deterministic);
   LeakyReLU      from the saved output; bilinear x2: its adjoint kernel.
 Gradients are pinned to the reference's own autograd (tests/golden/grad_block_*.npz, grad_cv_encoder_narrow.npz,
 grad_decoder_narrow.npz).  Not covered yet: the two encoders (no BatchNorm / InstanceNorm backward) -- DepthModel treats
@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .ops import _is_nhwc_view, _strides, as_nhwc, empty_nhwc
+from .ops import _is_nhwc_view, _strides, _workspace, as_nhwc, empty_nhwc
 
 
 def grad_wanted(*tensors_or_modules):
@@ -121,8 +121,10 @@ class _ConvBiasAct(torch.autograd.Function):
             if need_w and b > 0:
                 d_w = torch.empty_like(weight)
                 xsb, xsp = _strides(x)
+                nws = lib.sr_conv_wgrad_workspace_bytes(b, h, w, ci, co, k, s)
+                ws = _workspace(dev, "wgrad", nws)
                 _lib.check(lib.sr_conv_wgrad_nhwc(_lib.ptr(x), xsb, xsp, _lib.ptr(gp), gsb, gsp, _lib.ptr(d_w), b, h, w, ci,
-                                                  co, k, s, st), "sr_conv_wgrad_nhwc")
+                                                  co, k, s, _lib.ptr(ws), nws, st), "sr_conv_wgrad_nhwc")
             elif need_w:
                 d_w = torch.zeros_like(weight)
             if ctx.has_bias and need_b:

@@ -47,7 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // V and the epilogue slab O share the first 64 KB; the raw patch lives behind them so that the NEXT region's first
 // slab can be staged while the current region finishes (its last MFMA phase and its epilogue): 78 KB, 2 per CU.
 #define WN_VO_FLOATS (WN_V_FLOATS + WN_RAW_FLOATS > WN_O_FLOATS ? WN_V_FLOATS + WN_RAW_FLOATS : WN_O_FLOATS)
-#define WN_LDS_FLOATS (WN_VO_FLOATS + WN_RAW_FLOATS)
+#define WN_LDS_FLOATS (WN_VO_FLOATS + WN_RAW_FLOATS + 4)   // + the slab hand-over counter of the ASYNC variant
 #define WN_STAGE_ELEMS (WN_PH * WN_PW * 4)  // float4 elements per slab (720)
 #define WN_STAGE_PER_THREAD 3
 
@@ -132,9 +132,24 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) {
   return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
-template <int NT, bool VEC4, bool VOUT>
+// ASYNC: the raw-patch hand-over between the four waves goes through an LDS arrival counter instead of a workgroup
+// barrier per slab.  Every wave stores its share of slab c+1 EARLY (during its MFMAs of slab c, three steps in) and then
+// bumps the counter; a wave starts the transform of slab c+1 once all four shares have arrived -- which, unless it is a
+// whole MFMA phase ahead of the slowest wave, they long have.  Waves of a workgroup sit on four different SIMDs, each
+// shared with a wave of the co-resident workgroup, and finish their MFMA phases at different times: with a barrier per
+// slab everyone waits for the slowest one every slab (the s_memtime trace showed ~21 k of a region's 59 k cycles in
+// that wait); now they drift by up to a slab and only meet at the epilogue.  Buffer reuse is safe by construction:
+// storing slab c+1 overwrites slab c-1, and a wave can only be in the MFMAs of slab c after all waves stored slab c,
+// which each does after its own transform of slab c-1.  Same arithmetic, bit-identical results.
+template <int NT, bool VEC4, bool VOUT, bool ASYNC>
 __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned* arrivals = reinterpret_cast<unsigned*>(lds + WN_VO_FLOATS + WN_RAW_FLOATS);
+  unsigned expected = 0;   // arrivals the next asynchronously staged slab needs (4 per slab)
+  if (ASYNC) {
+    if (threadIdx.x == 0) *arrivals = 0u;
+    __syncthreads();
+  }
   float* V = lds;                     // [16][32][20]
   float* O = lds;                     // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases V and raw A)
   float* rawA = lds + WN_V_FLOATS;    // [10*18][20]  odd slabs  (inside the V/O area: dead by the epilogue)
@@ -241,6 +256,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     ++tr_region;
 #endif
     SR_TR(0);
+    bool slab_async = ASYNC && staged;   // slab 0 of this region was staged by the previous region's last chunk
     if (!staged) {
       aim(reg);
       stage_load(sl0 * 16, stg);
@@ -271,6 +287,11 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         stage_load(nxt.ks * chunks * 16, stg);
       }
 
+      if (ASYNC && slab_async) {   // all four waves' shares of this slab have landed in LDS?
+        while ((int)(__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - expected) < 0)
+          __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
       // ---- T: this wave's row of V = B^T d B, all 32 tiles x 16 channels ----
       if (!SR_WN_DBG(2)) {
         const float* raw = (ch & 1) ? rawA : rawB;
@@ -329,10 +350,22 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         for (int n = 0; n < NT; ++n)
           acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].w, b_f[cbuf][n].w, acc[s >> 1][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (ASYNC && s == 2 && (more || has_next)) {   // early hand-over of the next slab (see the kernel comment)
+          stage_store(stg, (ch & 1) ? rawB : rawA);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          expected += 4;
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (ch < 5) SR_TR(3 + 2 * ch);   // this wave's MFMAs issued (before the barrier)
-      if (more || has_next) stage_store(stg, (ch & 1) ? rawB : rawA);
-      __syncthreads();
+      if (!ASYNC) {
+        if (more || has_next) stage_store(stg, (ch & 1) ? rawB : rawA);
+        __syncthreads();
+      } else {
+        slab_async = true;
+        if (!more) __syncthreads();   // the epilogue's exchange slab aliases every wave's V and raw A
+      }
     }
     SR_TR(12);
 
@@ -606,8 +639,9 @@ extern "C" const char* sr_wino_kernel_name(int B, int H, int W, int Cin, int Cou
   static thread_local char buf[64];
   (void)Cin;
   const int vin = aligned_in != 0, vout = vin && aligned_out;
-  snprintf(buf, sizeof(buf), "sr_wino_kernel<%d, %s, %s>", sr_wino_plan(B, H, W, Cin, Cout, vout != 0).nt,
-           vin ? "true" : "false", vout ? "true" : "false");
+  const char* am = getenv("SR_WINO_ASYNC");
+  snprintf(buf, sizeof(buf), "sr_wino_kernel<%d, %s, %s, %s>", sr_wino_plan(B, H, W, Cin, Cout, vout != 0).nt,
+           vin ? "true" : "false", vout ? "true" : "false", (am && atoi(am) != 0) ? "true" : "false");
   return buf;
 }
 
@@ -658,12 +692,21 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   (void)hipMemsetAsync(trace_buf, 0, trace_n * 8, stream);
   p.trace = trace_buf;
 #endif
-#define SR_WINO_LAUNCH(NTV, V4, VO)                                                                               \
+  // SR_WINO_ASYNC=1 selects the counter-based slab hand-over (read per call so a test can flip it).  Measured r02:
+  // bit-identical and NOT faster (64 -> 64 @ 8x240x320: 270 vs 262 us) -- the per-slab barrier is not what limits the
+  // kernel, so the simpler barrier form stays the default and this one an ablation.
+  const char* async_env = getenv("SR_WINO_ASYNC");
+  const int async_mode = async_env ? atoi(async_env) : 0;
+#define SR_WINO_LAUNCH1(NTV, V4, VO, AS)                                                                          \
   {                                                                                                               \
-    hipError_t e = hipFuncSetAttribute((const void*)sr_wino_kernel<NTV, V4, VO>,                                  \
+    hipError_t e = hipFuncSetAttribute((const void*)sr_wino_kernel<NTV, V4, VO, AS>,                              \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
     if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
-    hipLaunchKernelGGL((sr_wino_kernel<NTV, V4, VO>), dim3(blocks), dim3(256), lds, stream, p);                   \
+    hipLaunchKernelGGL((sr_wino_kernel<NTV, V4, VO, AS>), dim3(blocks), dim3(256), lds, stream, p);               \
+  }
+#define SR_WINO_LAUNCH(NTV, V4, VO)                                                                               \
+  {                                                                                                               \
+    if (async_mode) SR_WINO_LAUNCH1(NTV, V4, VO, true) else SR_WINO_LAUNCH1(NTV, V4, VO, false)                   \
   }
   if (nt == 2 && vout) SR_WINO_LAUNCH(2, true, true)
   else if (nt == 2 && p.vec4) SR_WINO_LAUNCH(2, true, false)
@@ -672,6 +715,7 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   else if (p.vec4) SR_WINO_LAUNCH(1, true, false)
   else SR_WINO_LAUNCH(1, false, false)
 #undef SR_WINO_LAUNCH
+#undef SR_WINO_LAUNCH1
 #ifdef SR_WINO_TRACE
   {
     const char* path = getenv("SR_WINO_TRACE_FILE");

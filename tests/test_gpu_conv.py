@@ -151,3 +151,27 @@ def test_conv_random_shapes_and_options():
         assert tuple(y.shape) == ref.shape, (case, tuple(y.shape), ref.shape)
         assert_close(y, ref, tol=2e-5, what=f"case {case}: B{b} {ci}->{co} k{k} s{stride} {h}x{w} bias={use_bias} "
                                             f"res={use_res} leaky={leaky}")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 60, 80), (1, 192, 64, 40, 48), (3, 48, 32, 17, 29), (1, 384, 384, 15, 20),
+                                   (8, 64, 64, 120, 160)])
+def test_winograd_async_handover_is_bit_identical(shape, monkeypatch):
+    """The counter-based slab hand-over of sr_wino_kernel<..., ASYNC = true> (waves of a workgroup drift instead of
+    meeting at a barrier per slab) computes exactly what the barrier-per-slab variant computes: many regions per
+    workgroup (chained staging), odd and even slab counts, split-K plans, residual + LeakyReLU epilogue."""
+    B, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(ci + co + h)
+    conv = torch.nn.Conv2d(ci, co, 3, padding=1)
+    x = torch.randn((B, ci, h, w), generator=g).to(DEV)
+    res = torch.randn((B, co, h, w), generator=g).to(DEV)
+    conv = conv.to(DEV)
+    monkeypatch.setenv("SR_CONV_WINO", "2")
+    outs = []
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("SR_WINO_ASYNC", mode)
+        with torch.inference_mode():
+            outs.append(ops.conv2d(x, conv, residual=res, leaky=0.2).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, conv.weight, conv.bias, padding=1) + res, 0.2)
+    assert rel_err(outs[1], ref) < 2e-5
