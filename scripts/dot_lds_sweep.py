@@ -70,9 +70,8 @@ def main():
     if os.environ.get("SR_SWEEP_CHILD"):
         return child()
     variants = [{"SR_DOT_LDS": "0"}]
-    for cap, g in (("634", "4"), ("634", "2"), ("634", "0"), ("770", "4"), ("770", "8")):
+    for cap, g in (("634", "4"), ("634", "2"), ("506", "2"), ("506", "4")):
         variants.append({"SR_DOT_LDS": "1", "SR_DOT_LDS_CAP": cap, "SR_DOT_LDS_G": g})
-    variants.append({"SR_DOT_LDS": "1", "SR_DOT_LDS_CAP": "634", "SR_DOT_LDS_G": "4", "SR_DOT_LDS_CULL": "0"})
     for v in variants:
         env = dict(os.environ, SR_SWEEP_CHILD="1", **v)
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True,

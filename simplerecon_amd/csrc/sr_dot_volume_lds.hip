@@ -474,6 +474,7 @@ int sr_launch_dot_volume_lds(const SrDotParams& p, unsigned long long* keys, hip
   }
   switch (cap) {
     case 770: SR_LDS_CASE(770, 3) break;
+    case 506: SR_LDS_CASE(506, 5) break;
     default: SR_LDS_CASE(634, 4) break;
   }
 #undef SR_LDS_CASE

@@ -73,6 +73,7 @@ struct SrWinoParams {
   // split-K: a work item covers 1/ksplit of the input slabs and stores its raw partial output (no bias / residual /
   // activation) to part + ks * part_stride (dense channels-last [B, H*W, Cout]); sr_wino_reduce_kernel finishes.
   int ksplit; float* part; int64_t part_stride;
+  int stagger;  // shader cycles the second workgroup of a CU waits before its first region (0 = off)
 #ifdef SR_WINO_TRACE
   unsigned long long* trace;  // [blocks][SR_TR_REGIONS][SR_TR_EVENTS] shader-clock stamps (debug builds only)
 #endif
@@ -123,6 +124,10 @@ __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restri
 
 // float4 add / sub as two packed fp32 pairs (v_pk_add_f32): the transforms are pure add / sub work
 typedef float wn_f2 __attribute__((ext_vector_type(2)));
+#ifdef SR_WINO_NOPK   // ablation: plain fp32 adds instead of v_pk_add_f32 (packed fp32 VALU beside MFMAs)
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+#else
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) {
   const wn_f2 lo = wn_f2{a.x, a.y} - wn_f2{b.x, b.y}, hi = wn_f2{a.z, a.w} - wn_f2{b.z, b.w};
   return make_float4(lo.x, lo.y, hi.x, hi.y);
@@ -131,6 +136,7 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) {
   const wn_f2 lo = wn_f2{a.x, a.y} + wn_f2{b.x, b.y}, hi = wn_f2{a.z, a.w} + wn_f2{b.z, b.w};
   return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
+#endif
 
 // ASYNC: the raw-patch hand-over between the four waves goes through an LDS arrival counter instead of a workgroup
 // barrier per slab.  Every wave stores its share of slab c+1 EARLY (during its MFMAs of slab c, three steps in) and then
@@ -148,6 +154,22 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
   unsigned expected = 0;   // arrivals the next asynchronously staged slab needs (4 per slab)
   if (ASYNC) {
     if (threadIdx.x == 0) *arrivals = 0u;
+    __syncthreads();
+  }
+  // Phase stagger.  The two workgroups of a CU start together, do the same work and share each SIMD's matrix pipe
+  // fairly, so they stay in LOCKSTEP: both transform, both multiply (at half rate each), both run their epilogue --
+  // the pipe idles whenever they are in a non-MFMA phase together (a two-workgroup pipe-sharing model reproduces the
+  // measured 59 k-cycle region period from the phase lengths of the s_memtime trace).  Delaying the workgroup in the
+  // second wave slot of the SIMDs once, by about an epilogue + a transform, puts its non-MFMA phases under the other's
+  // MFMAs; the offset then persists (same region length for both).
+  if (p.stagger > 0) {
+    if (threadIdx.x == 0) {
+      const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u;  // HW_ID.WAVE_ID bit 0
+      if (slot) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)p.stagger) __builtin_amdgcn_s_sleep(32);
+      }
+    }
     __syncthreads();
   }
   float* V = lds;                     // [16][32][20]
@@ -304,10 +326,15 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
           for (int c = 0; c < 4; ++c) {
             const float4 da = *reinterpret_cast<const float4*>(&raw[base + (t_ra * WN_PW + c) * WN_ROW]);
             const float4 db = *reinterpret_cast<const float4*>(&raw[base + (t_rb * WN_PW + c) * WN_ROW]);
+#ifdef SR_WINO_NOPK
+            wv[c] = make_float4(fmaf(t_sign, db.x, da.x), fmaf(t_sign, db.y, da.y), fmaf(t_sign, db.z, da.z),
+                                fmaf(t_sign, db.w, da.w));
+#else
             const wn_f2 sg = {t_sign, t_sign};
             const wn_f2 lo = __builtin_elementwise_fma(sg, wn_f2{db.x, db.y}, wn_f2{da.x, da.y});
             const wn_f2 hi = __builtin_elementwise_fma(sg, wn_f2{db.z, db.w}, wn_f2{da.z, da.w});
             wv[c] = make_float4(lo.x, lo.y, hi.x, hi.y);
+#endif
           }
           float* vrow = V + ((4 * wave) * 32 + tt) * WN_ROW + 4 * tq;
           *reinterpret_cast<float4*>(vrow + 0 * 32 * WN_ROW) = f4sub(wv[0], wv[2]);
@@ -680,6 +707,7 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   p.co_blocks = p.Co_pad / (32 * nt);
   p.total = p.regions_x * p.regions_y * p.co_blocks * B * p.ksplit;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_WINO_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
+  { const char* e = getenv("SR_WINO_STAGGER"); p.stagger = e ? atoi(e) : 0; }
   hipStream_t stream = (hipStream_t)stream_;
   int blocks = sr_wino_num_cus() * 2;
   if (blocks > p.total) blocks = p.total;
