@@ -710,6 +710,7 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   { const char* e = getenv("SR_WINO_STAGGER"); p.stagger = e ? atoi(e) : 0; }
   hipStream_t stream = (hipStream_t)stream_;
   int blocks = sr_wino_num_cus() * 2;
+  { const char* e = getenv("SR_WINO_WG_PER_CU"); if (e && atoi(e) == 1) blocks = sr_wino_num_cus(); }  // ablation
   if (blocks > p.total) blocks = p.total;
   const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
 #ifdef SR_WINO_TRACE
