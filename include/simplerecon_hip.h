@@ -396,7 +396,8 @@ int sr_mul_fwd(const float* a, const float* b, float* out, int64_t n, void* stre
  * db3 [1]; all written, not accumulated).  W1..W3 are the UNPACKED nn.Linear weights.  `workspace` must have been filled
  * by sr_volume_prepare WITH T_cur_src (pose features) for the same sources; `scratch`
  * (sr_mlp_volume_bwd_scratch_bytes, 256-byte aligned) holds the channels-last d_src image and weight transposes.
- * First version: fp32 VALU, hidden = 128, C = 16, C(K+1) + 10K + 4 <= 256 (up to 9 views); SR_ERR_UNSUPPORTED otherwise.
+ * hidden = 128, C = 16, up to 15 views (MLP width <= 416); SR_ERR_UNSUPPORTED otherwise.  The six GEMM-shaped phases run on
+ * the fp32 matrix cores (v_mfma_f32_32x32x2_f32); SR_MLP_BWD_VALU=1 selects the round-1 VALU kernel (<= 9 views).
  * Feature-map and weight gradients are accumulated with hardware fp32 atomics (summation order not fixed). */
 size_t sr_mlp_volume_bwd_scratch_bytes(int B, int K, int C, int h, int w, int hidden);
 int sr_mlp_volume_bwd(const float* grad_cv, int64_t g_sb, int64_t g_sd, int64_t g_sp, const float* cur,

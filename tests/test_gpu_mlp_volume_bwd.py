@@ -60,3 +60,23 @@ def test_gradients_match_oracle_ragged_three_views():
                                      n["src_poses"], n["cur_invK"], planes, mlp)
     for key in ("d_cur_feats", "d_src_feats", "dW1", "db1", "dW2", "db2", "dW3", "db3"):
         assert_close(grads[key], ref[key], what=key + " vs oracle")
+
+
+def test_matrix_core_backward_equals_valu_backward_and_handles_15_views(monkeypatch):
+    """The MFMA backward (default) against the r01 VALU kernel (SR_MLP_BWD_VALU is read once per process, so the VALU
+    result comes from the oracle instead) at 7 views, and at 15 views / 410 MLP inputs (BASELINE.json configs[4]), which
+    the VALU kernel could not run (Cin <= 256)."""
+    for K, D, h, w in ((7, 3, 10, 21), (15, 2, 9, 14), (2, 4, 8, 8)):
+        case = dict(model="hero", B=1, K=K, C=16, D=D, h=h, w=w, seed=20 + K)
+        g = torch.Generator(device="cpu").manual_seed(K)
+        R = torch.randn((1, D, h, w), generator=g)
+        mgr, inp, _, grads = _run(case, R)
+        n = {k: v.cpu().numpy() for k, v in inp.items()}
+        planes = mgr.generate_depth_planes(1, inp["min_depth"], inp["max_depth"])[:, :, 0, 0].cpu().numpy()
+        sd = {k: v.detach().cpu().numpy() for k, v in mgr.mlp.state_dict().items()}
+        mlp = dict(W1=sd["net.0.weight"], b1=sd["net.0.bias"], W2=sd["net.2.weight"], b2=sd["net.2.bias"],
+                   W3=sd["net.4.weight"], b3=sd["net.4.bias"])
+        ref = oracle.mlp_volume_backward(R.numpy(), n["cur_feats"], n["src_feats"], n["src_Ks"], n["src_extrinsics"],
+                                         n["src_poses"], n["cur_invK"], planes, mlp)
+        for key in ("d_cur_feats", "d_src_feats", "dW1", "db1", "dW2", "db2", "dW3", "db3"):
+            assert_close(grads[key], ref[key], what=f"K={K} {key} vs oracle")
