@@ -34,10 +34,17 @@ struct SrDotBwdParams {
 
 template <int C>
 __global__ __launch_bounds__(256) void sr_dot_volume_bwd_kernel(SrDotBwdParams p) {
+  // wave-private LDS: tap records of the current (plane, view) [64 pixels][4 taps] (texel, weight * g * mask) and the
+  // wave's reference features [64][C] -- for the scatter with lane = channel (see below)
+  __shared__ int s_off[4][64 * 4];
+  __shared__ float s_wt[4][64 * 4];
+  __shared__ float s_cur[4][64 * C];
   const int b = blockIdx.y;
   const int N = p.h * p.w;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  if (pix >= N) return;   // no barriers below
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pix_raw = blockIdx.x * 256 + threadIdx.x;
+  const bool active = pix_raw < N;
+  const int pix = active ? pix_raw : N - 1;
   const int y = pix / p.w, x = pix - y * p.w;
 
   float cur[C], dcur[C];
@@ -45,6 +52,7 @@ __global__ __launch_bounds__(256) void sr_dot_volume_bwd_kernel(SrDotBwdParams p
   for (int c = 0; c < C; ++c) {
     cur[c] = p.cur[((size_t)b * C + c) * N + pix];
     dcur[c] = 0.0f;
+    s_cur[wave][lane * C + c] = cur[c];
   }
   float r0, r1, r2;
   {
@@ -60,10 +68,12 @@ __global__ __launch_bounds__(256) void sr_dot_volume_bwd_kernel(SrDotBwdParams p
   float* dsrc_b = p.d_src_nhwc ? p.d_src_nhwc + (size_t)b * p.K * N * C : nullptr;
   const float* planes = p.planes.ptr + b * p.planes.sb + y * p.planes.sy + x * p.planes.sx;
   const float* gcv = p.grad_cv + b * p.g_sb + (int64_t)pix * p.g_sp;
+  constexpr int UNITS_PER_INSTR = 64 / C;          // (pixel, tap) units one wave instruction scatters
+  const int sc = lane % C, su = lane / C;
 
   for (int j = 0; j < p.D; ++j) {
     const float d = planes[j * p.planes.sd];
-    const float g = gcv[j * p.g_sd];
+    const float g = active ? gcv[j * p.g_sd] : 0.0f;
     float X0, X1, X2;
     {
 #pragma clang fp contract(off)
@@ -74,15 +84,13 @@ __global__ __launch_bounds__(256) void sr_dot_volume_bwd_kernel(SrDotBwdParams p
       SrSample s;
       sr_project_sample(geom_b + k * SR_GEOM_STRIDE, X0, X1, X2, p.h, p.w, p.inv_w, p.inv_h, s);
       const float gm = (s.zp > 0.0f) ? g : 0.0f;   // mask_k (cost_volume.py:231-232)
-      if (gm == 0.0f) continue;
       const float* img = src_b + (size_t)k * N * C;
-      float* dimg = dsrc_b ? dsrc_b + (size_t)k * N * C : nullptr;
       const float wt[4] = {s.w_nw * gm, s.w_ne * gm, s.w_sw * gm, s.w_se * gm};
       const int ot[4] = {s.o_nw, s.o_ne, s.o_sw, s.o_se};
+      if (p.d_cur) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (wt[t] == 0.0f) continue;   // out-of-image taps (zero padding) and zero gradients
-        if (p.d_cur) {
+        for (int t = 0; t < 4; ++t) {
+          if (wt[t] == 0.0f) continue;   // out-of-image taps (zero padding), masked views and zero gradients
           const float4* tp = reinterpret_cast<const float4*>(img + (size_t)ot[t] * C);
 #pragma unroll
           for (int q = 0; q < C / 4; ++q) {
@@ -93,15 +101,35 @@ __global__ __launch_bounds__(256) void sr_dot_volume_bwd_kernel(SrDotBwdParams p
             dcur[4 * q + 3] = fmaf(wt[t], v.w, dcur[4 * q + 3]);
           }
         }
-        if (dimg) {
-          float* dp = dimg + (size_t)ot[t] * C;
+      }
+      if (dsrc_b) {
+        // scatter d_src[tap] += wt * cur with lane = channel: the C lanes of a (pixel, tap) unit add to the contiguous
+        // 4*C bytes of one texel, so a wave instruction touches 64 / C texels instead of 64 (the lane = pixel form did;
+        // the scatter's atomics are what bounds this kernel).  Tap records travel through wave-private LDS.
+        if (__ballot((wt[0] != 0.0f) | (wt[1] != 0.0f) | (wt[2] != 0.0f) | (wt[3] != 0.0f)) == 0) continue;
 #pragma unroll
-          for (int c = 0; c < C; ++c) unsafeAtomicAdd(dp + c, wt[t] * cur[c]);
+        for (int t = 0; t < 4; ++t) {
+          s_off[wave][lane * 4 + t] = ot[t];
+          s_wt[wave][lane * 4 + t] = wt[t];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* dimg = dsrc_b + (size_t)k * N * C;
+#pragma unroll 4
+        for (int unit0 = 0; unit0 < 256; unit0 += UNITS_PER_INSTR) {
+          const int unit = unit0 + su;                         // (pixel, tap) = (unit >> 2, unit & 3)
+          if (su < UNITS_PER_INSTR && unit < 256) {            // (C = 12, 24: the last lanes of a wave sit out)
+            const float wq = s_wt[wave][unit];
+            if (wq != 0.0f)
+              unsafeAtomicAdd(dimg + (size_t)s_off[wave][unit] * C + sc, wq * s_cur[wave][(unit >> 2) * C + sc]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();   // the records are overwritten by the next (plane, view)
       }
     }
   }
-  if (p.d_cur) {
+  if (p.d_cur && active) {
 #pragma unroll
     for (int c = 0; c < C; ++c) p.d_cur[((size_t)b * C + c) * N + pix] = dcur[c];
   }

@@ -340,6 +340,43 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_bwd_kernel(SrMlpBwdParam
 // Work per 32-pixel plane tile: ~2000 MFMAs (= 125 k MFMA cycles per workgroup) against ~0.3 MB of weights from L2.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// acc += A[32 x 2*ksteps] . B[2*ksteps x 32] on v_mfma_f32_32x32x2_f32: A from LDS (ap[2*ks]), B streamed from global / L2
+// (bp[2*ks*bstride]) through a double-buffered batch of BK fragments, so that ~BK * 64 matrix-pipe cycles cover the L2
+// latency of the next batch.  ACT: A = lrelu(A).
+template <bool ACT, int BK = 16>
+__device__ __forceinline__ f32x16 sr_gemm_lds_l2(f32x16 acc, const float* __restrict__ ap, const float* __restrict__ bp,
+                                                 size_t bstride, int ksteps, float slope) {
+  const int nb = ksteps / BK;
+  float cur[BK], nxt[BK];
+  if (nb > 0) {
+#pragma unroll
+    for (int u = 0; u < BK; ++u) cur[u] = bp[(size_t)2 * u * bstride];
+  }
+#pragma unroll 1
+  for (int kb = 0; kb < nb; ++kb) {
+    const bool more = kb + 1 < nb;
+    const float* bn = bp + (size_t)2 * (more ? (kb + 1) * BK : 0) * bstride;   // (a valid address when nothing follows)
+#pragma unroll
+    for (int u = 0; u < BK; ++u) nxt[u] = bn[(size_t)2 * u * bstride];
+    const float* aq = ap + 2 * kb * BK;
+#pragma unroll
+    for (int u = 0; u < BK; ++u) {
+      float a = aq[2 * u];
+      if (ACT) a = a > 0.0f ? a : a * slope;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cur[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < BK; ++u) cur[u] = nxt[u];
+  }
+#pragma unroll 1
+  for (int ks = nb * BK; ks < ksteps; ++ks) {   // tail (Cin / 2 is not a multiple of the batch)
+    float a = ap[2 * ks];
+    if (ACT) a = a > 0.0f ? a : a * slope;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(size_t)2 * ks * bstride], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 template <int C, int NT1>
 __global__ __launch_bounds__(256, 1) void sr_mlp_volume_bwd_mfma_kernel(SrMlpBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -476,9 +513,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_bwd_mfma_kernel(SrMlpBwd
         for (int r = 0; r < 16; ++r) acc[r] = bb;
         const float* ap = F + i * FS + kk;
         const float* bp = p.W1T + (size_t)kk * HID + 32 * wave + i;
-#pragma unroll 8
-        for (int ks = 0; ks < Cin / 2; ++ks)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[(size_t)2 * ks * HID], acc, 0, 0, 0);
+        acc = sr_gemm_lds_l2<false>(acc, ap, bp, HID, Cin / 2, slope);
 #pragma unroll
         for (int r = 0; r < 16; ++r) Z1[((r & 3) + 8 * (r >> 2) + 4 * kk) * ZS + 32 * wave + i] = acc[r];
       }
@@ -491,9 +526,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_bwd_mfma_kernel(SrMlpBwd
         for (int r = 0; r < 16; ++r) acc[r] = bb;
         const float* ap = Z1 + i * ZS + kk;
         const float* bp = p.W2T + (size_t)kk * HID + 32 * wave + i;
-#pragma unroll 8
-        for (int ks = 0; ks < HID / 2; ++ks)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lrelu(ap[2 * ks], slope), bp[(size_t)2 * ks * HID], acc, 0, 0, 0);
+        acc = sr_gemm_lds_l2<true>(acc, ap, bp, HID, HID / 2, slope);
 #pragma unroll
         for (int r = 0; r < 16; ++r) Z2[((r & 3) + 8 * (r >> 2) + 4 * kk) * ZS + 32 * wave + i] = acc[r];
       }
@@ -531,9 +564,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_bwd_mfma_kernel(SrMlpBwd
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* ap = Z2 + i * ZS + kk;
         const float* bp = p.W2 + (size_t)kk * HID + 32 * wave + i;
-#pragma unroll 8
-        for (int ks = 0; ks < HID / 2; ++ks)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[(size_t)2 * ks * HID], acc, 0, 0, 0);
+        acc = sr_gemm_lds_l2<false>(acc, ap, bp, HID, HID / 2, slope);
         __syncthreads();   // phase 5 of every wave has read its z1 values
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -562,9 +593,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_bwd_mfma_kernel(SrMlpBwd
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* ap = Z1 + i * ZS + kk;
         const float* bp = p.W1 + (size_t)kk * Cin + col;
-#pragma unroll 8
-        for (int ks = 0; ks < HID / 2; ++ks)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[(size_t)2 * ks * Cin], acc, 0, 0, 0);
+        acc = sr_gemm_lds_l2<false>(acc, ap, bp, (size_t)Cin, HID / 2, slope);
         if (q < NEED) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) DF[((r & 3) + 8 * (r >> 2) + 4 * kk) * DFS + q] = acc[r];
@@ -572,27 +601,30 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_bwd_mfma_kernel(SrMlpBwd
       }
       __syncthreads();
       // ---- 9: back through dot product and bilinear sampling ----------------------------------------------
+      // (a) d_cur: a thread owns (pixel, channel) pairs -- no atomics
+      for (int e = t; e < P * C; e += 256) {
+        const int q = e / C, c = e - q * C;
+        const float* f = F + q * FS;
+        const float* df = DF + q * DFS;
+        float s = df[o_cur + c];
+        for (int k = 0; k < K; ++k) s = fmaf(df[o_mask + k] * f[o_mask + k], f[k * C + c], s);   // ddot_k * warped[k][c]
+        DCUR[e] += s;
+      }
+      // (b) d_src scatter with lane = channel: the 16 lanes of a (pixel, view, tap) unit add to the 64 contiguous bytes
+      // of one texel, a wave instruction touches 4 texels (the r01 mapping -- lane = pixel -- touched 32 cache lines
+      // per atomic instruction; the scatter's 4.4 G atomics per batch-8 step are what bounds this kernel)
       {
-        const float* f = F + pp * FS;
-        const float* df = DF + pp * DFS;
-        if (kq == 0) {
-#pragma unroll
-          for (int c = 0; c < C; ++c) atomicAdd(&DCUR[pp * C + c], df[o_cur + c]);
-        }
-        for (int k = kq; k < K; k += 8) {
-          const float ddot = df[o_mask + k] * f[o_mask + k];     // DF column o_mask + k holds d f[o_dot + k]
-          float* dimg = dsrc_b + (size_t)k * N * C;
-#pragma unroll
-          for (int c = 0; c < C; ++c) {
-            const float dwarp = fmaf(ddot, CUR[pp * C + c], df[k * C + c]);
-            atomicAdd(&DCUR[pp * C + c], ddot * f[k * C + c]);
-            if (active) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float wq = TW[(pp * K + k) * 4 + q];
-                if (wq != 0.0f) unsafeAtomicAdd(dimg + (size_t)TI[(pp * K + k) * 4 + q] * C + c, wq * dwarp);
-              }
-            }
+        const int c = t & (C - 1);
+        for (int un = t / C; un < P * K * 4; un += 256 / C) {
+          const int q = un & 3, pk = un >> 2;          // tap, (pixel, view)
+          const int px = pk / K, k = pk - px * K;
+          const float wq = TW[pk * 4 + q];
+          if (wq != 0.0f && pix0 + px < N) {
+            const float* f = F + px * FS;
+            const float* df = DF + px * DFS;
+            const float ddot = df[o_mask + k] * f[o_mask + k];     // DF column o_mask + k holds d f[o_dot + k]
+            const float dwarp = fmaf(ddot, CUR[px * C + c], df[k * C + c]);
+            unsafeAtomicAdd(dsrc_b + ((size_t)k * N + TI[pk * 4 + q]) * C + c, wq * dwarp);
           }
         }
       }
