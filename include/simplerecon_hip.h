@@ -70,6 +70,19 @@ int sr_dot_volume_sweep(const float* cur, const float* invK_cur, const float* pl
                         float* out_lowest, uint8_t* out_mask, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* 1x1 convolution over a dense channels-last map as a plain library GEMM (hipBLASLt, fp32 in / out / accumulate):
+ * out[m][co] = act( sum_ci in[m][ci] * weight[co][ci] + bias[co] [+ residual[m][co]] ) for the M = B*H*W pixels of a map
+ * whose pixels are `*_pix_stride` floats apart (channel slices of wider buffers are fine).  `weight` is the UNPACKED
+ * [Cout][Cin] nn.Conv2d weight (eval-mode BatchNorm folded by the caller); act 0 none, 1 SiLU, 2 ReLU (a residual is added
+ * BEFORE the activation).  Replaces nn.Conv2d(k=1) + BatchNorm + SiLU of the image-prior encoder's MBConv blocks
+ * (reference depth_model.py:110-116) and the 1x1 skip convs of BasicBlock (layers.py:58-65) where this is faster than
+ * sr_conv2d_nhwc_fwd.  `workspace`: sr_gemm1x1_workspace_bytes(), 256-byte aligned.  SR_ERR_UNSUPPORTED when hipBLASLt
+ * offers no algorithm for the shape (use sr_conv2d_nhwc_fwd then). */
+size_t sr_gemm1x1_workspace_bytes(void);
+int sr_gemm1x1_nhwc_fwd(const float* in, int in_pix_stride, const float* weight, const float* bias, const float* residual,
+                        int res_pix_stride, float* out, int out_pix_stride, int M, int Cin, int Cout, int act,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Standalone forms of the reference's small geometry helpers (utils/geometry_utils.py) for callers outside the fused
  * sweeps; same operation order as the sweeps' internal arithmetic (FP contraction off).
  *  sr_backproject_fwd   BackprojectDepth.forward (:51-59): depth [B,h*w], invK [B,16] -> points [B,4,h*w]

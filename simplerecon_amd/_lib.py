@@ -29,6 +29,8 @@ SIGNATURES = {
                                  _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
     "sr_dot_volume_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i,
                                _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
+    "sr_gemm1x1_workspace_bytes": (_sz, []),
+    "sr_gemm1x1_nhwc_fwd": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "sr_backproject_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "sr_project3d_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "sr_pose_distance_fwd": (_i, [_p, _p, _i, _p]),

@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
             list(ex.map(lambda s: _compile(s, verbose), todo))
     objs = [os.path.join(BUILD, os.path.basename(s) + ".o") for s in srcs]
     if force or todo or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhipblaslt"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -65,7 +65,7 @@ class EdgeResidual(nn.Module):
 
     def forward(self, x):
         t = ops.conv2d(x, self.conv_exp, bn=self.bn1, act="silu", tf_same=True)
-        return ops.conv2d(t, self.conv_pwl, bn=self.bn2, residual=x if self.has_skip else None)
+        return ops.conv2d(t, self.conv_pwl, bn=self.bn2, residual=x if self.has_skip else None, library_gemm=True)
 
 
 class SqueezeExcite(nn.Module):
@@ -88,10 +88,10 @@ class InvertedResidual(nn.Module):
         self.has_skip = stride == 1 and cin == cout
 
     def forward(self, x):
-        t = ops.conv2d(x, self.conv_pw, bn=self.bn1, act="silu")
+        t = ops.conv2d(x, self.conv_pw, bn=self.bn1, act="silu", library_gemm=True)
         d, pool = ops.dwconv3x3(t, self.conv_dw, bn=self.bn2, act="silu", tf_same=True, want_pool=True)
         ops.se_scale_(d, pool, self.se.conv_reduce, self.se.conv_expand)
-        return ops.conv2d(d, self.conv_pwl, bn=self.bn3, residual=x if self.has_skip else None)
+        return ops.conv2d(d, self.conv_pwl, bn=self.bn3, residual=x if self.has_skip else None, library_gemm=True)
 
 
 class _FeatureInfo:

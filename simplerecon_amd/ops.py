@@ -5,6 +5,7 @@ A "channels-last view" is a logically [B,C,H,W] torch tensor whose memory is [B,
 this tensor occupying channels [c0, c0+C) of each pixel -- either a dense channels_last tensor or
 a channel slice `buf[:, c0:c1]` of one.  Kernels take (pointer, batch stride, pixel stride)."""
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -172,6 +173,25 @@ def packed_weight(conv: nn.Conv2d, bn=None):
     return packed, bias
 
 
+_GEMM_W = weakref.WeakKeyDictionary()  # nn.Conv2d (1x1) -> (state key, [Cout, Cin] weight with BN folded, bias)
+USE_GEMM_1X1 = os.environ.get("SR_CONV1X1_GEMM", "1") != "0"   # 0: every 1x1 conv on the implicit-GEMM HIP kernel
+GEMM_1X1_MIN_PIXELS = 1024
+
+
+def gemm_weight(conv: nn.Conv2d, bn=None):
+    """([Cout, Cin] weight, bias) of a 1x1 conv with the eval-mode BatchNorm folded in, for sr_gemm1x1_nhwc_fwd."""
+    _lib.require_device_f32("conv weight", conv.weight)
+    key = _state_key(conv, bn)
+    hit = _GEMM_W.get(conv)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    w, bias = _effective_weight(conv, bn)
+    w2d = w.reshape(w.shape[0], w.shape[1]).contiguous()
+    bias = bias.contiguous() if bias is not None else None
+    _GEMM_W[conv] = (key, w2d, bias)
+    return w2d, bias
+
+
 _PACKED_LIN = weakref.WeakKeyDictionary()  # nn.Linear -> (weight version, data_ptr, packed tensor)
 
 
@@ -233,11 +253,13 @@ def packed_wino_weight(conv: nn.Conv2d, bn=None):
     return packed, bias
 
 
-def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act=None, tf_same=False):
+def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act=None, tf_same=False, library_gemm=False):
     """act(bn(conv(x) + bias) [+ residual]) with nn.Conv2d semantics (zero or replicate padding); `bn` is an
     eval-mode BatchNorm2d folded into weight and bias.  `leaky` = LeakyReLU slope, or act="silu".  tf_same=True
-    replaces the module's symmetric padding by TensorFlow-"SAME" padding (tf_same_pads).  Returns a channels-last
-    view."""
+    replaces the module's symmetric padding by TensorFlow-"SAME" padding (tf_same_pads).  library_gemm=True lets a 1x1
+    conv over a dense map run as a hipBLASLt GEMM (faster on the MBConv shapes; its algorithm choice depends on the number
+    of pixels, so results are no longer bitwise independent of the batch size -- callers that promise that keep the
+    default).  Returns a channels-last view."""
     _lib.refuse_autograd(x, conv.weight)
     x = as_nhwc(x, "conv input")
     b, ci, h, w = x.shape
@@ -261,7 +283,6 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
     if padded and replicate:
         raise _lib.HipLibraryError("explicit padding is implemented for zero padding only")
     use_wino = (not replicate) and (not padded) and bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, s))
-    wp, bias = packed_wino_weight(conv, bn) if use_wino else packed_weight(conv, bn)
     if residual is not None:
         residual = as_nhwc(residual, "residual")
         if tuple(residual.shape) != (b, co, ho, wo):
@@ -282,6 +303,32 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
             b, h, w, ho, wo = 1, m // fw, fw, m // fw, fw
             isb, osb, rsb = m * ci, m * co, (m * co if residual is not None else 0)
     prof = PROFILE
+    # 1x1 convs over dense maps are plain GEMMs: hipBLASLt (north star: "rocBLAS/MFMA only where it is a dense im2col
+    # GEMM") is 1.25-1.75x faster than the implicit-GEMM kernel on the MBConv shapes (scripts/gemm_probe.py)
+    if library_gemm and k == 1 and s == 1 and not padded and not replicate and USE_GEMM_1X1 and \
+            b * h * w >= GEMM_1X1_MIN_PIXELS:
+        gact = 0 if (leaky is None and act is None) else 1 if act == "silu" else 2 if (act is None and leaky == 0.0) else -1
+        dense = (isb == h * w * isp or b == 1) and (osb == ho * wo * osp or b == 1) and \
+            (residual is None or rsb == ho * wo * rsp or b == 1)
+        if gact >= 0 and dense:
+            w2d, gbias = gemm_weight(conv, bn)
+            ws = _workspace(x.device, "gemm1x1", lib.sr_gemm1x1_workspace_bytes())
+            with torch.cuda.device(x.device):
+                if prof is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                rc = lib.sr_gemm1x1_nhwc_fwd(_lib.ptr(x), isp, _lib.ptr(w2d), _lib.ptr(gbias), _lib.ptr(residual), rsp,
+                                             _lib.ptr(out), osp, b * h * w, ci, co, gact, _lib.ptr(ws), ws.numel() * 4,
+                                             _lib.stream_ptr(x.device))
+                if prof is not None and rc == 0:
+                    ev1.record()
+                    prof.append(("hipBLASLt fp32 GEMM (1x1 conv)", 2.0 * b * ho * wo * co * ci, ev0, ev1,
+                                 (b, ci, h, w, co, k, s, ho, wo, residual is not None), None))
+            if rc == 0:
+                return out
+            if rc != 2:   # SR_ERR_UNSUPPORTED: no library algorithm for this shape -> the HIP kernel below
+                _lib.check(rc, "sr_gemm1x1_nhwc_fwd")
+    wp, bias = packed_wino_weight(conv, bn) if use_wino else packed_weight(conv, bn)
     slope = C.c_float(_act_code(leaky, act))
     with torch.cuda.device(x.device):
         if prof is not None:

@@ -175,3 +175,38 @@ def test_winograd_async_handover_is_bit_identical(shape, monkeypatch):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, conv.weight, conv.bias, padding=1) + res, 0.2)
     assert rel_err(outs[1], ref) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(8, 160, 960, 30, 40, "silu", False), (8, 960, 160, 30, 40, None, True),
+                                   (2, 64, 128, 120, 160, None, False), (1, 192, 64, 48, 64, "relu", True),
+                                   (3, 24, 1, 33, 47, None, False)])
+def test_conv1x1_library_gemm_path(shape, monkeypatch):
+    """1x1 convs over dense maps through hipBLASLt (sr_gemm1x1_nhwc_fwd: bias, BatchNorm fold, residual before the
+    activation, SiLU / ReLU epilogues, channel-slice outputs) against F.conv2d and against the implicit-GEMM HIP kernel."""
+    B, ci, co, h, w, act, with_res = shape
+    g = torch.Generator().manual_seed(ci * 3 + co)
+    conv = torch.nn.Conv2d(ci, co, 1).to(DEV)
+    bn = torch.nn.BatchNorm2d(co).eval()
+    synthetic.seeded_fill_(bn, seed=2)
+    bn = bn.to(DEV)
+    x = torch.randn((B, ci, h, w), generator=g).to(DEV)
+    res = torch.randn((B, co, h, w), generator=g).to(DEV) if with_res else None
+    kw = dict(act="silu") if act == "silu" else dict(leaky=0.0) if act == "relu" else {}
+    ref = bn(torch.nn.functional.conv2d(x, conv.weight, conv.bias))
+    if res is not None:
+        ref = ref + res
+    ref = torch.nn.functional.silu(ref) if act == "silu" else torch.relu(ref) if act == "relu" else ref
+    outs = {}
+    for use in (True, False):
+        monkeypatch.setattr(ops, "USE_GEMM_1X1", use)
+        with torch.inference_mode():
+            ops.PROFILE = []
+            buf = ops.empty_nhwc(B, co + 8, h, w, DEV).fill_(3.0)      # write into a channel slice of a wider buffer
+            ops.conv2d(x, conv, bn=bn, residual=res, out=buf[:, 4:4 + co], library_gemm=True, **kw)
+            names = [r[0] for r in ops.PROFILE]
+            ops.PROFILE = None
+        assert ("hipBLASLt" in names[0]) == (use and B * h * w >= ops.GEMM_1X1_MIN_PIXELS), names
+        assert bool((buf[:, :4] == 3).all()) and bool((buf[:, 4 + co:] == 3).all())
+        outs[use] = buf[:, 4:4 + co].clone()
+        assert rel_err(outs[use], ref.detach()) < 1e-5, use
+    assert rel_err(outs[True], outs[False]) < 1e-5
