@@ -1,0 +1,94 @@
+// sr_wino.h -- definitions shared by the two Winograd F(2x2, 3x3) kernels (sr_wino.hip: 4 waves, two workgroups per
+// CU; sr_wino8.hip: 8 waves, one workgroup per CU, transform / staging / epilogue issued between the MFMAs).
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "sr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef SR_WINO_WAVES
+#define SR_WINO_WAVES 2  // waves per SIMD the register allocation must allow (2 = two workgroups per CU)
+#endif
+
+#ifndef SR_WINO_NB
+#define SR_WINO_NB 4   // rotating weight-fragment register sets; must divide the 8 steps of a slab
+#define SR_WINO_PD 3   // prefetch distance in steps (< NB)
+#endif
+
+#define WN_TR 4
+#define WN_TC 8
+#define WN_PH (2 * WN_TR + 2)  // 10 patch rows
+#define WN_PW (2 * WN_TC + 2)  // 18 patch cols
+#define WN_ROW 20              // floats per staged pixel / per V row (16 channels + 4 pad)
+#define WN_RAW_FLOATS (WN_PH * WN_PW * WN_ROW)
+#define WN_V_FLOATS (16 * 32 * WN_ROW)
+#define WN_O_FLOATS (8 * 32 * 64)
+// V and the epilogue slab O share the first 64 KB; the raw patch lives behind them so that the NEXT region's first
+// slab can be staged while the current region finishes (its last MFMA phase and its epilogue): 78 KB, 2 per CU.
+#define WN_VO_FLOATS (WN_V_FLOATS + WN_RAW_FLOATS > WN_O_FLOATS ? WN_V_FLOATS + WN_RAW_FLOATS : WN_O_FLOATS)
+#define WN_LDS_FLOATS (WN_VO_FLOATS + WN_RAW_FLOATS + 4)   // + the slab hand-over counter of the ASYNC variant
+#define WN_STAGE_ELEMS (WN_PH * WN_PW * 4)  // float4 elements per slab (720)
+#define WN_STAGE_PER_THREAD 3
+
+// Phase-ablation switches (env SR_WINO_DEBUG) exist only in -DSR_WINO_ABLATION builds; in production they are compile-time 0,
+// which keeps dead branches out of the hot loops (they cost registers: the MLP sweep spilled because of them).
+#ifdef SR_WINO_ABLATION
+#define SR_WN_DBG(bit) (p.debug & (bit))
+#else
+#define SR_WN_DBG(bit) 0
+#endif
+
+struct SrWinoParams {
+  const float* in; int64_t in_sb; int in_sp;
+  const float* wu;                                  // packed U: [16][G][2][Co_pad][4]
+  const float* bias;
+  const float* res; int64_t res_sb; int res_sp;
+  float* out; int64_t out_sb; int out_sp;
+  int H, W, Cin, Cout, Co_pad, G;                   // stride 1, pad 1: output is H x W
+  int regions_x, regions_y, co_blocks, total;
+  float slope;
+  int vec4;
+  int debug;  // ablation bits (env SR_WINO_DEBUG), 0 in production
+  // split-K: a work item covers 1/ksplit of the input slabs and stores its raw partial output (no bias / residual /
+  // activation) to part + ks * part_stride (dense channels-last [B, H*W, Cout]); sr_wino_reduce_kernel finishes.
+  int ksplit; float* part; int64_t part_stride;
+  int stagger;  // shader cycles the second workgroup of a CU waits before its first region (0 = off)
+#ifdef SR_WINO_TRACE
+  unsigned long long* trace;  // [blocks][SR_TR_REGIONS][SR_TR_EVENTS] shader-clock stamps (debug builds only)
+#endif
+};
+
+#ifdef SR_WINO_TRACE
+#define SR_TR_REGIONS 12
+#define SR_TR_EVENTS 16
+#define SR_TR(ev)                                                                                          \
+  do {                                                                                                     \
+    if (tid == 0 && tr_region < SR_TR_REGIONS)                                                              \
+      p.trace[((size_t)blockIdx.x * SR_TR_REGIONS + tr_region) * SR_TR_EVENTS + (ev)] = clock64();          \
+  } while (0)
+#else
+#define SR_TR(ev) do {} while (0)
+#endif
+
+// float4 add / sub as two packed fp32 pairs (v_pk_add_f32): the transforms are pure add / sub work
+typedef float wn_f2 __attribute__((ext_vector_type(2)));
+#ifdef SR_WINO_NOPK   // ablation: plain fp32 adds instead of v_pk_add_f32 (packed fp32 VALU beside MFMAs)
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+#else
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) {
+  const wn_f2 lo = wn_f2{a.x, a.y} - wn_f2{b.x, b.y}, hi = wn_f2{a.z, a.w} - wn_f2{b.z, b.w};
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) {
+  const wn_f2 lo = wn_f2{a.x, a.y} + wn_f2{b.x, b.y}, hi = wn_f2{a.z, a.w} + wn_f2{b.z, b.w};
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+#endif
+
+
+// sr_wino8.hip: launches the 8-wave kernel on `blocks` workgroups; SR_ERR_UNSUPPORTED when the layer does not qualify.
+int sr_wino8_launch(const SrWinoParams& p, int blocks, hipStream_t stream);
+int sr_wino8_supported(const SrWinoParams& p, bool vout, int nt);

@@ -20,76 +20,7 @@
 // in registers and 2 of 4 values per (tile, channel) cross LDS (one 64-KB pass); a thread then owns (tile, 4 channels)
 // units: float4 residual loads, bias, LeakyReLU, float4 stores straight into the consumer's concat slice.
 // The live set (128 accumulator + 32 weight + 12 staging registers ...) fits 256 VGPRs without scratch spills.
-#include <stdio.h>
-#include <stdlib.h>
-
-#include "sr_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#ifndef SR_WINO_WAVES
-#define SR_WINO_WAVES 2  // waves per SIMD the register allocation must allow (2 = two workgroups per CU)
-#endif
-
-#ifndef SR_WINO_NB
-#define SR_WINO_NB 4   // rotating weight-fragment register sets; must divide the 8 steps of a slab
-#define SR_WINO_PD 3   // prefetch distance in steps (< NB)
-#endif
-
-#define WN_TR 4
-#define WN_TC 8
-#define WN_PH (2 * WN_TR + 2)  // 10 patch rows
-#define WN_PW (2 * WN_TC + 2)  // 18 patch cols
-#define WN_ROW 20              // floats per staged pixel / per V row (16 channels + 4 pad)
-#define WN_RAW_FLOATS (WN_PH * WN_PW * WN_ROW)
-#define WN_V_FLOATS (16 * 32 * WN_ROW)
-#define WN_O_FLOATS (8 * 32 * 64)
-// V and the epilogue slab O share the first 64 KB; the raw patch lives behind them so that the NEXT region's first
-// slab can be staged while the current region finishes (its last MFMA phase and its epilogue): 78 KB, 2 per CU.
-#define WN_VO_FLOATS (WN_V_FLOATS + WN_RAW_FLOATS > WN_O_FLOATS ? WN_V_FLOATS + WN_RAW_FLOATS : WN_O_FLOATS)
-#define WN_LDS_FLOATS (WN_VO_FLOATS + WN_RAW_FLOATS + 4)   // + the slab hand-over counter of the ASYNC variant
-#define WN_STAGE_ELEMS (WN_PH * WN_PW * 4)  // float4 elements per slab (720)
-#define WN_STAGE_PER_THREAD 3
-
-// Phase-ablation switches (env SR_WINO_DEBUG) exist only in -DSR_WINO_ABLATION builds; in production they are compile-time 0,
-// which keeps dead branches out of the hot loops (they cost registers: the MLP sweep spilled because of them).
-#ifdef SR_WINO_ABLATION
-#define SR_WN_DBG(bit) (p.debug & (bit))
-#else
-#define SR_WN_DBG(bit) 0
-#endif
-
-struct SrWinoParams {
-  const float* in; int64_t in_sb; int in_sp;
-  const float* wu;                                  // packed U: [16][G][2][Co_pad][4]
-  const float* bias;
-  const float* res; int64_t res_sb; int res_sp;
-  float* out; int64_t out_sb; int out_sp;
-  int H, W, Cin, Cout, Co_pad, G;                   // stride 1, pad 1: output is H x W
-  int regions_x, regions_y, co_blocks, total;
-  float slope;
-  int vec4;
-  int debug;  // ablation bits (env SR_WINO_DEBUG), 0 in production
-  // split-K: a work item covers 1/ksplit of the input slabs and stores its raw partial output (no bias / residual /
-  // activation) to part + ks * part_stride (dense channels-last [B, H*W, Cout]); sr_wino_reduce_kernel finishes.
-  int ksplit; float* part; int64_t part_stride;
-  int stagger;  // shader cycles the second workgroup of a CU waits before its first region (0 = off)
-#ifdef SR_WINO_TRACE
-  unsigned long long* trace;  // [blocks][SR_TR_REGIONS][SR_TR_EVENTS] shader-clock stamps (debug builds only)
-#endif
-};
-
-#ifdef SR_WINO_TRACE
-#define SR_TR_REGIONS 12
-#define SR_TR_EVENTS 16
-#define SR_TR(ev)                                                                                          \
-  do {                                                                                                     \
-    if (tid == 0 && tr_region < SR_TR_REGIONS)                                                              \
-      p.trace[((size_t)blockIdx.x * SR_TR_REGIONS + tr_region) * SR_TR_EVENTS + (ev)] = clock64();          \
-  } while (0)
-#else
-#define SR_TR(ev) do {} while (0)
-#endif
+#include "sr_wino.h"
 
 // U = G g G^T per (co, ci), stored in MFMA B-fragment order: element (xi, g8, kk, co, e) = U_xi[co][8*g8 + 4*kk + e]
 __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wu, int Co, int Ci, int G,
@@ -121,22 +52,6 @@ __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restri
     wu[e] = v;
   }
 }
-
-// float4 add / sub as two packed fp32 pairs (v_pk_add_f32): the transforms are pure add / sub work
-typedef float wn_f2 __attribute__((ext_vector_type(2)));
-#ifdef SR_WINO_NOPK   // ablation: plain fp32 adds instead of v_pk_add_f32 (packed fp32 VALU beside MFMAs)
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-#else
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) {
-  const wn_f2 lo = wn_f2{a.x, a.y} - wn_f2{b.x, b.y}, hi = wn_f2{a.z, a.w} - wn_f2{b.z, b.w};
-  return make_float4(lo.x, lo.y, hi.x, hi.y);
-}
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) {
-  const wn_f2 lo = wn_f2{a.x, a.y} + wn_f2{b.x, b.y}, hi = wn_f2{a.z, a.w} + wn_f2{b.z, b.w};
-  return make_float4(lo.x, lo.y, hi.x, hi.y);
-}
-#endif
 
 // ASYNC: the raw-patch hand-over between the four waves goes through an LDS arrival counter instead of a workgroup
 // barrier per slab.  Every wave stores its share of slab c+1 EARLY (during its MFMAs of slab c, three steps in) and then
@@ -621,6 +536,9 @@ extern "C" int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int 
 //   max(rounds over the 2-per-CU slots x item length alone on a CU, items per CU x item length under sharing) (+ reduce),
 // item length ~ slabs + 2 (prologue / epilogue); constants fitted on r01 measurements, in units of a full NT = 2 item.
 struct SrWinoPlan { int nt, ks; };
+#ifndef SR_WINO8_DEFAULT
+#define SR_WINO8_DEFAULT 0
+#endif
 static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allow_split) {
   const int co_pad = ((Cout + 31) / 32) * 32;
   const int slabs = (Cin + 15) / 16;
@@ -631,8 +549,11 @@ static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allo
   const long cus = sr_wino_num_cus(), slots = 2 * cus;
   SrWinoPlan best = {co_pad % 64 == 0 ? 2 : 1, 1};
   double best_cost = -1.0;
+  const char* e8 = getenv("SR_WINO8");
+  const bool force8 = (e8 ? atoi(e8) : SR_WINO8_DEFAULT) == 2;   // tests: the 8-wave kernel wherever it can run
   for (int nt = 2; nt >= 1; --nt) {
     if (nt == 2 && co_pad % 64 != 0) continue;
+    if (nt == 1 && force8 && co_pad % 64 == 0) continue;
     if ((forced_nt == 1 || forced_nt == 2) && nt != forced_nt && !(forced_nt == 2 && co_pad % 64 != 0)) continue;
     for (int ks = 1; ks <= 8; ks *= 2) {
       if (ks > 1 && (!allow_split || slabs % ks != 0 || slabs / ks < 4 || Cout % 4 != 0)) continue;
@@ -648,6 +569,18 @@ static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allo
     }
   }
   return best;
+}
+
+// The 8-wave kernel (sr_wino8.hip) takes the layers whose regions keep one workgroup per CU busy for several rounds.
+// SR_WINO8: 0 never, 1 by the rule below, 2 wherever it is applicable (tests).  Read per call.
+static bool sr_wino_use8(const SrWinoPlan& plan, bool vout, int Cin, int Cout, long items) {
+  const char* e = getenv("SR_WINO8");
+  const int mode = e ? atoi(e) : SR_WINO8_DEFAULT;
+  if (mode == 0 || !vout || plan.nt != 2) return false;
+  const int slabs = (Cin + 15) / 16;
+  if (slabs % plan.ks != 0 || slabs / plan.ks < 2 || (((Cout + 31) / 32) * 32) % 64 != 0) return false;
+  if (mode == 2) return true;
+  return items >= 3L * sr_wino_num_cus();
 }
 
 extern "C" int sr_wino_splitk_factor(int B, int H, int W, int Cin, int Cout) {
@@ -666,6 +599,15 @@ extern "C" const char* sr_wino_kernel_name(int B, int H, int W, int Cin, int Cou
   static thread_local char buf[64];
   (void)Cin;
   const int vin = aligned_in != 0, vout = vin && aligned_out;
+  {
+    const SrWinoPlan plan = sr_wino_plan(B, H, W, Cin, Cout, vout != 0);
+    const long regions = (long)((H + 2 * WN_TR - 1) / (2 * WN_TR)) * ((W + 2 * WN_TC - 1) / (2 * WN_TC)) * B;
+    const int co_pad = ((Cout + 31) / 32) * 32;
+    if (sr_wino_use8(plan, vout != 0, Cin, Cout, regions * (co_pad / (32 * plan.nt)) * plan.ks)) {
+      snprintf(buf, sizeof(buf), "sr_wino8_kernel");
+      return buf;
+    }
+  }
   const char* am = getenv("SR_WINO_ASYNC");
   snprintf(buf, sizeof(buf), "sr_wino_kernel<%d, %s, %s, %s>", sr_wino_plan(B, H, W, Cin, Cout, vout != 0).nt,
            vin ? "true" : "false", vout ? "true" : "false", (am && atoi(am) != 0) ? "true" : "false");
@@ -712,6 +654,8 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   int blocks = sr_wino_num_cus() * 2;
   { const char* e = getenv("SR_WINO_WG_PER_CU"); if (e && atoi(e) == 1) blocks = sr_wino_num_cus(); }  // ablation
   if (blocks > p.total) blocks = p.total;
+  const bool use8 = sr_wino_use8(plan, vout, Cin, Cout, p.total) && sr_wino8_supported(p, vout, nt);
+  if (use8) blocks = sr_wino_num_cus() < p.total ? sr_wino_num_cus() : p.total;
   const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
 #ifdef SR_WINO_TRACE
   static unsigned long long* trace_buf = nullptr;
@@ -737,7 +681,10 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   {                                                                                                               \
     if (async_mode) SR_WINO_LAUNCH1(NTV, V4, VO, true) else SR_WINO_LAUNCH1(NTV, V4, VO, false)                   \
   }
-  if (nt == 2 && vout) SR_WINO_LAUNCH(2, true, true)
+  if (use8) {
+    const int rc8 = sr_wino8_launch(p, blocks, stream);
+    if (rc8 != SR_OK) return rc8;
+  } else if (nt == 2 && vout) SR_WINO_LAUNCH(2, true, true)
   else if (nt == 2 && p.vec4) SR_WINO_LAUNCH(2, true, false)
   else if (nt == 2) SR_WINO_LAUNCH(2, false, false)
   else if (vout) SR_WINO_LAUNCH(1, true, true)

@@ -177,6 +177,40 @@ def test_winograd_async_handover_is_bit_identical(shape, monkeypatch):
     assert rel_err(outs[1], ref) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 60, 80, True, 0.2), (1, 192, 64, 40, 48, True, 0.2), (3, 48, 48, 17, 29, False, None),
+                                   (1, 384, 384, 15, 20, True, 0.2), (8, 64, 64, 120, 160, True, 0.2), (4, 32, 64, 37, 53, True, 0.0),
+                                   (2, 128, 128, 64, 96, False, 0.2), (1, 64, 128, 8, 16, True, None), (5, 80, 64, 24, 40, True, 0.2)])
+def test_winograd_8_wave_kernel_is_bit_identical(shape, monkeypatch):
+    """sr_wino8_kernel (one 8-wave workgroup per CU; transform, staging and the previous region's epilogue issued
+    between the MFMAs) performs the same floating-point operations in the same order as sr_wino_kernel: equal bit for
+    bit.  Cases: several regions per workgroup with the overlapped epilogue (>= 4 slabs), 2- and 3-slab layers (serial
+    epilogue), 5 / 12 / 24 slabs, split-K plans, ragged edges, Cout = 48 inside a 64-channel block, two 64-channel
+    blocks, fewer regions than CUs, with / without bias + residual, LeakyReLU / ReLU / identity."""
+    B, ci, co, h, w, extras, leaky = shape
+    g = torch.Generator().manual_seed(ci + co + h)
+    conv = torch.nn.Conv2d(ci, co, 3, padding=1, bias=extras)
+    x = torch.randn((B, ci, h, w), generator=g).to(DEV)
+    res = torch.randn((B, co, h, w), generator=g).to(DEV) if extras else None
+    conv = conv.to(DEV)
+    from simplerecon_amd import _lib
+    lib = _lib.lib()
+    outs = []
+    for mode in ("0", "2", "2"):
+        monkeypatch.setenv("SR_WINO8", mode)
+        name = lib.sr_wino_kernel_name(B, h, w, ci, co, 1, 1).decode()
+        assert ("wino8" in name) == (mode == "2"), name
+        with torch.inference_mode():
+            outs.append(ops.conv2d(x, conv, residual=res, leaky=leaky).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    ref = torch.nn.functional.conv2d(x, conv.weight, conv.bias, padding=1)
+    if res is not None:
+        ref = ref + res
+    if leaky is not None:
+        ref = torch.nn.functional.leaky_relu(ref, leaky)
+    assert rel_err(outs[1], ref) < 2e-5
+
+
 @pytest.mark.parametrize("shape", [(8, 160, 960, 30, 40, "silu", False), (8, 960, 160, 30, 40, None, True),
                                    (2, 64, 128, 120, 160, None, False), (1, 192, 64, 48, 64, "relu", True),
                                    (3, 24, 1, 33, 47, None, False)])
