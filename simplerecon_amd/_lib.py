@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsimplerecon_hip.so")
+LIB_PATH = os.environ.get("SR_HIP_LIBRARY") or os.path.join(_HERE, "libsimplerecon_hip.so")   # override: ablation / trace builds
 ABI_VERSION = 1
 
 _lib = None

@@ -571,8 +571,16 @@ static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allo
   return best;
 }
 
-// The 8-wave kernel (sr_wino8.hip) takes the layers whose regions keep one workgroup per CU busy for several rounds.
-// SR_WINO8: 0 never, 1 by the rule below, 2 wherever it is applicable (tests).  Read per call.
+// The 8-wave kernel (sr_wino8.hip) overlaps a region's transform and epilogue with the MFMAs instead of running them as
+// phases.  Measured r02 on MI355X (scripts/wino8_micro.py, both kernels in one process, batch 8): 64 -> 64 @ 240x320
+// (4 slabs per region): 1.08-1.10x; 192 -> 64 @ 240x320 (12 slabs): 1.03-1.07x; 128 -> 64 @ 240x320 (8 slabs): 0.93-1.04x
+// depending on the box; everything at 120x160 and below: 0.90-0.98x (too few regions per CU for a one-workgroup-per-CU
+// kernel to amortise its prologue and the last region's serial epilogue).  Rule of mode 1: full-resolution layers
+// (>= 16 regions per CU) whose regions are short (<= 4 slabs: the epilogue is a large share) or long (>= 12 slabs).
+// Inside the whole step (bench.py hero_cfg3, same box, back to back) that rule measured 242.1 vs 246.4 frames/s without
+// it -- the isolated gain does not survive next to the side-stream encoder and real concat-slice layouts -- so the
+// default is 0: the kernel stays as a tested, bit-identical alternative and as the vehicle of the r02 pipe measurements.
+// SR_WINO8: 0 never (default), 1 by the rule above, 2 wherever it is applicable (tests).  Read per call.
 static bool sr_wino_use8(const SrWinoPlan& plan, bool vout, int Cin, int Cout, long items) {
   const char* e = getenv("SR_WINO8");
   const int mode = e ? atoi(e) : SR_WINO8_DEFAULT;
@@ -580,7 +588,8 @@ static bool sr_wino_use8(const SrWinoPlan& plan, bool vout, int Cin, int Cout, l
   const int slabs = (Cin + 15) / 16;
   if (slabs % plan.ks != 0 || slabs / plan.ks < 2 || (((Cout + 31) / 32) * 32) % 64 != 0) return false;
   if (mode == 2) return true;
-  return items >= 3L * sr_wino_num_cus();
+  const int per_item = slabs / plan.ks;
+  return items >= 16L * sr_wino_num_cus() && per_item >= 4 && (per_item <= 4 || per_item >= 12);
 }
 
 extern "C" int sr_wino_splitk_factor(int B, int H, int W, int Cin, int Cout) {
