@@ -103,7 +103,15 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
   // Transform-phase role: wave w produces the frequency ROW ur = w of V (the rows it alone multiplies), so V is
   // wave-private and no barrier separates a wave's transform from its MFMAs.  Lane -> 4-channel group tq and tiles
   // tt0, tt0 + 16.  Row ur of B^T d needs two patch rows: (0,2) d0-d2, (1,2) d1+d2, (2,1) d2-d1, (1,3) d1-d3.
+  // 16 lanes (one LDS access group of a 128-bit operation: 64 banks x 4 B) = 4 tiles x 4 channel quads.  Tiles j, j + 4,
+  // j + 8, j + 12 of a 16-tile group sit at patch offsets (160 j' B) and V offsets (80 j' B) whose 64-byte blocks fall on
+  // four different quarters of the 256-byte bank line; consecutive tiles overlap by 32 / 16 bytes (r02 PMC: 32 % of the
+  // LDS-active cycles of the transform were bank conflicts).  SR_WINO_TLINEAR keeps the old mapping (ablation build).
+#ifdef SR_WINO_TLINEAR
   const int tq = lane & 3, tt0 = lane >> 2;
+#else
+  const int tq = lane & 3, tt0 = (((lane >> 2) & 3) << 2) | (lane >> 4);
+#endif
   const int t_ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1), t_rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
   const float t_sign = wave == 1 ? 1.0f : -1.0f;
 

@@ -213,7 +213,12 @@ __global__ __launch_bounds__(512, 2) void sr_wino8_kernel(SrWinoParams p) {
   constexpr int NB = W8_NB, PD = W8_PD;
 
   // transform role (see sr_wino.hip): row u of B^T d needs patch rows (t_ra, t_rb): d_ra + t_sign * d_rb
+  // (tiles j, j + 4, j + 8, j + 12 share a 16-lane LDS access group: conflict-free patch reads and V writes, see sr_wino.hip)
+#ifdef SR_WINO_TLINEAR
   const int tq = lane & 3, tt = 16 * h + (lane >> 2);
+#else
+  const int tq = lane & 3, tt = 16 * h + ((((lane >> 2) & 3) << 2) | (lane >> 4));
+#endif
   const int t_ra = u == 0 ? 0 : (u == 2 ? 2 : 1), t_rb = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 3));
   const float t_s1 = u == 1 ? 1.0f : -1.0f;
   const w8_f2 t_sign = {t_s1, t_s1};
