@@ -62,6 +62,36 @@ def main():
     save.update({"d_" + k: prm[k].grad.numpy() for k in gc.DECODER_GRAD_PARAMS})
     np.savez_compressed(os.path.join(OUT, "grad_decoder_narrow.npz"), **save)
     print("decoder", {k: v.shape for k, v in save.items()})
+    # ---- the whole training chain behind the encoders, float64 (see the decoder note above) ---------------
+    case = gc.CHAIN_CASE
+    inp = synthetic.cost_volume_inputs(case["B"], case["K"], case["C"], case["h"], case["w"], seed=case["seed"], device="cpu")
+    mgr = cv.FeatureVolumeManager(case["h"], case["w"], num_depth_bins=case["D"],
+                                  mlp_channels=[case["C"] * (case["K"] + 1) + 10 * case["K"] + 4, 128, 128, 1],
+                                  matching_dim_size=case["C"], num_source_views=case["K"])
+    synthetic.seeded_fill_(mgr.mlp, seed=case["seed"])
+    enc = synthetic.seeded_fill_(nets.CVEncoder(num_ch_cv=case["D"], num_ch_enc=case["enc_ch"][1:],
+                                                num_ch_outs=case["cv_outs"]), seed=case["seed"] + 1)
+    dec = synthetic.seeded_fill_(nets.DepthDecoderPP(case["enc_ch"][:1] + case["cv_outs"]), seed=case["seed"] + 2)
+    mgr, enc, dec = mgr.double(), enc.double(), dec.double()
+    inp = {k: (v.double() if v.is_floating_point() else v) for k, v in inp.items()}
+    inp["cur_feats"].requires_grad_()
+    inp["src_feats"].requires_grad_()
+    pyr = [f.double().requires_grad_() for f in synthetic.image_prior_pyramid(case["B"], case["h"], case["w"],
+                                                                             chans=case["enc_ch"], seed=case["seed"])]
+    vol = mgr(**inp)[0]
+    outs = dec(pyr[:1] + enc(vol, pyr[1:]))
+    cot = gc.chain_cotangents(case, {k: tuple(v.shape) for k, v in outs.items()})
+    sum((torch.exp(outs[k]) * torch.from_numpy(c).double()).sum() for k, c in cot.items()).backward()
+    save = {"depth_s0": torch.exp(outs["log_depth_pred_s0_b1hw"]).detach().numpy(), "cost_volume": vol.detach().numpy(),
+            "d_cur_feats": inp["cur_feats"].grad.numpy(), "d_src_feats": inp["src_feats"].grad.numpy()}
+    save.update({f"d_pyr_{i}": t.grad.numpy() for i, t in enumerate(pyr)})
+    save.update({"d_mlp." + k: v.grad.numpy() for k, v in mgr.mlp.state_dict(keep_vars=True).items()})
+    prm = dict(enc.named_parameters())
+    save.update({"d_enc." + k: prm[k].grad.numpy() for k in gc.CHAIN_ENC_PARAMS})
+    prm = dict(dec.named_parameters())
+    save.update({"d_dec." + k: prm[k].grad.numpy() for k in gc.DECODER_GRAD_PARAMS})
+    np.savez_compressed(os.path.join(OUT, "grad_chain_narrow.npz"), **save)
+    print("chain", {k: v.shape for k, v in save.items()})
     # ---- BasicBlock (conv stack) ---------------------------------------------------------------------
     for name in gc.GRAD_BLOCK_CASES:
         case = gc.BLOCK_CASES[name]

@@ -122,6 +122,18 @@ def net_inputs(case, device="cpu"):
     return vol.to(device), [f.to(device) for f in feats]
 
 
+# end-to-end training chain (reference train.py:126-145 behind the encoders): FeatureVolumeManager -> CVEncoder ->
+# DepthDecoderPP -> exp, loss = sum_k sum(exp(log_depth_k) * R_k); golden = the reference's autograd in float64
+CHAIN_CASE = dict(B=1, K=2, C=16, D=8, h=8, w=16, seed=61, enc_ch=[6, 10, 12, 20, 28], cv_outs=[64, 128, 256, 384])
+CHAIN_ENC_PARAMS = ("convs.ds_conv_0.conv1.weight", "convs.conv_0.0.downsample.0.weight", "convs.conv_1.1.conv2.bias",
+                    "convs.ds_conv_3.conv1.bias")
+
+
+def chain_cotangents(case, shapes):
+    rng = np.random.default_rng(8400 + case["seed"])
+    return {k: rng.standard_normal(shapes[k], dtype=np.float32) for k in sorted(shapes)}
+
+
 DECODER_GRAD_PARAMS = ("convs.output_0.1.weight", "convs.output_3.0.conv1.bias", "convs.in_conv_04.0.conv1.bias",
                        "convs.right_conv_00.conv1.weight", "convs.diag_conv_40.conv2.bias", "convs.up_conv_12.conv1.weight",
                        "convs.in_conv_31.conv_0.conv2.bias")
