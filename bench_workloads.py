@@ -96,13 +96,19 @@ def _pmc_algorithmic_bytes(tag):
         return None
 
 
-def _pmc_traffic(tag):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/traffic.json), or None."""
+def _pmc_traffic(tag, kernel=None):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/traffic.json), or None -- also None when
+    the entry was measured on another kernel than the one this run launches (an ablation such as SR_DOT_LDS=0)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(path):
         try:
             v = json.load(open(path)).get(tag)
-            return v.get("bytes") if isinstance(v, dict) else v
+            if isinstance(v, dict):
+                if kernel and v.get("kernel") and not (kernel.startswith(v["kernel"].rstrip(">")) or
+                                                       v["kernel"].startswith(kernel.rstrip(">"))):
+                    return None
+                return v.get("bytes")
+            return v
         except Exception:
             return None
     return None
@@ -169,7 +175,7 @@ class DotCfg2:
         nbytes = self.algorithmic_bytes()
         achieved = nbytes / t / 1e9
         N = h * w
-        traffic = _pmc_traffic(self.name)
+        traffic = _pmc_traffic(self.name, _dot_kernel_name(B, h, w, D))
         return {"kernel": _dot_kernel_name(B, h, w, D), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_over_algorithmic": (traffic / nbytes) if traffic else None,
