@@ -4,6 +4,8 @@
 Activations flow between our layers as channels_last (NHWC-in-memory) torch tensors -- logically
 still b,c,h,w, so callers see the reference's shapes -- and every BasicBlock writes straight into
 its slice of the next concat buffer (no torch.cat copies)."""
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -137,8 +139,12 @@ class DepthDecoderPP(nn.Module):
     # The three inputs of a node (right / diagonal / up branch) are independent BasicBlocks writing disjoint channel
     # slices of the node's concat buffer.  At small batch a single conv launch leaves CUs idle (150-600 work items for
     # 512 slots), so for batches <= `branch_stream_max_batch` the diagonal and up branches run on two side HIP
-    # streams and join before `in_conv`.  (At batch 8 every launch fills the chip and the fork/join only costs.)
+    # streams and join before `in_conv`.  At batch 8 the 240x320 launches fill the chip and the fork / join only costs,
+    # but the nodes from 120x160 down (<= 1200 of the convs' 8x16-pixel regions for 512 workgroup slots, their diagonal
+    # / up branches a quarter of that) leave part of it idle: those fork at any batch (`branch_stream_max_regions`,
+    # 0 = off; measured r02 at batch 8: 32.3 -> 32.0 ms per step with 1300, nothing with 400, nothing more with 5000).
     branch_stream_max_batch = 2
+    branch_stream_max_regions = int(os.environ.get("SR_DECODER_FORK_REGIONS", "1300"))
 
     @staticmethod
     def _side_streams(device):
@@ -175,8 +181,8 @@ class DepthDecoderPP(nn.Module):
         outputs = []
         depth_outputs = {}
         dev = prev_outputs[0].device
-        fork = dev.type == "cuda" and prev_outputs[0].shape[0] <= self.branch_stream_max_batch
-        if fork:
+        small_batch = dev.type == "cuda" and prev_outputs[0].shape[0] <= self.branch_stream_max_batch
+        if dev.type == "cuda":
             main = torch.cuda.current_stream(dev)
             s1, s2 = self._side_streams(dev)
         for j in range(1, 5):
@@ -188,6 +194,8 @@ class DepthDecoderPP(nn.Module):
                 x_i = prev_outputs[i]
                 n_parts = 3 if i + j != 4 else 2
                 buf = ops.empty_nhwc(x_i.shape[0], c * n_parts, x_i.shape[2], x_i.shape[3], x_i.device)
+                regions = x_i.shape[0] * ((x_i.shape[2] + 7) // 8) * ((x_i.shape[3] + 15) // 16)
+                fork = small_batch or (dev.type == "cuda" and regions <= self.branch_stream_max_regions)
                 if fork:
                     s1.wait_stream(main)
                     with torch.cuda.stream(s1):
