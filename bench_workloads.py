@@ -311,10 +311,20 @@ class HeroCfg3:
                             + (" (BASELINE.json configs[2]: hero_model.yaml, batch 8)" if self.B == 8 and
                                self.feature_volume_type == "mlp_feature_volume" else ""),
                 "frames_per_step_per_gpu": self.B,
+                # main stream(s) + the image-prior encoder's side stream + the two branch streams of the decoder (its
+                # right / diagonal / up branches fork for every node up to `branch_stream_max_regions` regions)
                 "hip_streams_per_gpu": self.streams + (1 if (self.prior and getattr(self.model, "prior_on_side_stream", True))
-                                                       else 0),
+                                                       else 0) + (2 if self._decoder_forks() else 0),
                 "submission": "one HIP graph replay per step" if self.use_graph else "eager (one launch per kernel)",
                 "parallelism": f"replica x{world} (keyframes sharded)"}
+
+    def _decoder_forks(self):
+        dec = getattr(self.model, "depth_decoder", None)
+        if dec is None:
+            return False
+        # the smallest node (15 x 20 at 640 x 480) decides whether any node forks
+        regions = self.B * ((self.h // 8 + 7) // 8) * ((self.w // 8 + 15) // 16)
+        return self.B <= dec.branch_stream_max_batch or regions <= dec.branch_stream_max_regions
 
     def _profile_convs(self, n):
         from simplerecon_amd import ops
