@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for wl in hero_cfg3; do for m in 0 1300 5000 0 1300 5000; do SR_DECODER_FORK_REGIONS=$m timeout 300 python bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$wl', 'FORK_REGIONS=$m', round(d['value'],1), round(d['ms_per_step'],2))"; done; done
+export SR_MICRO_SHAPES=0,1 SR_MICRO_MODES=0,2
+for st in 0 8000 30000 60000 0; do echo "STAGGER_CU=$st"; SR_WINO_STAGGER_CU=$st timeout 200 python scripts/wino8_micro.py 2>&1 | grep -v amdgpu; done

@@ -55,6 +55,7 @@ struct SrWinoParams {
   // activation) to part + ks * part_stride (dense channels-last [B, H*W, Cout]); sr_wino_reduce_kernel finishes.
   int ksplit; float* part; int64_t part_stride;
   int stagger;  // shader cycles the second workgroup of a CU waits before its first region (0 = off)
+  int stagger_cu;  // ablation: every workgroup waits a pseudo-random part of this many cycles first (de-phases the CUs)
 #ifdef SR_WINO_TRACE
   unsigned long long* trace;  // [blocks][SR_TR_REGIONS][SR_TR_EVENTS] shader-clock stamps (debug builds only)
 #endif

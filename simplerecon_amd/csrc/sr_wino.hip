@@ -87,6 +87,14 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     }
     __syncthreads();
   }
+  if (p.stagger_cu > 0) {   // ablation: start the workgroups of different CUs at different phases of a region
+    if (threadIdx.x == 0) {
+      const long long wait = (long long)(((blockIdx.x >> 1) * 2654435761u) >> 24) * p.stagger_cu / 256;
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while ((long long)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+  }
   float* V = lds;                     // [16][32][20]
   float* O = lds;                     // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases V and raw A)
   float* rawA = lds + WN_V_FLOATS;    // [10*18][20]  odd slabs  (inside the V/O area: dead by the epilogue)
@@ -667,6 +675,7 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   p.total = p.regions_x * p.regions_y * p.co_blocks * B * p.ksplit;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_WINO_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   { const char* e = getenv("SR_WINO_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+  { const char* e = getenv("SR_WINO_STAGGER_CU"); p.stagger_cu = e ? atoi(e) : 0; }
   hipStream_t stream = (hipStream_t)stream_;
   int blocks = sr_wino_num_cus() * 2;
   { const char* e = getenv("SR_WINO_WG_PER_CU"); if (e && atoi(e) == 1) blocks = sr_wino_num_cus(); }  // ablation

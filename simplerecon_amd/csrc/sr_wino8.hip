@@ -451,6 +451,14 @@ __global__ __launch_bounds__(512, 2) void sr_wino8_kernel(SrWinoParams p) {
   int ch = 0, pz = 0;
   unsigned wcur = w_base(reg_cb, reg_ks, 0), wnxt = chunks == 1 ? w_base(nreg_cb, nreg_ks, 0) : w_base(reg_cb, reg_ks, 1);
 
+  if (p.stagger_cu > 0) {   // ablation: start the workgroups at different phases of a region (de-phases their memory bursts)
+    if (tid == 0) {
+      const long long wait = (long long)((blockIdx.x * 2654435761u) >> 24) * p.stagger_cu / 256;
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while ((long long)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+  }
   // ---- prologue: slabs 0 and 1 of the stream into the raw buffers, slab 2 into registers, slab 0 transformed ----
   stage_load(stg); stage_advance(); stage_store(stg, Rbuf);
   stage_load(stg); stage_advance(); stage_store(stg, Rbuf + W8_RAW_FLOATS);
