@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
   float* rawA = lds + WN_V_FLOATS;    // [10*18][20]  odd slabs  (inside the V/O area: dead by the epilogue)
   float* rawB = lds + WN_VO_FLOATS;   // [10*18][20]  even slabs (behind it: survives the epilogue)
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  // (readfirstlane: the wave index is uniform, so everything derived from it -- the weight-record offsets of the MFMA
+  // loop above all -- is scalar arithmetic; as a plain `tid >> 6` it cost 7 VALU instructions per MFMA step)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, kk = lane >> 5;
   const int chunks = (p.G >> 1) / p.ksplit;  // input slabs per work item
   const int64_t rec = (int64_t)2 * p.Co_pad;
