@@ -385,6 +385,10 @@ int sr_dot_volume_bwd(const float* grad_cv, int64_t g_sb, int64_t g_sd, int64_t 
  *                                (sr_conv_wgrad_workspace_bytes) added in index order by a second kernel (deterministic)
  *  sr_bias_grad_nhwc             d_bias [C] = sum over pixels of grad_out
  *  sr_act_bwd                    grad * LeakyReLU'(saved output), dense arrays of n floats
+ *  sr_act_bwd_bias_nhwc          both of the above in one float4 pass over a dense [pixels, C] gradient (C % 4 == 0):
+ *                                grad_pre = grad * LeakyReLU'(out_saved) (out_saved null: no activation, nothing written),
+ *                                d_bias = sum over pixels of grad_pre (null: skipped); per-block partial sums in
+ *                                `workspace` (sr_act_bwd_bias_workspace_bytes) are added in block order (deterministic)
  *  sr_zero_stuff2x_nhwc          out [B,Hs,Ws,C] dense: out[:, 2y, 2x] = in[:, y, x], zero elsewhere
  *  sr_upsample2x_bwd_nhwc        adjoint of sr_upsample2x_nhwc_fwd: grad_out [B,2H,2W,C] -> grad_in [B,H,W,C]
  *  sr_conv_flip_transpose_weights  out [Cin,Cout,k,k] = W[co,ci,k-1-ky,k-1-kx]
@@ -396,6 +400,9 @@ int sr_conv_wgrad_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stri
 int sr_bias_grad_nhwc(const float* grad_out, int64_t g_batch_stride, int g_pix_stride, float* d_bias, int B, int H, int W,
                       int C, void* stream);
 int sr_act_bwd(const float* grad, const float* out_saved, float* grad_pre, int64_t n, float leaky_slope, void* stream);
+size_t sr_act_bwd_bias_workspace_bytes(int64_t pixels, int C);
+int sr_act_bwd_bias_nhwc(const float* grad, const float* out_saved, float* grad_pre, float* d_bias, int64_t pixels, int C,
+                         float leaky_slope, void* workspace, size_t workspace_bytes, void* stream);
 int sr_zero_stuff2x_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, float* out, int B, int H, int W,
                          int Hs, int Ws, int C, void* stream);
 int sr_upsample2x_bwd_nhwc(const float* grad_out, int64_t g_batch_stride, int g_pix_stride, float* grad_in,

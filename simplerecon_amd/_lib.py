@@ -69,6 +69,8 @@ SIGNATURES = {
     "sr_conv_wgrad_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "sr_bias_grad_nhwc": (_i, [_p, _i64, _i, _p, _i, _i, _i, _i, _p]),
     "sr_act_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
+    "sr_act_bwd_bias_workspace_bytes": (_sz, [_i64, _i]),
+    "sr_act_bwd_bias_nhwc": (_i, [_p, _p, _p, _p, _i64, _i, _f, _p, _sz, _p]),
     "sr_zero_stuff2x_nhwc": (_i, [_p, _i64, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sr_upsample2x_bwd_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "sr_conv_flip_transpose_weights": (_i, [_p, _i, _i, _i, _p, _p]),

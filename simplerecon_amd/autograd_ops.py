@@ -10,12 +10,16 @@ Gradients are pinned to the reference's own autograd (tests/golden/grad_block_*.
 grad_decoder_narrow.npz).  Not covered yet: the two encoders (no BatchNorm / InstanceNorm backward) -- DepthModel treats
 their outputs as constants."""
 import ctypes as C
+import os
 
 import torch
 from torch import nn
 
 from . import _lib
 from .ops import _is_nhwc_view, _strides, _workspace, as_nhwc, empty_nhwc
+
+
+FUSED_ACT_BIAS = os.environ.get("SR_FUSED_ACT_BIAS", "1") != "0"   # 0: separate sr_act_bwd + sr_bias_grad_nhwc launches (r02 a/b)
 
 
 def grad_wanted(*tensors_or_modules):
@@ -109,14 +113,29 @@ class _ConvBiasAct(torch.autograd.Function):
         g = _dense_nhwc(g if g.dtype == torch.float32 else g.float())
         st = _lib.stream_ptr(dev)
         need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
+        want_b = ctx.has_bias and need_b
+        fused = FUSED_ACT_BIAS and co % 4 == 0 and b > 0 and (ctx.slope is not None or want_b)
+        d_b = None
         with torch.cuda.device(dev):
-            if ctx.slope is not None:
+            if fused:
+                # one float4 pass: LeakyReLU' of the saved output and / or the bias gradient (deterministic two-stage sum)
+                gp = torch.empty_like(g) if ctx.slope is not None else g
+                px = b * ho * wo
+                nws = lib.sr_act_bwd_bias_workspace_bytes(px, co) if want_b else 0
+                ws = _workspace(dev, "bias_grad", nws) if want_b else None
+                if want_b:
+                    d_b = torch.empty((co,), dtype=torch.float32, device=dev)
+                _lib.check(lib.sr_act_bwd_bias_nhwc(_lib.ptr(g), _lib.ptr(_dense_nhwc(out)) if ctx.slope is not None else None,
+                                                    _lib.ptr(gp) if ctx.slope is not None else None, _lib.ptr(d_b), px, co,
+                                                    C.c_float(float(ctx.slope) if ctx.slope is not None else 0.0),
+                                                    _lib.ptr(ws), nws, st), "sr_act_bwd_bias_nhwc")
+            elif ctx.slope is not None:
                 gp = torch.empty_like(g)
                 _lib.check(lib.sr_act_bwd(_lib.ptr(g), _lib.ptr(_dense_nhwc(out)), _lib.ptr(gp), g.numel(),
                                           C.c_float(float(ctx.slope)), st), "sr_act_bwd")
             else:
                 gp = g
-            d_x = d_w = d_b = None
+            d_x = d_w = None
             gsb, gsp = _strides(gp)
             if need_w and b > 0:
                 d_w = torch.empty_like(weight)
@@ -127,7 +146,7 @@ class _ConvBiasAct(torch.autograd.Function):
                                                   co, k, s, _lib.ptr(ws), nws, st), "sr_conv_wgrad_nhwc")
             elif need_w:
                 d_w = torch.zeros_like(weight)
-            if ctx.has_bias and need_b:
+            if want_b and d_b is None:
                 d_b = torch.empty((co,), dtype=torch.float32, device=dev)
                 _lib.check(lib.sr_bias_grad_nhwc(_lib.ptr(gp), gsb, gsp, _lib.ptr(d_b), b, ho, wo, co, st),
                            "sr_bias_grad_nhwc")
