@@ -370,14 +370,22 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         }
         SR_TR(10);
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n) {
+          // whole-vector arithmetic: packed fp32 adds, half the VALU instructions of the element-wise form (every VALU
+          // instruction here costs matrix-pipe time of the co-resident workgroup)
+          {
+            const f32x16 c0 = (acc[0][n] + acc[1][n]) + acc[2][n];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int tile = (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
-            O[((wave * 2 + 0) * 32 + tile) * CO + 32 * n + i] = (m0 + m1) + m2;
-            O[((wave * 2 + 1) * 32 + tile) * CO + 32 * n + i] = (m1 - m2) - m3;
+            for (int r = 0; r < 16; ++r)
+              O[((wave * 2 + 0) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CO + 32 * n + i] = c0[r];
           }
+          {
+            const f32x16 c1 = (acc[1][n] - acc[2][n]) - acc[3][n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              O[((wave * 2 + 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CO + 32 * n + i] = c1[r];
+          }
+        }
         SR_TR(11);
         __syncthreads();
         SR_TR(13);
