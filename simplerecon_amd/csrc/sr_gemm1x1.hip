@@ -9,8 +9,11 @@
 // B (= X as Cin x M, ld = in pixel stride) [+ C = residual, beta = 1]; bias per row of D, SiLU = the SWISH_EXT epilogue.
 // fp32 in / out / accumulate (HIPBLAS_COMPUTE_32F: gfx950 has no xf32 path) -- same arithmetic class as sr_conv.hip.
 // The handle and the per-shape algorithm choices are process-wide caches (created on first use, under a mutex): the
-// one place where this library keeps state, never freed.
+// one place where this library keeps state, never freed.  The choice per shape is made by timing hipBLASLt's heuristic
+// candidates once (first call with that shape; it synchronises the stream then and only then).
 #include <hipblaslt/hipblaslt.h>
+
+#include <stdlib.h>
 
 #include <map>
 #include <mutex>
@@ -35,7 +38,15 @@ std::map<Key, Plan> g_plans;
 
 constexpr size_t kWorkspace = 32u << 20;
 
-bool make_plan(const Key& key, Plan& plan) {
+// Arguments of the call that creates a plan: the candidates hipBLASLt's heuristic returns are timed on them once.
+struct TuneArgs {
+  const float* in; const float* weight; const float* bias; const float* residual; float* out; void* workspace;
+  hipStream_t stream;
+};
+
+constexpr int kCandidates = 12;
+
+bool make_plan(const Key& key, Plan& plan, const TuneArgs& ta) {
   const int M = std::get<0>(key), Cin = std::get<1>(key), Cout = std::get<2>(key), in_sp = std::get<3>(key);
   const int out_sp = std::get<4>(key), res_sp = std::get<5>(key), act = std::get<6>(key), has_bias = std::get<7>(key);
   if (hipblasLtMatmulDescCreate(&plan.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return false;
@@ -59,14 +70,48 @@ bool make_plan(const Key& key, Plan& plan) {
   if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return false;
   const uint64_t ws = kWorkspace;
   hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws));
-  hipblasLtMatmulHeuristicResult_t res[1];
+  hipblasLtMatmulHeuristicResult_t res[kCandidates];
   int found = 0;
-  const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, plan.desc, plan.la, plan.lb, plan.lc, plan.ld, pref, 1,
-                                                             res, &found);
+  const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, plan.desc, plan.la, plan.lb, plan.lc, plan.ld, pref,
+                                                             kCandidates, res, &found);
   hipblasLtMatmulPreferenceDestroy(pref);
   if (st != HIPBLAS_STATUS_SUCCESS || found < 1) return false;
-  plan.algo = res[0].algo;
-  plan.workspace = res[0].workspaceSize;
+  int best = 0;
+  // The heuristic's first choice is tuned for large square-ish problems; the encoder's GEMMs are short-K / short-N with
+  // M = 2400 ... 38400.  Time the candidates once, on the caller's own buffers and stream (the output is simply written
+  // several times; C is the residual, never the output).  Skipped inside a stream capture (no synchronisation allowed
+  // there) and with SR_GEMM_AUTOTUNE=0.
+  const char* env = getenv("SR_GEMM_AUTOTUNE");
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(ta.stream, &cap);
+  if (found > 1 && !(env && atoi(env) == 0) && cap == hipStreamCaptureStatusNone) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+      if (ta.bias) hipblasLtMatmulDescSetAttribute(plan.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &ta.bias, sizeof(ta.bias));
+      const float alpha = 1.0f, beta = ta.residual ? 1.0f : 0.0f;
+      float best_ms = -1.0f;
+      for (int c = 0; c < found; ++c) {
+        if (res[c].workspaceSize > kWorkspace) continue;
+        bool ok = true;
+        for (int rep = 0; rep < 3 && ok; ++rep) {   // one warm-up, two timed
+          if (rep == 1) (void)hipEventRecord(e0, ta.stream);
+          ok = hipblasLtMatmul(g_handle, plan.desc, &alpha, ta.weight, plan.la, ta.in, plan.lb, &beta,
+                               ta.residual ? ta.residual : ta.out, plan.lc, ta.out, plan.ld, &res[c].algo, ta.workspace,
+                               kWorkspace, ta.stream) == HIPBLAS_STATUS_SUCCESS;
+        }
+        if (!ok) continue;
+        (void)hipEventRecord(e1, ta.stream);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+        if (best_ms < 0.0f || ms < best_ms) { best_ms = ms; best = c; }
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+  }
+  plan.algo = res[best].algo;
+  plan.workspace = res[best].workspaceSize;
   return true;
 }
 
@@ -92,7 +137,8 @@ extern "C" int sr_gemm1x1_nhwc_fwd(const float* in, int in_pix_stride, const flo
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
       Plan p{};
-      if (!make_plan(key, p)) return SR_ERR_UNSUPPORTED;
+      const TuneArgs ta = {in, weight, bias, residual, out, workspace, (hipStream_t)stream};
+      if (!make_plan(key, p, ta)) return SR_ERR_UNSUPPORTED;
       it = g_plans.emplace(key, p).first;
     }
     plan = it->second;
