@@ -4,7 +4,9 @@
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
 A "step" is one pass of the hot path over one batch of synthetic keyframes that are already
-resident in HBM.  One process per GPU (launched by torch.distributed.run for N > 1); keyframes
+resident in HBM.  One process per GPU: under torch.distributed.run the process is one rank; a plain
+`python bench.py --gpus N` (no WORLD_SIZE in the environment) launches the N ranks itself and fails
+loudly when fewer than N GPUs are visible -- it never reports an N-GPU line from one device.  Keyframes
 are independent, so ranks shard them with no data-path collective ("scaling": "weak"); the only
 exchange is the final gather of the depth maps to rank 0 over RCCL (inside the timed region).
 Rank 0 prints ONE JSON line; see DESIGN.md for the roofline / cpu_baseline definitions.
@@ -25,6 +27,39 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(n, argv, port=None):
+    """The one-node launch of N ranks (one process per GPU) the driver would use: torch.distributed.run, rendezvous on
+    127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def _shared_gpu():
+    """SR_BENCH_SHARED_GPU=1 (tests only): the N ranks share the visible GPU(s) round-robin and rendezvous over gloo
+    (RCCL refuses two ranks on one device) -- exercises the N > 1 job on a 1-GPU box.  Never a measurement."""
+    return os.environ.get("SR_BENCH_SHARED_GPU", "0") == "1"
+
+
+def _require_gpus(n):
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have == 0:
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if have < n and not _shared_gpu():
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (one rank per GPU; refusing to report a "
+                         f"{n}-GPU line from fewer devices)")
+    return have
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,19 +69,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) and return their exit code
+        _require_gpus(args.gpus)
+        import subprocess
+        raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:])))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    have = _require_gpus(world)
+    shared = _shared_gpu() and world > 1
+    local_dev = local_rank % have if shared else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import bench_workloads
     name = args.workload or bench_workloads.DEFAULT
@@ -67,7 +114,11 @@ def main():
         wl.finish(world)  # result gather to rank 0 (RCCL) -- part of the job
         barrier()
         elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dump = os.environ.get("SR_BENCH_DUMP")   # tests: the gathered result of the job, as rank 0 holds it
+    if dump and rank == 0 and getattr(wl, "gathered", None) is not None:
+        import numpy as np
+        np.save(dump, wl.gathered.cpu().numpy())
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -88,6 +139,8 @@ def main():
         "data": "synthetic",
         "config": wl.config(world),
     }
+    if shared:
+        out["config"]["parallelism"] += " -- SR_BENCH_SHARED_GPU test mode: ranks share a device over gloo, not a measurement"
     if rank == 0:
         with torch.inference_mode():
             if not args.no_roofline:

@@ -543,8 +543,9 @@ class HeroCfg4Stream(HeroCfg3):
     over the GPUs (keyframe i -> rank i mod world, sharding.shard_indices; reference loop test.py:257-280), batches of 8,
     and the depth map of EVERY keyframe gathered to rank 0 over RCCL (sharding.gather_results) inside the timed region.
     The stream has world x steps x 8 keyframes (2048 = the BASELINE config at 8 GPUs x 32 steps); keyframe i's images are
-    generated on the device from a generator seeded with i, its poses are the seeded DVMVS-like layout of
-    synthetic.poses with batch seed i // 8."""
+    generated on the device from a generator seeded with i, its cameras are synthetic.keyframe_poses (the DVMVS-like
+    layout with a rigid jitter seeded by i): a keyframe is the same data on whatever rank / in whatever batch it lands,
+    so the gathered result of N ranks equals the 1-rank result (tests/test_gpu_multirank.py)."""
     name = "hero_cfg4_stream"
 
     def __init__(self, dev, rank, max_batches=256):
@@ -555,6 +556,7 @@ class HeroCfg4Stream(HeroCfg3):
         self.src_Ks = torch.from_numpy(np.broadcast_to(Kmat, (self.B, self.K, 4, 4)).copy()).to(dev)
         self.cur_invK = torch.from_numpy(np.broadcast_to(invK, (self.B, 4, 4)).copy()).to(dev)
         self._pose_cache = {}
+        self._gen = torch.Generator(device=dev)
         self.results = []
         self.gathered = None
 
@@ -562,22 +564,30 @@ class HeroCfg4Stream(HeroCfg3):
         return stream_batch_ids(self.rank, self.world, self.B, self.max_batches, step)
 
     def _poses(self, ids):
-        key = ids[0]
-        hit = self._pose_cache.get(key)
+        hit = self._pose_cache.get(ids[0])
         if hit is None:
-            poses, extr = synthetic.poses(self.B, self.K, seed=key)
+            poses, extr = synthetic.keyframe_poses(ids, self.K)
             hit = (torch.from_numpy(poses).to(self.dev), torch.from_numpy(extr).to(self.dev))
-            self._pose_cache[key] = hit
+            self._pose_cache[ids[0]] = hit
         return hit
+
+    def keyframes(self, ids):
+        """Images and cameras of the keyframes `ids`: functions of the keyframe id alone, so a keyframe is the same
+        data whatever rank and batch it lands in (the gathered stream of N ranks equals the 1-rank stream)."""
+        cur = torch.empty((len(ids), 3, 4 * self.h, 4 * self.w), device=self.dev)
+        src = torch.empty((len(ids), self.K, 3, 4 * self.h, 4 * self.w), device=self.dev)
+        for j, i in enumerate(ids):
+            g = self._gen.manual_seed(int(i))
+            cur[j].normal_(generator=g)
+            src[j].normal_(generator=g)
+        poses, extr = self._poses(ids)
+        return cur, src, poses, extr
 
     def step(self, i=None):
         if i == 0 or i is None:
             self.results = []          # warm-up steps and the start of the timed region
         ids = self._batch_ids(0 if i is None else i)
-        g = torch.Generator(device=self.dev).manual_seed(ids[0])
-        cur = torch.randn((self.B, 3, 4 * self.h, 4 * self.w), generator=g, device=self.dev)
-        src = torch.randn((self.B, self.K, 3, 4 * self.h, 4 * self.w), generator=g, device=self.dev)
-        poses, extr = self._poses(ids)
+        cur, src, poses, extr = self.keyframes(ids)
         out = self.model.forward_tensors(cur, src, extr, poses, self.src_Ks, self.cur_invK, return_mask=True)
         self.last = out
         self.results.append(out["depth_pred_s0_b1hw"])

@@ -36,13 +36,21 @@ def gather_results(local: torch.Tensor, n_items: int, dst: int = 0, group=None) 
         pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 0)
     local = local.contiguous()
+    device = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo (the CPU-test / shared-GPU backend) has no device-tensor gather: stage through host memory.  RCCL
+        # ("nccl") gathers the device buffers directly over xGMI.
+        local = local.cpu()
     bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
     dist.gather(local, bufs, dst=dst, group=group)
     if rank != dst:
         return None
+    if bufs[0].device != device:
+        bufs = [b.to(device) for b in bufs]
+        local = bufs[0]
     out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     for r in range(world):
-        idx = shard_indices(n_items, r, world)
-        if idx:
-            out[torch.as_tensor(idx, device=local.device)] = bufs[r][:len(idx)]
+        cnt = len(range(r, n_items, world))
+        if cnt:
+            out[r::world] = bufs[r][:cnt]      # keyframe i lives on rank i mod world: a strided copy, no index tensor
     return out

@@ -71,6 +71,27 @@ def poses(B, K, seed=0, jitter=0.02):
     return src_poses.astype(np.float32), src_extr.astype(np.float32)
 
 
+def keyframe_poses(ids, K, jitter=0.02):
+    """Poses of the keyframes of a STREAM: a function of the keyframe id alone (so that a keyframe gets the same
+    cameras whatever rank / batch it lands in): the §8d layout composed with a small rigid jitter seeded by the id.
+    Returns (src_poses, src_extrinsics), [len(ids),K,4,4] fp32."""
+    base = np.zeros((K, 4, 4))
+    for k in range(K):
+        T = _rot_y(0.05 * (k + 1))
+        T[:3, 3] = np.array([0.10, -0.03, 0.02]) * (k + 1)
+        base[k] = T
+    src_poses = np.zeros((len(ids), K, 4, 4))
+    for j, i in enumerate(ids):
+        rng = np.random.default_rng(500000 + int(i))
+        for k in range(K):
+            J = np.eye(4)
+            J[:3, :3] = _small_rot(rng, jitter)
+            J[:3, 3] = rng.normal(size=3) * jitter
+            src_poses[j, k] = J @ base[k]
+    src_extr = np.linalg.inv(src_poses)
+    return src_poses.astype(np.float32), src_extr.astype(np.float32)
+
+
 def cost_volume_inputs(B, K, C, h, w, seed=0, device="cpu", jitter=0.02):
     """Keyword arguments of CostVolumeManager.forward (reference cost_volume.py:345-357)."""
     rng = np.random.default_rng(seed)

@@ -1,0 +1,48 @@
+"""bench.py's N > 1 entry point: a plain `python bench.py --gpus N` must either launch N ranks or
+fail loudly -- it must never print a line for fewer GPUs than asked."""
+import json
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SR_BENCH_SHARED_GPU")}
+    return env
+
+
+def test_launch_command_is_one_rank_per_gpu_on_loopback():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "5"], port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5"]
+
+
+def test_gpus_2_without_torchrun_never_reports_one_gpu():
+    """On a box with fewer than 2 GPUs (this container: none) the command exits non-zero with the reason and prints
+    no JSON line at all; with >= 2 GPUs it would have become the launcher of 2 ranks."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU" in (r.stderr + r.stdout)
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            assert json.loads(line).get("n_gpus") != 1, "bench.py --gpus 2 reported a 1-GPU line"
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
