@@ -138,14 +138,15 @@ class _ConvBiasAct(torch.autograd.Function):
             d_x = d_w = None
             gsb, gsp = _strides(gp)
             if need_w and b > 0:
-                d_w = torch.empty_like(weight)
+                # dense [Co][Ci][k][k]: what sr_conv_wgrad_nhwc writes -- NOT empty_like (a channels_last weight's strides)
+                d_w = torch.empty(weight.shape, dtype=torch.float32, device=dev)
                 xsb, xsp = _strides(x)
                 nws = lib.sr_conv_wgrad_workspace_bytes(b, h, w, ci, co, k, s)
                 ws = _workspace(dev, "wgrad", nws)
                 _lib.check(lib.sr_conv_wgrad_nhwc(_lib.ptr(x), xsb, xsp, _lib.ptr(gp), gsb, gsp, _lib.ptr(d_w), b, h, w, ci,
                                                   co, k, s, _lib.ptr(ws), nws, st), "sr_conv_wgrad_nhwc")
             elif need_w:
-                d_w = torch.zeros_like(weight)
+                d_w = torch.zeros(weight.shape, dtype=torch.float32, device=dev)
             if want_b and d_b is None:
                 d_b = torch.empty((co,), dtype=torch.float32, device=dev)
                 _lib.check(lib.sr_bias_grad_nhwc(_lib.ptr(gp), gsb, gsp, _lib.ptr(d_b), b, ho, wo, co, st),

@@ -9,11 +9,11 @@ parameter/buffer names as the reference (cost_volume.py:13-380 `CostVolumeManage
 works exactly like the reference's own `to_fast()` seam (reference test.py:196-198) and a
 reference checkpoint loads with strict=True.  The arithmetic runs in hand-written gfx950
 kernels reached through the C ABI of include/simplerecon_hip.h; there is no torch/CPU
-fallback (inputs must be fp32 device tensors).  Inference everywhere; in addition both cost volumes have HIP
-backward kernels behind torch.autograd.Functions -- the first piece of the training path (SURVEY.md §8f "next" #3):
-the dot-product `CostVolumeManager` w.r.t. the matching features (`_DotVolumeFunction`), and, opt-in through
-`manager.differentiable = True`, the metadata-MLP `FeatureVolumeManager` w.r.t. the matching features and the six
-MLP tensors (`_MlpVolumeFunction`).
+fallback (inputs must be fp32 device tensors).  Both cost volumes have HIP backward kernels behind
+torch.autograd.Functions (SURVEY.md §8f "next" #3), taken whenever grad mode is on and an input or parameter requires
+grad -- like any torch module: the dot-product `CostVolumeManager` w.r.t. the matching features
+(`_DotVolumeFunction`), the metadata-MLP `FeatureVolumeManager` w.r.t. the matching features and the six MLP tensors
+(`_MlpVolumeFunction`).  `manager.differentiable = False` opts out (inputs that require grad are then refused).
 """
 import ctypes as C
 
@@ -148,7 +148,7 @@ class _MlpVolumeFunction(torch.autograd.Function):
 class CostVolumeManager(nn.Module):
     """Dot-product plane-sweep volume (reference cost_volume.py:13-380)."""
 
-    differentiable = True   # HIP backward for cur_feats / src_feats (the MLP managers are inference-only so far)
+    differentiable = True   # HIP backward for cur_feats / src_feats (and, in the MLP managers, the six MLP tensors)
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, matching_dim_size=None,
                  num_source_views=None):
@@ -354,10 +354,11 @@ class FeatureVolumeManager(CostVolumeManager):
     `mlp_channels` is taken BY VALUE (the reference mutates a shared default list,
     cost_volume.py:402, 429 -- harmless there, not replicated)."""
 
-    # The MLP sweep has a HIP backward (csrc/sr_mlp_volume_bwd.hip, gradients = the reference's autograd) but it is
-    # OPT-IN for now (`manager.differentiable = True`): nn.Parameters require grad by default, so turning it on makes
-    # every grad-enabled call build an autograd graph, and the conv stack / encoders around it are inference-only.
-    differentiable = False
+    # The MLP sweep has a HIP backward (csrc/sr_mlp_volume_bwd.hip, gradients = the reference's autograd): a swapped-in
+    # manager trains under the reference's train.py like the torch one it replaces.  As with any nn.Module, a call in
+    # grad mode with parameters that require grad builds an autograd graph; inference runs under no_grad /
+    # inference_mode (reference test.py:210).
+    differentiable = True
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=(202, 128, 128, 1),
                  matching_dim_size=16, num_source_views=7):
@@ -459,12 +460,16 @@ class FastFeatureVolumeManager(FeatureVolumeManager):
 
 
 def to_hip(manager):
-    """Builds the HIP-backed twin of a REFERENCE manager instance (or of one of ours), sharing
-    its MLP and buffers -- the attribute-swap seam of reference test.py:196-198:
+    """Builds the HIP-backed twin of a REFERENCE manager instance (or of one of ours) -- the attribute-swap seam of
+    reference test.py:196-198:
 
         model.cost_volume = simplerecon_amd.cost_volume.to_hip(model.cost_volume)
-    """
+
+    Like the reference's own `to_fast()` (cost_volume.py:739-746) the twin SHARES the matching MLP module with the
+    manager it was built from (same nn.Parameters: an optimizer / checkpoint that holds them keeps working); a
+    `FastFeatureVolumeManager` comes back as a `FastFeatureVolumeManager`."""
     h, w, d = manager.matching_height, manager.matching_width, manager.num_depth_bins
+    dev = manager.linear_ramp_1d11.device
     if hasattr(manager, "mlp"):
         lin = [m for m in manager.mlp.net if isinstance(m, nn.Linear)]
         cin = lin[0].in_features
@@ -472,11 +477,13 @@ def to_hip(manager):
         # C(1+K) + 10K + 4 = cin; recover (C, K) from the attributes when present, else assume C = 16
         c = getattr(manager, "matching_dim_size", 16)
         k = (cin - c - 4) // (c + 10)
-        new = FeatureVolumeManager(h, w, num_depth_bins=d, mlp_channels=chans, matching_dim_size=c,
-                                   num_source_views=k)
-        new.mlp.load_state_dict(manager.mlp.state_dict())
+        cls = FastFeatureVolumeManager if "Fast" in type(manager).__name__ else FeatureVolumeManager
+        new = cls(h, w, num_depth_bins=d, mlp_channels=chans, matching_dim_size=c, num_source_views=k)
+        new.to(dev)
+        new.mlp = manager.mlp       # shared, not copied
     else:
-        new = CostVolumeManager(h, w, num_depth_bins=d)
+        new = CostVolumeManager(h, w, num_depth_bins=d).to(dev)
     new.linear_ramp_1d11.copy_(manager.linear_ramp_1d11)
-    dev = manager.linear_ramp_1d11.device
-    return new.to(dev)
+    if hasattr(manager, "volume_memory_format"):
+        new.volume_memory_format = manager.volume_memory_format
+    return new

@@ -118,6 +118,9 @@ struct SrMlpParams {
   int chunk, chunks;      // planes per work unit, ceil(D / chunk)
   float inv_w, inv_h, slope;
   int debug;              // ablation bits (env SR_MLP_DEBUG), 0 in production
+  int vec_store;          // channels-last volume (plane stride 1): a lane keeps the costs of its unit's planes and
+                          // stores them as 16-byte pieces at the end of the unit (instead of one 4-byte store per plane
+                          // into 64 different 256-byte rows: r02 PMC counted 6.7x the volume's bytes in WRITE_SIZE)
 };
 
 __device__ __forceinline__ void sr_swap_halves(float fa, float fb, float& bP, float& bQ) {
@@ -330,6 +333,14 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
     }
 #define SR_SB __builtin_amdgcn_sched_barrier(0);
 
+    // costs of this unit's planes, kept until the 16-byte stores at its end: in registers (select chain), or -- in the
+    // variants that stream W1 and have neither registers nor a full LDS -- in a wave-private LDS strip
+    constexpr bool CST_LDS = !W1_LDS;
+    const int cst_base = SR_LDS_W3_FLOATS + W2_FLOATS +
+                         __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (SR_PLANE_CHUNK * 64);   // scalar
+    float cst[SR_PLANE_CHUNK];
+#pragma unroll
+    for (int q = 0; q < SR_PLANE_CHUNK; ++q) cst[q] = 0.0f;
 #pragma unroll 1
     for (int j = j0; j < j1; ++j) {
       d = plane_ptr[j * p.planes.sd];
@@ -450,9 +461,32 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
       oQ += __shfl_xor(oQ, 32);
       const float cost = (half ? oQ : oP) + lds[128];
 
+      if (p.vec_store) {
+        if (CST_LDS) lds[cst_base + (j - j0) * 64 + lane] = cost;
+        else {
+#pragma unroll
+          for (int q = 0; q < SR_PLANE_CHUNK; ++q) cst[q] = (j - j0 == q) ? cost : cst[q];
+        }
+      }
       if (active) {
-        p.out.cv[b * p.out.sb + j * p.out.sd + (int64_t)pix * p.out.sp] = cost;
+        if (!p.vec_store) p.out.cv[b * p.out.sb + j * p.out.sd + (int64_t)pix * p.out.sp] = cost;
         if (j == p.D - 1 && p.out.mask) p.out.mask[(size_t)b * N + pix] = (uint8_t)(any_depth && any_bounds);
+      }
+    }
+    if (p.vec_store && active) {   // planes j0 .. j1-1 of this pixel are consecutive floats (host checked the alignment)
+      float* row = p.out.cv + b * p.out.sb + (int64_t)pix * p.out.sp + j0;
+      if (CST_LDS) {
+#pragma unroll
+        for (int q = 0; q < SR_PLANE_CHUNK; ++q) cst[q] = lds[cst_base + q * 64 + lane];   // this lane's own writes: no barrier
+      }
+#pragma unroll
+      for (int q = 0; q < SR_PLANE_CHUNK; q += 4) {
+        if (j0 + q + 4 <= j1) *reinterpret_cast<float4*>(row + q) = make_float4(cst[q], cst[q + 1], cst[q + 2], cst[q + 3]);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (j0 + q + i < j1) row[q + i] = cst[q + i];
+        }
       }
     }
   }
@@ -543,6 +577,9 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
     p.chunk = best;
     p.chunks = (D + best - 1) / best;
   }
+  p.vec_store = (cv_sd == 1) && (p.chunk % 4 == 0) && (cv_sp % 4 == 0) && (cv_sb % 4 == 0) &&
+                (((uintptr_t)out_cv & 15) == 0);
+  { const char* e = getenv("SR_MLP_VEC_STORE"); if (e && atoi(e) == 0) p.vec_store = 0; }   // ablation
   const long nunits = (long)B * p.tiles * p.chunks;
   const int blocks = (int)((nunits + 3) / 4 < cus ? (nunits + 3) / 4 : cus);
   const size_t w3_bytes = SR_LDS_W3_FLOATS * sizeof(float);
@@ -558,7 +595,7 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
   }
   if (w1_bytes + w2_bytes + w3_bytes <= lds_max) SR_MLP_LAUNCH(true, true, w1_bytes + w2_bytes + w3_bytes)
   else if (w1_bytes + w3_bytes <= lds_max) SR_MLP_LAUNCH(true, false, w1_bytes + w3_bytes)
-  else SR_MLP_LAUNCH(false, true, w2_bytes + w3_bytes)
+  else SR_MLP_LAUNCH(false, true, w2_bytes + w3_bytes + 4 * SR_PLANE_CHUNK * 64 * sizeof(float))
 #undef SR_MLP_LAUNCH
   int rc = sr_hip_rc(hipGetLastError());
   if (rc) return rc;

@@ -17,6 +17,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SR_WINO_PD 3   // prefetch distance in steps (< NB)
 #endif
 
+#ifndef SR_WINO_REGV
+#define SR_WINO_REGV 1   // 1: the input transform feeds the MFMA A operands from registers; 0: through the V array in LDS
+#endif
+
 #define WN_TR 4
 #define WN_TC 8
 #define WN_PH (2 * WN_TR + 2)  // 10 patch rows
@@ -55,6 +59,7 @@ struct SrWinoParams {
   // activation) to part + ks * part_stride (dense channels-last [B, H*W, Cout]); sr_wino_reduce_kernel finishes.
   int ksplit; float* part; int64_t part_stride;
   int stagger;  // shader cycles the second workgroup of a CU waits before its first region (0 = off)
+  int xcd_order;   // 1: items of a round are dealt to the XCDs in contiguous eighths (SR_WINO_XCD, default 1)
   int stagger_cu;  // ablation: every workgroup waits a pseudo-random part of this many cycles first (de-phases the CUs)
 #ifdef SR_WINO_TRACE
   unsigned long long* trace;  // [blocks][SR_TR_REGIONS][SR_TR_EVENTS] shader-clock stamps (debug builds only)

@@ -124,6 +124,12 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #endif
   const int t_ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1), t_rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
   const float t_sign = wave == 1 ? 1.0f : -1.0f;
+#if SR_WINO_REGV
+  // Register-V variant: lane (i, kk) transforms tile i (= the MFMA row it feeds) for the channel quads 2g + kk, g = 0, 1
+  // -- exactly the A operands of its own MFMAs, so V never goes through LDS (no ds_write / ds_read round trip, and the
+  // transform of the second 8-channel group is issued under the MFMAs of the first).  Patch offset of tile i, quad kk:
+  const int rv_base = ((2 * (i >> 3)) * WN_PW + 2 * (i & 7)) * WN_ROW + 4 * kk;
+#endif
 
 #ifdef SR_WINO_TRACE
   int tr_region = -1;
@@ -135,7 +141,17 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
 #endif
   // Region coordinates of a work item and the per-thread staging offsets of its 10x18 input patch.
   struct Region { int b, oy0, ox0, co0, ks; };
+  // XCD-aware work order.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and each XCD has its own L2.  In round r
+  // the grid works on items [r G, (r + 1) G): give XCD x the CONTIGUOUS eighth [r G + x G/8, r G + (x + 1) G/8) of them
+  // (consecutive items are horizontally adjacent regions, G/8 of them about three region rows), so that the halo
+  // pixels two neighbouring regions share are fetched into ONE L2 instead of two (r02 PMC: 1.40x the algorithmic
+  // bytes).  The last, partial round keeps the plain order.
+  const int xcd_g = (int)gridDim.x;
   auto decode = [&](int wk) {
+    if (p.xcd_order && (xcd_g & 7) == 0) {
+      const int r0 = wk / xcd_g * xcd_g;
+      if (r0 + xcd_g <= p.total) { const int bb = wk - r0; wk = r0 + (bb & 7) * (xcd_g >> 3) + (bb >> 3); }
+    }
     Region r;
     r.ks = wk % p.ksplit; wk /= p.ksplit;
     const int cb = wk % p.co_blocks; wk /= p.co_blocks;
@@ -189,7 +205,11 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     };
     const float4* wu4 = nullptr;
     auto load_b = [&](int ch, int s, float4 (&dst)[NT]) {
+#if SR_WINO_REGV
+      const int xi = 4 * wave + (s & 3), g = s >> 2;   // register-V order: all four frequencies of group g = 0, then g = 1
+#else
       const int xi = 4 * wave + (s >> 1), g = s & 1;
+#endif
       const float4* wrec = wu4 + (SR_WN_DBG(32) ? (int64_t)0 : (int64_t)(xi * p.G + 2 * ch + g) * rec);
 #pragma unroll
       for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
@@ -247,6 +267,66 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
           __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
+#if SR_WINO_REGV
+      // ---- T + M, register-V form.  rv_col(g, c): row `ur = wave` of B^T d at patch column c, channel quad 2g + kk;
+      // rv_out: the four frequencies uc = 0..3 of that row = the A operands of steps (g, uc).  Same operations on the
+      // same values as the LDS form below -> bit-identical results.
+      const float* raw = (ch & 1) ? rawA : rawB;
+      auto rv_col = [&](int g, int c) {
+        const float4 da = *reinterpret_cast<const float4*>(&raw[rv_base + 8 * g + (t_ra * WN_PW + c) * WN_ROW]);
+        const float4 db = *reinterpret_cast<const float4*>(&raw[rv_base + 8 * g + (t_rb * WN_PW + c) * WN_ROW]);
+        const wn_f2 sg = {t_sign, t_sign};
+        const wn_f2 lo = __builtin_elementwise_fma(sg, wn_f2{db.x, db.y}, wn_f2{da.x, da.y});
+        const wn_f2 hi = __builtin_elementwise_fma(sg, wn_f2{db.z, db.w}, wn_f2{da.z, da.w});
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+      };
+      float4 av[2][4];   // A operands: [g][uc]
+      {
+        const float4 w0 = rv_col(0, 0), w1 = rv_col(0, 1), w2 = rv_col(0, 2), w3 = rv_col(0, 3);
+        av[0][0] = f4sub(w0, w2); av[0][1] = f4add(w1, w2); av[0][2] = f4sub(w2, w1); av[0][3] = f4sub(w1, w3);
+      }
+      if (ch < 5) SR_TR(2 + 2 * ch);
+      float4 wq[4];
+      if (!SR_WN_DBG(8))
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        const int cbuf = s % NB, g = s >> 2, uc = s & 3;
+        const float4 a = av[g][uc];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[uc][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b_f[cbuf][n].x, acc[uc][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + PD < STEPS) load_b(sl0 + ch, s + PD, b_f[(s + PD) % NB]);
+        else if (more) load_b(sl0 + ch + 1, s + PD - STEPS, b_f[(s + PD) % NB]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[uc][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b_f[cbuf][n].y, acc[uc][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // the transform of channel group 1, one patch column per step of group 0 (LDS latency << a step's 8 MFMAs)
+        if (s < 4) wq[s] = rv_col(1, s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[uc][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b_f[cbuf][n].z, acc[uc][n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[uc][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b_f[cbuf][n].w, acc[uc][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 3) {
+          av[1][0] = f4sub(wq[0], wq[2]); av[1][1] = f4add(wq[1], wq[2]);
+          av[1][2] = f4sub(wq[2], wq[1]); av[1][3] = f4sub(wq[1], wq[3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ASYNC && s == 4 && (more || has_next)) {   // early hand-over of the next slab -- AFTER this wave's last read
+          stage_store(stg, (ch & 1) ? rawB : rawA);    // of the current one (the reads of group 1 end with step 3)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          expected += 4;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#else
       // ---- T: this wave's row of V = B^T d B, all 32 tiles x 16 channels ----
       if (!SR_WN_DBG(2)) {
         const float* raw = (ch & 1) ? rawA : rawB;
@@ -318,6 +398,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#endif
       if (ch < 5) SR_TR(3 + 2 * ch);   // this wave's MFMAs issued (before the barrier)
       if (!ASYNC) {
         if (more || has_next) stage_store(stg, (ch & 1) ? rawB : rawA);
@@ -686,6 +767,7 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_WINO_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   { const char* e = getenv("SR_WINO_STAGGER"); p.stagger = e ? atoi(e) : 0; }
   { const char* e = getenv("SR_WINO_STAGGER_CU"); p.stagger_cu = e ? atoi(e) : 0; }
+  { const char* e = getenv("SR_WINO_XCD"); p.xcd_order = e ? atoi(e) : 1; }
   hipStream_t stream = (hipStream_t)stream_;
   int blocks = sr_wino_num_cus() * 2;
   { const char* e = getenv("SR_WINO_WG_PER_CU"); if (e && atoi(e) == 1) blocks = sr_wino_num_cus(); }  // ablation

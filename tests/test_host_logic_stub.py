@@ -71,7 +71,11 @@ def test_inference_paths(stub, cls, kw, fwd):
         assert (mask is None) == (not return_mask or cls is cv.CostVolumeManager)
         assert mask is None or mask.dtype == torch.bool
         assert stub[-1] == fwd
-    # grad mode on, parameters require grad, features do not: still the plain path, no autograd graph
+    # grad mode on: like any nn.Module, a manager whose parameters require grad builds an autograd graph (the MLP
+    # managers -- reference train.py trains the matching MLP); with no parameters and constant features it does not
+    assert mgr(**inp)[0].requires_grad == (cls is not cv.CostVolumeManager)
+    for p_ in mgr.parameters():
+        p_.requires_grad_(False)
     assert not mgr(**inp)[0].requires_grad
     # empty batch: nothing is launched
     empty = {k: (v[:0] if v.dim() > 0 and v.shape[0] == B and k not in ("min_depth", "max_depth") else v)
@@ -94,11 +98,13 @@ def test_autograd_seams(stub):
     assert src.grad.shape == src.shape
     with pytest.raises(NotImplementedError):
         dot(**dict(inp, src_Ks=inp["src_Ks"].clone().requires_grad_()))
-    # MLP model: refuses feature gradients until opted in
+    # MLP model: differentiable out of the box (a swapped-in manager trains under train.py); opting out refuses
     hero = cv.FeatureVolumeManager(H, W, num_depth_bins=D, num_source_views=K)
+    hero.differentiable = False
     with pytest.raises(NotImplementedError):
         hero(**dict(inp, cur_feats=cur))
-    hero.differentiable = True
+    del hero.differentiable
+    assert hero.differentiable
     cur.grad = None
     vol, lowest, _, mask = hero(**dict(inp, cur_feats=cur), return_mask=True)
     assert vol.requires_grad and not lowest.requires_grad and mask.dtype == torch.bool and not mask.requires_grad

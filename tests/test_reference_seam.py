@@ -48,7 +48,10 @@ def test_to_hip_of_a_reference_manager(ref, stub, kind, K):  # noqa: F811
     if kind == "dot":
         assert type(twin) is cv.CostVolumeManager and not hasattr(twin, "mlp")
     else:
-        assert isinstance(twin, cv.FeatureVolumeManager)
+        assert type(twin) is (cv.FastFeatureVolumeManager if kind == "fast" else cv.FeatureVolumeManager)
+        # shared like the reference's own to_fast() (cost_volume.py:739-746): the same module, the same nn.Parameters
+        assert twin.mlp is m.mlp
+        assert [id(p) for p in twin.mlp.parameters()] == [id(p) for p in m.mlp.parameters()]
         assert (twin.matching_dim_size, twin.num_source_views) == (16, K)          # recovered from the MLP width
         assert twin.mlp_channels == [cv.mlp_input_channels(16, K), 128, 128, 1]
         sd_ref, sd = m.mlp.state_dict(), twin.mlp.state_dict()
