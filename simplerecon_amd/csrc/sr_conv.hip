@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
       float* __restrict__ outp = partial ? p.part + t.ks * p.part_stride + (int64_t)t.b * p.Ho * p.Wo * p.Cout
                                          : p.out + (int64_t)t.b * p.out_sb;
       const int osp = partial ? p.Cout : p.out_sp, rsp = p.res_sp;
-      const float slope = partial ? SR_ACT_NONE : p.slope;
+      const float slope = sr_uniform(partial ? SR_ACT_NONE : p.slope);   // scalar: tested once per 16-value fragment
       const bool no_res = (resp == nullptr);
       // interior tiles (workgroup-uniform test) take a branch-free path
       const bool full = (t.oy0 + TH <= p.Ho) && (t.ox0 + CM <= p.Wo) && (t.co0 + 32 * NT <= p.Cout) && !SR_CV_DBG(1);
@@ -345,12 +345,14 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) rv[r] = 0.0f;
             }
+            float o16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o16[r] = acc[m][n][r] + bv + rv[r];
+            sr_activate_group(o16, slope);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
-              float v = acc[m][n][r] + bv + rv[r];
-              v = sr_activate(v, slope);
-              outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
+              outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = o16[r];
             }
           } else {
             bool ok[16];
@@ -360,12 +362,14 @@ __global__ __launch_bounds__(256) void sr_conv_kernel(SrConvParams p) {
               ok[r] = okc && (oyb + row < p.Ho) && (t.ox0 + colc + 4 * kk < p.Wo);
               if (!RES_PF) rv[r] = (!no_res && ok[r]) ? resp[rb + (unsigned)((row * p.Wo + colc) * rsp)] : 0.0f;
             }
+            float o16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o16[r] = acc[m][n][r] + bv + rv[r];
+            sr_activate_group(o16, slope);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int row = (8 * (r >> 2)) / CM, colc = (8 * (r >> 2)) % CM + (r & 3);
-              float v = acc[m][n][r] + bv + rv[r];
-              v = sr_activate(v, slope);
-              if (ok[r] && (!SR_CV_DBG(1) || v == 1.2345e33f)) outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = v;
+              if (ok[r] && (!SR_CV_DBG(1) || o16[r] == 1.2345e33f)) outp[ob + (unsigned)((row * p.Wo + colc) * osp)] = o16[r];
             }
           }
         }

@@ -80,10 +80,11 @@ __global__ __launch_bounds__(256) void sr_dwconv3x3_kernel(SrDwParams p) {
         float4 acc = bv;
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc = f4fma(v[u][t], wt[t], acc);
-        acc.x = sr_activate(acc.x, p.slope);
-        acc.y = sr_activate(acc.y, p.slope);
-        acc.z = sr_activate(acc.z, p.slope);
-        acc.w = sr_activate(acc.w, p.slope);
+        {
+          float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+          sr_activate_group(a4, sr_uniform(p.slope));
+          acc = make_float4(a4[0], a4[1], a4[2], a4[3]);
+        }
         *reinterpret_cast<float4*>(outb + (int64_t)opix[u] * p.out_sp) = acc;
         sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;
       }

@@ -1,5 +1,4 @@
-// sr_wino.h -- definitions shared by the two Winograd F(2x2, 3x3) kernels (sr_wino.hip: 4 waves, two workgroups per
-// CU; sr_wino8.hip: 8 waves, one workgroup per CU, transform / staging / epilogue issued between the MFMAs).
+// sr_wino.h -- definitions of the Winograd F(2x2, 3x3) kernel (sr_wino.hip: 4 waves, two workgroups per CU).
 #pragma once
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,8 +16,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SR_WINO_PD 3   // prefetch distance in steps (< NB)
 #endif
 
-#ifndef SR_WINO_REGV
-#define SR_WINO_REGV 1   // 1: the input transform feeds the MFMA A operands from registers; 0: through the V array in LDS
+#ifndef SR_WINO_PIPE
+#define SR_WINO_PIPE 1   // 1: next slab stored mid-slab, barrier after step 5, its first transform half under steps 6-7
 #endif
 
 #define WN_TR 4
@@ -27,12 +26,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WN_PW (2 * WN_TC + 2)  // 18 patch cols
 #define WN_ROW 20              // floats per staged pixel / per V row (16 channels + 4 pad)
 #define WN_RAW_FLOATS (WN_PH * WN_PW * WN_ROW)
-#define WN_V_FLOATS (16 * 32 * WN_ROW)
 #define WN_O_FLOATS (8 * 32 * 64)
-// V and the epilogue slab O share the first 64 KB; the raw patch lives behind them so that the NEXT region's first
-// slab can be staged while the current region finishes (its last MFMA phase and its epilogue): 78 KB, 2 per CU.
-#define WN_VO_FLOATS (WN_V_FLOATS + WN_RAW_FLOATS > WN_O_FLOATS ? WN_V_FLOATS + WN_RAW_FLOATS : WN_O_FLOATS)
-#define WN_LDS_FLOATS (WN_VO_FLOATS + WN_RAW_FLOATS + 4)   // + the slab hand-over counter of the ASYNC variant
+// Raw buffer A shares the first 64 KB with the epilogue slab O (A is dead by the epilogue); raw buffer B lives behind
+// them so that the NEXT region's first slab can be staged while the current region finishes (its last MFMA phase and
+// its epilogue): 78 KB, 2 workgroups per CU.
+#define WN_V_FLOATS (WN_O_FLOATS - WN_RAW_FLOATS)   // offset of raw A: the tail of the O area
+#define WN_VO_FLOATS WN_O_FLOATS
+#define WN_LDS_FLOATS (WN_VO_FLOATS + WN_RAW_FLOATS)
 #define WN_STAGE_ELEMS (WN_PH * WN_PW * 4)  // float4 elements per slab (720)
 #define WN_STAGE_PER_THREAD 3
 
@@ -58,9 +58,7 @@ struct SrWinoParams {
   // split-K: a work item covers 1/ksplit of the input slabs and stores its raw partial output (no bias / residual /
   // activation) to part + ks * part_stride (dense channels-last [B, H*W, Cout]); sr_wino_reduce_kernel finishes.
   int ksplit; float* part; int64_t part_stride;
-  int stagger;  // shader cycles the second workgroup of a CU waits before its first region (0 = off)
   int xcd_order;   // 1: items of a round are dealt to the XCDs in contiguous eighths (SR_WINO_XCD, default 1)
-  int stagger_cu;  // ablation: every workgroup waits a pseudo-random part of this many cycles first (de-phases the CUs)
 #ifdef SR_WINO_TRACE
   unsigned long long* trace;  // [blocks][SR_TR_REGIONS][SR_TR_EVENTS] shader-clock stamps (debug builds only)
 #endif
@@ -95,6 +93,3 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) {
 #endif
 
 
-// sr_wino8.hip: launches the 8-wave kernel on `blocks` workgroups; SR_ERR_UNSUPPORTED when the layer does not qualify.
-int sr_wino8_launch(const SrWinoParams& p, int blocks, hipStream_t stream);
-int sr_wino8_supported(const SrWinoParams& p, bool vout, int nt);

@@ -8,18 +8,22 @@
 //
 // A workgroup (4 waves, 2 workgroups per CU) owns a region of 4 x 8 Winograd tiles (= 8 x 16 output pixels = the 32
 // rows of one MFMA M-tile) x 32*NT output channels.  Per 16-channel slab of the input:
-//   S  the 10 x 18 pixel input patch is staged global -> registers -> LDS, double-buffered: slab c+1 is fetched at the
-//      top of slab c and stored at its end; with an even slab count the NEXT region's first slab follows the same way
-//      (it lands behind the V/O area, which the epilogue leaves alone),
-//   T  wave w applies B^T d B for frequency row ur = w -- exactly the rows it multiplies -- to all 32 tiles x 16
-//      channels -> its private quarter of V[16][32 tiles][16 ch]; no barrier between T and M, one per slab overall,
+//   S  the 10 x 18 pixel input patch is staged global -> registers -> LDS, double-buffered (raw A / raw B); with an even
+//      slab count the NEXT region's first slab follows the same way (it lands behind the O area, which the epilogue
+//      leaves alone),
+//   T  wave w applies B^T d B for frequency row ur = w -- exactly the rows it multiplies.  Lane (i, kk) transforms tile
+//      i for the channel quads 2g + kk, g = 0, 1: precisely the A operands of its own MFMAs, so V lives in REGISTERS
+//      (r03; it used to make a ds_write / ds_read round trip through a 40 KB V array).  The transform of group g = 1 is
+//      issued under the MFMAs of group 0, and (SR_WINO_PIPE) the transform of the NEXT slab's group 0 under the MFMAs of
+//      group 1: the next slab is stored to LDS at step 3, the slab barrier sits after step 5,
 //   M  wave w multiplies the 4 "frequencies" xi = 4w..4w+3:  M_xi[tile, co] += V_xi[tile, ci] . U_xi[ci, co]
-//      (A fragments: conflict-free ds_read_b128 on 20-float rows; U streams from L2 in B-fragment order,
-//      prefetched 3 steps ahead through 4 rotating register sets).
+//      (U streams from L2 in B-fragment order, prefetched 3 steps ahead through 4 rotating register sets).
 // Epilogue: the output transform is separable -- wave w holds a whole frequency row, so the column half (M A) happens
 // in registers and 2 of 4 values per (tile, channel) cross LDS (one 64-KB pass); a thread then owns (tile, 4 channels)
 // units: float4 residual loads, bias, LeakyReLU, float4 stores straight into the consumer's concat slice.
-// The live set (128 accumulator + 32 weight + 12 staging registers ...) fits 256 VGPRs without scratch spills.
+// The live set (128 accumulator + 32 weight + 32 operand + 12 staging registers ...) fits 256 VGPRs without scratch spills.
+#include <type_traits>
+
 #include "sr_wino.h"
 
 // U = G g G^T per (co, ci), stored in MFMA B-fragment order: element (xi, g8, kk, co, e) = U_xi[co][8*g8 + 4*kk + e]
@@ -53,51 +57,11 @@ __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-// ASYNC: the raw-patch hand-over between the four waves goes through an LDS arrival counter instead of a workgroup
-// barrier per slab.  Every wave stores its share of slab c+1 EARLY (during its MFMAs of slab c, three steps in) and then
-// bumps the counter; a wave starts the transform of slab c+1 once all four shares have arrived -- which, unless it is a
-// whole MFMA phase ahead of the slowest wave, they long have.  Waves of a workgroup sit on four different SIMDs, each
-// shared with a wave of the co-resident workgroup, and finish their MFMA phases at different times: with a barrier per
-// slab everyone waits for the slowest one every slab (the s_memtime trace showed ~21 k of a region's 59 k cycles in
-// that wait); now they drift by up to a slab and only meet at the epilogue.  Buffer reuse is safe by construction:
-// storing slab c+1 overwrites slab c-1, and a wave can only be in the MFMAs of slab c after all waves stored slab c,
-// which each does after its own transform of slab c-1.  Same arithmetic, bit-identical results.
-template <int NT, bool VEC4, bool VOUT, bool ASYNC>
+template <int NT, bool VEC4, bool VOUT>
 __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  unsigned* arrivals = reinterpret_cast<unsigned*>(lds + WN_VO_FLOATS + WN_RAW_FLOATS);
-  unsigned expected = 0;   // arrivals the next asynchronously staged slab needs (4 per slab)
-  if (ASYNC) {
-    if (threadIdx.x == 0) *arrivals = 0u;
-    __syncthreads();
-  }
-  // Phase stagger.  The two workgroups of a CU start together, do the same work and share each SIMD's matrix pipe
-  // fairly, so they stay in LOCKSTEP: both transform, both multiply (at half rate each), both run their epilogue --
-  // the pipe idles whenever they are in a non-MFMA phase together (a two-workgroup pipe-sharing model reproduces the
-  // measured 59 k-cycle region period from the phase lengths of the s_memtime trace).  Delaying the workgroup in the
-  // second wave slot of the SIMDs once, by about an epilogue + a transform, puts its non-MFMA phases under the other's
-  // MFMAs; the offset then persists (same region length for both).
-  if (p.stagger > 0) {
-    if (threadIdx.x == 0) {
-      const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u;  // HW_ID.WAVE_ID bit 0
-      if (slot) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)p.stagger) __builtin_amdgcn_s_sleep(32);
-      }
-    }
-    __syncthreads();
-  }
-  if (p.stagger_cu > 0) {   // ablation: start the workgroups of different CUs at different phases of a region
-    if (threadIdx.x == 0) {
-      const long long wait = (long long)(((blockIdx.x >> 1) * 2654435761u) >> 24) * p.stagger_cu / 256;
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-      while ((long long)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(32);
-    }
-    __syncthreads();
-  }
-  float* V = lds;                     // [16][32][20]
-  float* O = lds;                     // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases V and raw A)
-  float* rawA = lds + WN_V_FLOATS;    // [10*18][20]  odd slabs  (inside the V/O area: dead by the epilogue)
+  float* O = lds;                     // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases raw A)
+  float* rawA = lds + WN_V_FLOATS;    // [10*18][20]  odd slabs  (inside the O area: dead by the epilogue)
   float* rawB = lds + WN_VO_FLOATS;   // [10*18][20]  even slabs (behind it: survives the epilogue)
   const int tid = threadIdx.x;
   // (readfirstlane: the wave index is uniform, so everything derived from it -- the weight-record offsets of the MFMA
@@ -106,30 +70,16 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
   const int i = lane & 31, kk = lane >> 5;
   const int chunks = (p.G >> 1) / p.ksplit;  // input slabs per work item
   const int64_t rec = (int64_t)2 * p.Co_pad;
-  constexpr int STEPS = 8;            // (frequency, 8-channel group) steps per slab and wave
+  constexpr int STEPS = 8;            // (8-channel group, frequency) steps per slab and wave
   static_assert(8 % SR_WINO_NB == 0 && SR_WINO_PD < SR_WINO_NB, "the register rotation must line up across slabs");
   constexpr int NB = SR_WINO_NB, PD = SR_WINO_PD;  // weight prefetch: PD steps ahead through NB rotating register sets
 
-  // Transform-phase role: wave w produces the frequency ROW ur = w of V (the rows it alone multiplies), so V is
-  // wave-private and no barrier separates a wave's transform from its MFMAs.  Lane -> 4-channel group tq and tiles
-  // tt0, tt0 + 16.  Row ur of B^T d needs two patch rows: (0,2) d0-d2, (1,2) d1+d2, (2,1) d2-d1, (1,3) d1-d3.
-  // 16 lanes (one LDS access group of a 128-bit operation: 64 banks x 4 B) = 4 tiles x 4 channel quads.  Tiles j, j + 4,
-  // j + 8, j + 12 of a 16-tile group sit at patch offsets (160 j' B) and V offsets (80 j' B) whose 64-byte blocks fall on
-  // four different quarters of the 256-byte bank line; consecutive tiles overlap by 32 / 16 bytes (r02 PMC: 32 % of the
-  // LDS-active cycles of the transform were bank conflicts).  SR_WINO_TLINEAR keeps the old mapping (ablation build).
-#ifdef SR_WINO_TLINEAR
-  const int tq = lane & 3, tt0 = lane >> 2;
-#else
-  const int tq = lane & 3, tt0 = (((lane >> 2) & 3) << 2) | (lane >> 4);
-#endif
+  // Transform role: wave w produces the frequency ROW ur = w of V = B^T d B (the rows it alone multiplies).  Row ur of
+  // B^T d needs two patch rows: (0,2) d0-d2, (1,2) d1+d2, (2,1) d2-d1, (1,3) d1-d3.  Lane (i, kk) does it for tile i (the
+  // MFMA row it feeds) and the channel quads 2g + kk -- the A operands of its own MFMAs.
   const int t_ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1), t_rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
   const float t_sign = wave == 1 ? 1.0f : -1.0f;
-#if SR_WINO_REGV
-  // Register-V variant: lane (i, kk) transforms tile i (= the MFMA row it feeds) for the channel quads 2g + kk, g = 0, 1
-  // -- exactly the A operands of its own MFMAs, so V never goes through LDS (no ds_write / ds_read round trip, and the
-  // transform of the second 8-channel group is issued under the MFMAs of the first).  Patch offset of tile i, quad kk:
-  const int rv_base = ((2 * (i >> 3)) * WN_PW + 2 * (i & 7)) * WN_ROW + 4 * kk;
-#endif
+  const int rv_base = ((2 * (i >> 3)) * WN_PW + 2 * (i & 7)) * WN_ROW + 4 * kk;   // patch offset of tile i, quad kk
 
 #ifdef SR_WINO_TRACE
   int tr_region = -1;
@@ -175,50 +125,69 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
       offs[it] = ok ? (iy * p.W + ix) * p.in_sp + 4 * q : -1;
     }
   };
-    auto stage_load = [&](int c0, float4 (&stg)[WN_STAGE_PER_THREAD]) {
+  auto stage_load = [&](int c0, float4 (&stg)[WN_STAGE_PER_THREAD]) {
 #pragma unroll
-      for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
-        const int c = c0 + 4 * ((tid + it * 256) & 3);
-        const bool ok = (offs[it] >= 0) & (c < p.Cin) & !SR_WN_DBG(4);
-        const float* src = in_b + (ok ? offs[it] + c0 : 0);
-        if (VEC4) {
-          const float4 v = *reinterpret_cast<const float4*>(src);
-          stg[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok) {
-            v.x = src[0];
-            if (c + 1 < p.Cin) v.y = src[1];
-            if (c + 2 < p.Cin) v.z = src[2];
-            if (c + 3 < p.Cin) v.w = src[3];
-          }
-          stg[it] = v;
+    for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
+      const int c = c0 + 4 * ((tid + it * 256) & 3);
+      const bool ok = (offs[it] >= 0) & (c < p.Cin) & !SR_WN_DBG(4);
+      const float* src = in_b + (ok ? offs[it] + c0 : 0);
+      if (VEC4) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        stg[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          v.x = src[0];
+          if (c + 1 < p.Cin) v.y = src[1];
+          if (c + 2 < p.Cin) v.z = src[2];
+          if (c + 3 < p.Cin) v.w = src[3];
         }
+        stg[it] = v;
       }
-    };
-    auto stage_store = [&](const float4 (&stg)[WN_STAGE_PER_THREAD], float* raw) {
+    }
+  };
+  auto stage_store = [&](const float4 (&stg)[WN_STAGE_PER_THREAD], float* raw) {
 #pragma unroll
-      for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
-        const int e = tid + it * 256;
-        if (e < WN_STAGE_ELEMS) *reinterpret_cast<float4*>(&raw[(e >> 2) * WN_ROW + 4 * (e & 3)]) = stg[it];
-      }
-    };
-    const float4* wu4 = nullptr;
-    auto load_b = [&](int ch, int s, float4 (&dst)[NT]) {
-#if SR_WINO_REGV
-      const int xi = 4 * wave + (s & 3), g = s >> 2;   // register-V order: all four frequencies of group g = 0, then g = 1
-#else
-      const int xi = 4 * wave + (s >> 1), g = s & 1;
-#endif
-      const float4* wrec = wu4 + (SR_WN_DBG(32) ? (int64_t)0 : (int64_t)(xi * p.G + 2 * ch + g) * rec);
+    for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
+      const int e = tid + it * 256;
+      if (e < WN_STAGE_ELEMS) *reinterpret_cast<float4*>(&raw[(e >> 2) * WN_ROW + 4 * (e & 3)]) = stg[it];
+    }
+  };
+  const float4* wu4 = nullptr;
+  auto load_b = [&](int ch, int s, float4 (&dst)[NT]) {   // step s = (g, uc): all four frequencies of group 0, then group 1
+    const int xi = 4 * wave + (s & 3), g = s >> 2;
+    const float4* wrec = wu4 + (SR_WN_DBG(32) ? (int64_t)0 : (int64_t)(xi * p.G + 2 * ch + g) * rec);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
-    };
+    for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
+  };
+  // rv_col(raw, g, c): row `ur = wave` of B^T d at patch column c, channel quad 2g + kk; rv_row: the four frequencies
+  // uc = 0..3 of that row from its four columns = the A operands of steps (g, uc).
+  auto rv_fma = [&](const float4 da, const float4 db) {
+    const wn_f2 sg = {t_sign, t_sign};
+    const wn_f2 lo = __builtin_elementwise_fma(sg, wn_f2{db.x, db.y}, wn_f2{da.x, da.y});
+    const wn_f2 hi = __builtin_elementwise_fma(sg, wn_f2{db.z, db.w}, wn_f2{da.z, da.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+  };
+  auto rv_ld = [&](const float* raw, int g, int c, float4& da, float4& db) {
+    da = *reinterpret_cast<const float4*>(&raw[rv_base + 8 * g + (t_ra * WN_PW + c) * WN_ROW]);
+    db = *reinterpret_cast<const float4*>(&raw[rv_base + 8 * g + (t_rb * WN_PW + c) * WN_ROW]);
+  };
+  auto rv_col = [&](const float* raw, int g, int c) {
+    float4 da, db;
+    rv_ld(raw, g, c, da, db);
+    return rv_fma(da, db);
+  };
+  auto rv_row = [&](const float4 (&w)[4], float4 (&a)[4]) {
+    a[0] = f4sub(w[0], w[2]); a[1] = f4add(w[1], w[2]); a[2] = f4sub(w[2], w[1]); a[3] = f4sub(w[1], w[3]);
+  };
 
   // Software pipeline: slab c of a region sits in raw buffer (c odd ? A : B); slab c+1 is fetched into registers at
-  // the top of chunk c and stored at its end (one barrier per chunk).  With an even slab count the NEXT region's
-  // slab 0 follows the same way during the last chunk -- it lands in B, which the epilogue leaves alone, and is
-  // issued in front of the epilogue's stores (VMEM returns in order: waiting for it does not wait for them).
+  // the top of slab c.  SR_WINO_PIPE: it is stored to the other buffer after step 3 (the last read of this wave's own
+  // transform of slab c is in step 3, the other buffer's last readers finished a slab ago), the workgroup barrier sits
+  // after step 5, and steps 6 / 7 carry the transform of slab c+1's first channel group -- so a slab boundary costs no
+  // serial LDS latency chain.  Otherwise: stored at the end of slab c, barrier, transform at the top of slab c+1.
+  // With an even slab count the NEXT region's slab 0 follows the same way during the last slab -- it lands in B,
+  // which the epilogue leaves alone, and is issued in front of the epilogue's stores (VMEM returns in order).
   float4 stg[WN_STAGE_PER_THREAD];
   const bool chain = !(chunks & 1);
   bool staged = false;
@@ -231,7 +200,6 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     ++tr_region;
 #endif
     SR_TR(0);
-    bool slab_async = ASYNC && staged;   // slab 0 of this region was staged by the previous region's last chunk
     if (!staged) {
       aim(reg);
       stage_load(sl0 * 16, stg);
@@ -240,20 +208,27 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
     }
     staged = has_next;
 
+    // (not zeroed: the first MFMA into each accumulator takes the constant 0 as its C operand -- zeroing 128 registers
+    // cost 128 VALU instructions per region, each ~13 clocks while the co-resident workgroup keeps the matrix pipe busy)
     f32x16 acc[4][NT];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][n][r] = 0.0f;
 
-    float4 b_f[NB][NT], a_f[2];
+    float4 b_f[NB][NT];
 #pragma unroll
     for (int s = 0; s < PD; ++s) load_b(sl0, s, b_f[s]);
     SR_TR(1);
 
-    for (int ch = 0; ch < chunks; ++ch) {
+    float4 av[2][4];   // A operands of the current slab: [g][uc]
+    float4 wq[4];
+#if SR_WINO_PIPE
+    float4 pa[2], pb[2];   // patch rows on their way from LDS to the next slab's transform
+    {  // first slab of the region: its group 0 has no MFMAs to hide under
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wq[c] = rv_col(rawB, 0, c);
+      rv_row(wq, av[0]);
+    }
+#endif
+    auto slab = [&](auto first_tag, const int ch) {
+      constexpr bool FIRST = decltype(first_tag)::value;   // first slab of the region: accumulators start from 0
       const bool more = ch + 1 < chunks;
       if (more) stage_load((sl0 + ch + 1) * 16, stg);
       else if (has_next) {
@@ -261,40 +236,34 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         aim(nxt);
         stage_load(nxt.ks * chunks * 16, stg);
       }
-
-      if (ASYNC && slab_async) {   // all four waves' shares of this slab have landed in LDS?
-        while ((int)(__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - expected) < 0)
-          __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      }
-#if SR_WINO_REGV
-      // ---- T + M, register-V form.  rv_col(g, c): row `ur = wave` of B^T d at patch column c, channel quad 2g + kk;
-      // rv_out: the four frequencies uc = 0..3 of that row = the A operands of steps (g, uc).  Same operations on the
-      // same values as the LDS form below -> bit-identical results.
       const float* raw = (ch & 1) ? rawA : rawB;
-      auto rv_col = [&](int g, int c) {
-        const float4 da = *reinterpret_cast<const float4*>(&raw[rv_base + 8 * g + (t_ra * WN_PW + c) * WN_ROW]);
-        const float4 db = *reinterpret_cast<const float4*>(&raw[rv_base + 8 * g + (t_rb * WN_PW + c) * WN_ROW]);
-        const wn_f2 sg = {t_sign, t_sign};
-        const wn_f2 lo = __builtin_elementwise_fma(sg, wn_f2{db.x, db.y}, wn_f2{da.x, da.y});
-        const wn_f2 hi = __builtin_elementwise_fma(sg, wn_f2{db.z, db.w}, wn_f2{da.z, da.w});
-        return make_float4(lo.x, lo.y, hi.x, hi.y);
-      };
-      float4 av[2][4];   // A operands: [g][uc]
-      {
-        const float4 w0 = rv_col(0, 0), w1 = rv_col(0, 1), w2 = rv_col(0, 2), w3 = rv_col(0, 3);
-        av[0][0] = f4sub(w0, w2); av[0][1] = f4add(w1, w2); av[0][2] = f4sub(w2, w1); av[0][3] = f4sub(w1, w3);
+      float* raw_next = (ch & 1) ? rawB : rawA;
+#if !SR_WINO_PIPE
+      if (!SR_WN_DBG(2)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wq[c] = rv_col(raw, 0, c);
+        rv_row(wq, av[0]);
       }
+#endif
       if (ch < 5) SR_TR(2 + 2 * ch);
-      float4 wq[4];
+
+      // ---- M: this wave's 4 frequencies x 2 channel groups (same products in the same order as ever: bit-identical) ----
       if (!SR_WN_DBG(8))
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const int cbuf = s % NB, g = s >> 2, uc = s & 3;
         const float4 a = av[g][uc];
+        // k-step outer, N-tile inner: consecutive MFMAs hit different accumulators.  The prefetches of later steps and
+        // the transform pieces sit BETWEEN the MFMA pairs, where the wave has idle issue cycles; sched_barrier pins them.
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[uc][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b_f[cbuf][n].x, acc[uc][n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) {
+          if (FIRST && s < 4) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[uc][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b_f[cbuf][n].x, zero, 0, 0, 0);
+          } else {
+            acc[uc][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b_f[cbuf][n].x, acc[uc][n], 0, 0, 0);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (s + PD < STEPS) load_b(sl0 + ch, s + PD, b_f[(s + PD) % NB]);
         else if (more) load_b(sl0 + ch + 1, s + PD - STEPS, b_f[(s + PD) % NB]);
@@ -303,8 +272,16 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         for (int n = 0; n < NT; ++n)
           acc[uc][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b_f[cbuf][n].y, acc[uc][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        // the transform of channel group 1, one patch column per step of group 0 (LDS latency << a step's 8 MFMAs)
-        if (s < 4) wq[s] = rv_col(1, s);
+        // steps 0-3: one patch column of this slab's channel group 1 each (LDS latency << a step's 8 MFMAs)
+        if (s < 4) wq[s] = rv_col(raw, 1, s);
+#if SR_WINO_PIPE
+        // steps 6, 7: the next slab's channel group 0 (its patch was stored at step 3, barrier after step 5); the LDS
+        // reads are issued one slot before their use.  Unconditional (no branch in the MFMA stream): after the last slab
+        // of a region the values are simply not used.
+        if (s == 6) { wq[0] = rv_fma(pa[0], pb[0]); wq[1] = rv_fma(pa[1], pb[1]);
+                      rv_ld(raw_next, 0, 2, pa[0], pb[0]); rv_ld(raw_next, 0, 3, pa[1], pb[1]); }
+        if (s == 7) { wq[2] = rv_fma(pa[0], pb[0]); wq[3] = rv_fma(pa[1], pb[1]); }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -314,100 +291,30 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
           acc[uc][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b_f[cbuf][n].w, acc[uc][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (s == 3) {
-          av[1][0] = f4sub(wq[0], wq[2]); av[1][1] = f4add(wq[1], wq[2]);
-          av[1][2] = f4sub(wq[2], wq[1]); av[1][3] = f4sub(wq[1], wq[3]);
+          rv_row(wq, av[1]);
+#if SR_WINO_PIPE
+          stage_store(stg, raw_next);   // unconditional: after the last slab of the last region it stores stale registers
+#endif                                  // into a buffer nobody reads before it is restaged
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (ASYNC && s == 4 && (more || has_next)) {   // early hand-over of the next slab -- AFTER this wave's last read
-          stage_store(stg, (ch & 1) ? rawB : rawA);    // of the current one (the reads of group 1 end with step 3)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (lane == 0) __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          expected += 4;
+#if SR_WINO_PIPE
+        if (s == 5) {   // every wave has stored its share of the next slab and finished reading this one
+          __syncthreads();
+          rv_ld(raw_next, 0, 0, pa[0], pb[0]); rv_ld(raw_next, 0, 1, pa[1], pb[1]);
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
-#else
-      // ---- T: this wave's row of V = B^T d B, all 32 tiles x 16 channels ----
-      if (!SR_WN_DBG(2)) {
-        const float* raw = (ch & 1) ? rawA : rawB;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int tt = tt0 + 16 * j;
-          const int base = ((2 * (tt >> 3)) * WN_PW + 2 * (tt & 7)) * WN_ROW + 4 * tq;
-          float4 wv[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float4 da = *reinterpret_cast<const float4*>(&raw[base + (t_ra * WN_PW + c) * WN_ROW]);
-            const float4 db = *reinterpret_cast<const float4*>(&raw[base + (t_rb * WN_PW + c) * WN_ROW]);
-#ifdef SR_WINO_NOPK
-            wv[c] = make_float4(fmaf(t_sign, db.x, da.x), fmaf(t_sign, db.y, da.y), fmaf(t_sign, db.z, da.z),
-                                fmaf(t_sign, db.w, da.w));
-#else
-            const wn_f2 sg = {t_sign, t_sign};
-            const wn_f2 lo = __builtin_elementwise_fma(sg, wn_f2{db.x, db.y}, wn_f2{da.x, da.y});
-            const wn_f2 hi = __builtin_elementwise_fma(sg, wn_f2{db.z, db.w}, wn_f2{da.z, da.w});
-            wv[c] = make_float4(lo.x, lo.y, hi.x, hi.y);
 #endif
-          }
-          float* vrow = V + ((4 * wave) * 32 + tt) * WN_ROW + 4 * tq;
-          *reinterpret_cast<float4*>(vrow + 0 * 32 * WN_ROW) = f4sub(wv[0], wv[2]);
-          *reinterpret_cast<float4*>(vrow + 1 * 32 * WN_ROW) = f4add(wv[1], wv[2]);
-          *reinterpret_cast<float4*>(vrow + 2 * 32 * WN_ROW) = f4sub(wv[2], wv[1]);
-          *reinterpret_cast<float4*>(vrow + 3 * 32 * WN_ROW) = f4sub(wv[1], wv[3]);
-        }
       }
-      if (ch < 5) SR_TR(2 + 2 * ch);
-
-      // ---- M: this wave's 4 frequencies x 2 channel groups ----
-      a_f[0] = *reinterpret_cast<const float4*>(&V[((4 * wave) * 32 + i) * WN_ROW + 4 * kk]);
-      if (!SR_WN_DBG(8))
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
-        const int cbuf = s % NB, ca = s & 1;
-        // k-step outer, N-tile inner: consecutive MFMAs hit different accumulators.  The prefetches of later steps
-        // (weight fragments, next A fragment) and their address arithmetic sit BETWEEN the MFMA pairs, where the
-        // wave has ~60 idle issue cycles per MFMA; clustered at the step boundary they overran that window.
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].x, b_f[cbuf][n].x, acc[s >> 1][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + PD < STEPS) load_b(sl0 + ch, s + PD, b_f[(s + PD) % NB]);
-        else if (more) load_b(sl0 + ch + 1, s + PD - STEPS, b_f[(s + PD) % NB]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].y, b_f[cbuf][n].y, acc[s >> 1][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < STEPS) {
-          const int xi = 4 * wave + ((s + 1) >> 1), g = (s + 1) & 1;
-          a_f[ca ^ 1] = *reinterpret_cast<const float4*>(&V[(xi * 32 + i) * WN_ROW + 8 * g + 4 * kk]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].z, b_f[cbuf][n].z, acc[s >> 1][n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[s >> 1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_f[ca].w, b_f[cbuf][n].w, acc[s >> 1][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ASYNC && s == 2 && (more || has_next)) {   // early hand-over of the next slab (see the kernel comment)
-          stage_store(stg, (ch & 1) ? rawB : rawA);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (lane == 0) __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          expected += 4;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+      if (ch < 5) SR_TR(3 + 2 * ch);   // this wave's MFMAs issued
+#if SR_WINO_PIPE
+      rv_row(wq, av[0]);
+#else
+      if (more || has_next) stage_store(stg, raw_next);
+      __syncthreads();
 #endif
-      if (ch < 5) SR_TR(3 + 2 * ch);   // this wave's MFMAs issued (before the barrier)
-      if (!ASYNC) {
-        if (more || has_next) stage_store(stg, (ch & 1) ? rawB : rawA);
-        __syncthreads();
-      } else {
-        slab_async = true;
-        if (!more) __syncthreads();   // the epilogue's exchange slab aliases every wave's V and raw A
-      }
-    }
+    };
+    slab(std::true_type{}, 0);
+    for (int ch = 1; ch < chunks; ++ch) slab(std::false_type{}, ch);
     SR_TR(12);
 
     // ---- epilogue: Y = A^T M A, + bias + residual, LeakyReLU, store ----
@@ -417,7 +324,7 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
                                        : p.out + (int64_t)b * p.out_sb;
     const unsigned out_sp = partial ? (unsigned)p.Cout : (unsigned)p.out_sp;
     const float* bias_p = partial ? nullptr : p.bias;
-    const float slope = partial ? -1.0f : p.slope;
+    const float slope = sr_uniform(partial ? -1.0f : p.slope);   // scalar: the activation code is tested once per group
     // Y = A^T M A is separable: wave w holds the whole frequency ROW ur = w (its 4 accumulators are the columns
     // uc = 0..3), so the column half (M A) is done in registers and only 2 of 4 values per (tile, channel) go
     // through LDS: O[ur][b][tile][co] (64 KB for both N-tiles -> one pass, two barriers).
@@ -454,17 +361,15 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
         for (int n = 0; n < NT; ++n) {
           // whole-vector arithmetic: packed fp32 adds, half the VALU instructions of the element-wise form (every VALU
           // instruction here costs matrix-pipe time of the co-resident workgroup)
-          {
-            const f32x16 c0 = (acc[0][n] + acc[1][n]) + acc[2][n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              O[((wave * 2 + 0) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CO + 32 * n + i] = c0[r];
-          }
-          {
-            const f32x16 c1 = (acc[1][n] - acc[2][n]) - acc[3][n];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              O[((wave * 2 + 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CO + 32 * n + i] = c1[r];
+          for (int r = 0; r < 16; r += 2) {   // register PAIRS spelled out: v_pk_add_f32 (the f32x16 form compiled to scalar adds)
+            const wn_f2 m0 = {acc[0][n][r], acc[0][n][r + 1]}, m1 = {acc[1][n][r], acc[1][n][r + 1]};
+            const wn_f2 m2 = {acc[2][n][r], acc[2][n][r + 1]}, m3 = {acc[3][n][r], acc[3][n][r + 1]};
+            const wn_f2 c0 = (m0 + m1) + m2, c1 = (m1 - m2) - m3;
+            float* o0 = &O[((wave * 2 + 0) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CO + 32 * n + i];
+            float* o1 = &O[((wave * 2 + 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CO + 32 * n + i];
+            o0[0] = c0.x; o0[CO] = c0.y;
+            o1[0] = c1.x; o1[CO] = c1.y;
           }
         }
         SR_TR(11);
@@ -483,15 +388,18 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
               t[ur][bb] = *reinterpret_cast<const float4*>(&O[((ur * 2 + bb) * 32 + tile) * CO + 4 * cg]);
           const float4 y[4] = {f4add(f4add(t[0][0], t[1][0]), t[2][0]), f4add(f4add(t[0][1], t[1][1]), t[2][1]),
                                f4sub(f4sub(t[1][0], t[2][0]), t[3][0]), f4sub(f4sub(t[1][1], t[2][1]), t[3][1])};
+          float o16[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float4 v = f4add(f4add(y[q], bv), rv[it][q]);
-            v.x = sr_activate(v.x, slope);
-            v.y = sr_activate(v.y, slope);
-            v.z = sr_activate(v.z, slope);
-            v.w = sr_activate(v.w, slope);
-            if (ok[it][q] && (!SR_WN_DBG(1) || v.x == 1.2345e33f))
-              *reinterpret_cast<float4*>(outp + (opix[it][q] * out_sp + cog)) = v;
+            const float4 v = f4add(f4add(y[q], bv), rv[it][q]);
+            o16[4 * q + 0] = v.x; o16[4 * q + 1] = v.y; o16[4 * q + 2] = v.z; o16[4 * q + 3] = v.w;
+          }
+          sr_activate_group(o16, slope);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (ok[it][q] && (!SR_WN_DBG(1) || o16[4 * q] == 1.2345e33f))
+              *reinterpret_cast<float4*>(outp + (opix[it][q] * out_sp + cog)) =
+                  make_float4(o16[4 * q], o16[4 * q + 1], o16[4 * q + 2], o16[4 * q + 3]);
           }
         }
 #ifdef SR_WINO_TRACE
@@ -545,12 +453,13 @@ __global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParam
             for (int bb = 0; bb < 2; ++bb) t[ur][bb] = O[((ur * 2 + bb) * 32 + tile) * CO + co];
           const float y[4] = {(t[0][0] + t[1][0]) + t[2][0], (t[0][1] + t[1][1]) + t[2][1],
                               (t[1][0] - t[2][0]) - t[3][0], (t[1][1] - t[2][1]) - t[3][1]};
+          float o4[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v = y[q] + bv + rv[it][q];
-            v = sr_activate(v, slope);
-            if (ok[it][q] && (!SR_WN_DBG(1) || v == 1.2345e33f)) outp[opix[it][q] * out_sp + cog] = v;
-          }
+          for (int q = 0; q < 4; ++q) o4[q] = y[q] + bv + rv[it][q];
+          sr_activate_group(o4, slope);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (ok[it][q] && (!SR_WN_DBG(1) || o4[q] == 1.2345e33f)) outp[opix[it][q] * out_sp + cog] = o4[q];
         }
         __syncthreads();
       }
@@ -574,11 +483,9 @@ __global__ __launch_bounds__(256) void sr_wino_reduce_kernel(const float* __rest
     for (int k = 1; k < ksplit; ++k) v = f4add(v, *reinterpret_cast<const float4*>(q + k * part_stride));
     if (bias) v = f4add(v, *reinterpret_cast<const float4*>(bias + 4 * c4));
     if (res) v = f4add(v, *reinterpret_cast<const float4*>(res + (int64_t)b * res_sb + px * res_sp + 4 * c4));
-    v.x = sr_activate(v.x, slope);
-    v.y = sr_activate(v.y, slope);
-    v.z = sr_activate(v.z, slope);
-    v.w = sr_activate(v.w, slope);
-    *reinterpret_cast<float4*>(out + (int64_t)b * out_sb + px * out_sp + 4 * c4) = v;
+    float o4[4] = {v.x, v.y, v.z, v.w};
+    sr_activate_group(o4, sr_uniform(slope));
+    *reinterpret_cast<float4*>(out + (int64_t)b * out_sb + px * out_sp + 4 * c4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
   }
 }
 
@@ -643,9 +550,6 @@ extern "C" int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int 
 //   max(rounds over the 2-per-CU slots x item length alone on a CU, items per CU x item length under sharing) (+ reduce),
 // item length ~ slabs + 2 (prologue / epilogue); constants fitted on r01 measurements, in units of a full NT = 2 item.
 struct SrWinoPlan { int nt, ks; };
-#ifndef SR_WINO8_DEFAULT
-#define SR_WINO8_DEFAULT 0
-#endif
 static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allow_split) {
   const int co_pad = ((Cout + 31) / 32) * 32;
   const int slabs = (Cin + 15) / 16;
@@ -656,11 +560,8 @@ static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allo
   const long cus = sr_wino_num_cus(), slots = 2 * cus;
   SrWinoPlan best = {co_pad % 64 == 0 ? 2 : 1, 1};
   double best_cost = -1.0;
-  const char* e8 = getenv("SR_WINO8");
-  const bool force8 = (e8 ? atoi(e8) : SR_WINO8_DEFAULT) == 2;   // tests: the 8-wave kernel wherever it can run
   for (int nt = 2; nt >= 1; --nt) {
     if (nt == 2 && co_pad % 64 != 0) continue;
-    if (nt == 1 && force8 && co_pad % 64 == 0) continue;
     if ((forced_nt == 1 || forced_nt == 2) && nt != forced_nt && !(forced_nt == 2 && co_pad % 64 != 0)) continue;
     for (int ks = 1; ks <= 8; ks *= 2) {
       if (ks > 1 && (!allow_split || slabs % ks != 0 || slabs / ks < 4 || Cout % 4 != 0)) continue;
@@ -678,27 +579,6 @@ static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allo
   return best;
 }
 
-// The 8-wave kernel (sr_wino8.hip) overlaps a region's transform and epilogue with the MFMAs instead of running them as
-// phases.  Measured r02 on MI355X (scripts/wino8_micro.py, both kernels in one process, batch 8): 64 -> 64 @ 240x320
-// (4 slabs per region): 1.08-1.10x; 192 -> 64 @ 240x320 (12 slabs): 1.03-1.07x; 128 -> 64 @ 240x320 (8 slabs): 0.93-1.04x
-// depending on the box; everything at 120x160 and below: 0.90-0.98x (too few regions per CU for a one-workgroup-per-CU
-// kernel to amortise its prologue and the last region's serial epilogue).  Rule of mode 1: full-resolution layers
-// (>= 16 regions per CU) whose regions are short (<= 4 slabs: the epilogue is a large share) or long (>= 12 slabs).
-// Inside the whole step (bench.py hero_cfg3, same box, back to back) that rule measured 242.1 vs 246.4 frames/s without
-// it -- the isolated gain does not survive next to the side-stream encoder and real concat-slice layouts -- so the
-// default is 0: the kernel stays as a tested, bit-identical alternative and as the vehicle of the r02 pipe measurements.
-// SR_WINO8: 0 never (default), 1 by the rule above, 2 wherever it is applicable (tests).  Read per call.
-static bool sr_wino_use8(const SrWinoPlan& plan, bool vout, int Cin, int Cout, long items) {
-  const char* e = getenv("SR_WINO8");
-  const int mode = e ? atoi(e) : SR_WINO8_DEFAULT;
-  if (mode == 0 || !vout || plan.nt != 2) return false;
-  const int slabs = (Cin + 15) / 16;
-  if (slabs % plan.ks != 0 || slabs / plan.ks < 2 || (((Cout + 31) / 32) * 32) % 64 != 0) return false;
-  if (mode == 2) return true;
-  const int per_item = slabs / plan.ks;
-  return items >= 16L * sr_wino_num_cus() && per_item >= 4 && (per_item <= 4 || per_item >= 12);
-}
-
 extern "C" int sr_wino_splitk_factor(int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 1;
   return sr_wino_plan(B, H, W, Cin, Cout, true).ks;
@@ -713,20 +593,9 @@ extern "C" size_t sr_wino_splitk_workspace_bytes(int B, int H, int W, int Cin, i
 // rows 16-byte aligned and Cin % 4 == 0, `aligned_out` = output / residual / bias rows 16-byte aligned and Cout % 4 == 0.
 extern "C" const char* sr_wino_kernel_name(int B, int H, int W, int Cin, int Cout, int aligned_in, int aligned_out) {
   static thread_local char buf[64];
-  (void)Cin;
   const int vin = aligned_in != 0, vout = vin && aligned_out;
-  {
-    const SrWinoPlan plan = sr_wino_plan(B, H, W, Cin, Cout, vout != 0);
-    const long regions = (long)((H + 2 * WN_TR - 1) / (2 * WN_TR)) * ((W + 2 * WN_TC - 1) / (2 * WN_TC)) * B;
-    const int co_pad = ((Cout + 31) / 32) * 32;
-    if (sr_wino_use8(plan, vout != 0, Cin, Cout, regions * (co_pad / (32 * plan.nt)) * plan.ks)) {
-      snprintf(buf, sizeof(buf), "sr_wino8_kernel");
-      return buf;
-    }
-  }
-  const char* am = getenv("SR_WINO_ASYNC");
-  snprintf(buf, sizeof(buf), "sr_wino_kernel<%d, %s, %s, %s>", sr_wino_plan(B, H, W, Cin, Cout, vout != 0).nt,
-           vin ? "true" : "false", vout ? "true" : "false", (am && atoi(am) != 0) ? "true" : "false");
+  snprintf(buf, sizeof(buf), "sr_wino_kernel<%d, %s, %s>", sr_wino_plan(B, H, W, Cin, Cout, vout != 0).nt,
+           vin ? "true" : "false", vout ? "true" : "false");
   return buf;
 }
 
@@ -765,15 +634,11 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   p.co_blocks = p.Co_pad / (32 * nt);
   p.total = p.regions_x * p.regions_y * p.co_blocks * B * p.ksplit;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_WINO_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
-  { const char* e = getenv("SR_WINO_STAGGER"); p.stagger = e ? atoi(e) : 0; }
-  { const char* e = getenv("SR_WINO_STAGGER_CU"); p.stagger_cu = e ? atoi(e) : 0; }
   { const char* e = getenv("SR_WINO_XCD"); p.xcd_order = e ? atoi(e) : 1; }
   hipStream_t stream = (hipStream_t)stream_;
   int blocks = sr_wino_num_cus() * 2;
   { const char* e = getenv("SR_WINO_WG_PER_CU"); if (e && atoi(e) == 1) blocks = sr_wino_num_cus(); }  // ablation
   if (blocks > p.total) blocks = p.total;
-  const bool use8 = sr_wino_use8(plan, vout, Cin, Cout, p.total) && sr_wino8_supported(p, vout, nt);
-  if (use8) blocks = sr_wino_num_cus() < p.total ? sr_wino_num_cus() : p.total;
   const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
 #ifdef SR_WINO_TRACE
   static unsigned long long* trace_buf = nullptr;
@@ -783,33 +648,20 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   (void)hipMemsetAsync(trace_buf, 0, trace_n * 8, stream);
   p.trace = trace_buf;
 #endif
-  // SR_WINO_ASYNC=1 selects the counter-based slab hand-over (read per call so a test can flip it).  Measured r02:
-  // bit-identical and NOT faster (64 -> 64 @ 8x240x320: 270 vs 262 us) -- the per-slab barrier is not what limits the
-  // kernel, so the simpler barrier form stays the default and this one an ablation.
-  const char* async_env = getenv("SR_WINO_ASYNC");
-  const int async_mode = async_env ? atoi(async_env) : 0;
-#define SR_WINO_LAUNCH1(NTV, V4, VO, AS)                                                                          \
-  {                                                                                                               \
-    hipError_t e = hipFuncSetAttribute((const void*)sr_wino_kernel<NTV, V4, VO, AS>,                              \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-    if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
-    hipLaunchKernelGGL((sr_wino_kernel<NTV, V4, VO, AS>), dim3(blocks), dim3(256), lds, stream, p);               \
-  }
 #define SR_WINO_LAUNCH(NTV, V4, VO)                                                                               \
   {                                                                                                               \
-    if (async_mode) SR_WINO_LAUNCH1(NTV, V4, VO, true) else SR_WINO_LAUNCH1(NTV, V4, VO, false)                   \
+    hipError_t e = hipFuncSetAttribute((const void*)sr_wino_kernel<NTV, V4, VO>,                                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+    if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
+    hipLaunchKernelGGL((sr_wino_kernel<NTV, V4, VO>), dim3(blocks), dim3(256), lds, stream, p);                   \
   }
-  if (use8) {
-    const int rc8 = sr_wino8_launch(p, blocks, stream);
-    if (rc8 != SR_OK) return rc8;
-  } else if (nt == 2 && vout) SR_WINO_LAUNCH(2, true, true)
+  if (nt == 2 && vout) SR_WINO_LAUNCH(2, true, true)
   else if (nt == 2 && p.vec4) SR_WINO_LAUNCH(2, true, false)
   else if (nt == 2) SR_WINO_LAUNCH(2, false, false)
   else if (vout) SR_WINO_LAUNCH(1, true, true)
   else if (p.vec4) SR_WINO_LAUNCH(1, true, false)
   else SR_WINO_LAUNCH(1, false, false)
 #undef SR_WINO_LAUNCH
-#undef SR_WINO_LAUNCH1
 #ifdef SR_WINO_TRACE
   {
     const char* path = getenv("SR_WINO_TRACE_FILE");

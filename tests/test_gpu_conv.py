@@ -153,52 +153,27 @@ def test_conv_random_shapes_and_options():
                                             f"res={use_res} leaky={leaky}")
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 64, 60, 80), (1, 192, 64, 40, 48), (3, 48, 32, 17, 29), (1, 384, 384, 15, 20),
-                                   (8, 64, 64, 120, 160)])
-def test_winograd_async_handover_is_bit_identical(shape, monkeypatch):
-    """The counter-based slab hand-over of sr_wino_kernel<..., ASYNC = true> (waves of a workgroup drift instead of
-    meeting at a barrier per slab) computes exactly what the barrier-per-slab variant computes: many regions per
-    workgroup (chained staging), odd and even slab counts, split-K plans, residual + LeakyReLU epilogue."""
-    B, ci, co, h, w = shape
-    g = torch.Generator().manual_seed(ci + co + h)
-    conv = torch.nn.Conv2d(ci, co, 3, padding=1)
-    x = torch.randn((B, ci, h, w), generator=g).to(DEV)
-    res = torch.randn((B, co, h, w), generator=g).to(DEV)
-    conv = conv.to(DEV)
-    monkeypatch.setenv("SR_CONV_WINO", "2")
-    outs = []
-    for mode in ("0", "1", "1"):
-        monkeypatch.setenv("SR_WINO_ASYNC", mode)
-        with torch.inference_mode():
-            outs.append(ops.conv2d(x, conv, residual=res, leaky=0.2).clone())
-    torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
-    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, conv.weight, conv.bias, padding=1) + res, 0.2)
-    assert rel_err(outs[1], ref) < 2e-5
-
-
 @pytest.mark.parametrize("shape", [(2, 64, 64, 60, 80, True, 0.2), (1, 192, 64, 40, 48, True, 0.2), (3, 48, 48, 17, 29, False, None),
                                    (1, 384, 384, 15, 20, True, 0.2), (8, 64, 64, 120, 160, True, 0.2), (4, 32, 64, 37, 53, True, 0.0),
-                                   (2, 128, 128, 64, 96, False, 0.2), (1, 64, 128, 8, 16, True, None), (5, 80, 64, 24, 40, True, 0.2)])
-def test_winograd_8_wave_kernel_is_bit_identical(shape, monkeypatch):
-    """sr_wino8_kernel (one 8-wave workgroup per CU; transform, staging and the previous region's epilogue issued
-    between the MFMAs) performs the same floating-point operations in the same order as sr_wino_kernel: equal bit for
-    bit.  Cases: several regions per workgroup with the overlapped epilogue (>= 4 slabs), 2- and 3-slab layers (serial
-    epilogue), 5 / 12 / 24 slabs, split-K plans, ragged edges, Cout = 48 inside a 64-channel block, two 64-channel
-    blocks, fewer regions than CUs, with / without bias + residual, LeakyReLU / ReLU / identity."""
+                                   (2, 128, 128, 64, 96, False, 0.2), (1, 64, 128, 8, 16, True, None), (5, 80, 64, 24, 40, True, 0.2),
+                                   (3, 48, 32, 17, 29, True, 0.2), (8, 64, 64, 240, 320, True, 0.2), (2, 16, 64, 33, 47, True, 0.2)])
+def test_winograd_pipeline_cases_and_work_order(shape, monkeypatch):
+    """The software-pipelined slab loop of sr_wino_kernel (next slab stored mid-slab, barrier after step 5, transform of
+    its first channel group under the last MFMA steps; next REGION's first slab chained in when the slab count is even)
+    over its structural cases: one slab (16 channels), odd and even slab counts (2, 3, 4, 5, 8, 12, 24), many regions
+    per workgroup, fewer regions than CUs, split-K plans, ragged edges, Cout = 48 inside a 64-channel block and two
+    64-channel blocks, with / without bias + residual, LeakyReLU / ReLU / identity.  The XCD-aware work order
+    (SR_WINO_XCD) only permutes which workgroup computes which region: results are equal bit for bit, run to run too."""
     B, ci, co, h, w, extras, leaky = shape
     g = torch.Generator().manual_seed(ci + co + h)
     conv = torch.nn.Conv2d(ci, co, 3, padding=1, bias=extras)
     x = torch.randn((B, ci, h, w), generator=g).to(DEV)
     res = torch.randn((B, co, h, w), generator=g).to(DEV) if extras else None
     conv = conv.to(DEV)
-    from simplerecon_amd import _lib
-    lib = _lib.lib()
+    monkeypatch.setenv("SR_CONV_WINO", "2")
     outs = []
-    for mode in ("0", "2", "2"):
-        monkeypatch.setenv("SR_WINO8", mode)
-        name = lib.sr_wino_kernel_name(B, h, w, ci, co, 1, 1).decode()
-        assert ("wino8" in name) == (mode == "2"), name
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("SR_WINO_XCD", mode)
         with torch.inference_mode():
             outs.append(ops.conv2d(x, conv, residual=res, leaky=leaky).clone())
     torch.cuda.synchronize()
