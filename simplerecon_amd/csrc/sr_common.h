@@ -127,6 +127,27 @@ __device__ __forceinline__ bool sr_in_bounds(const SrSample& s, int h, int w) {
 // Activation code carried by the `leaky_slope` argument of the convolution entry points (simplerecon_hip.h): a value
 // >= 0 is the LeakyReLU slope (0 = ReLU), SR_ACT_NONE (any value in (-1.5, 0)) the identity, SR_ACT_SILU x * sigmoid(x).
 #ifdef __HIPCC__
+// max / min as ONE instruction.  fmaxf() compiles to two: hipcc first canonicalises an operand it cannot prove quiet
+// (v_max x, x, x) although in IEEE mode the instruction itself already returns a quiet result -- and it folds
+// v_med3(a, b, inf) back into the same thing, so this is inline asm.  The compiler's hazard recogniser does not look
+// inside inline asm: a (non-MFMA) VALU write needs 2 wait states before an MFMA reads the register (measured: wrong
+// volumes in the W2-streaming MLP sweep without them), hence the `s_nop 1` in the _mfma form.  The plain form is for
+// values that go to VALU arithmetic / stores.  For ordinary computed values (activations): NaN handling = v_max's.
+__device__ __forceinline__ float sr_vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float sr_vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float sr_vmax_mfma(float a, float b) {   // result may be an MFMA operand
+  float r;
+  asm("v_max_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float sr_activate(float v, float slope) {
   if (slope >= 0.0f) return fmaxf(v, 0.0f) + slope * fminf(v, 0.0f);
   if (slope < -1.5f) return v / (1.0f + __expf(-v));
@@ -146,10 +167,10 @@ __device__ __forceinline__ void sr_activate_group(float (&v)[N], float slope) {
   if (slope >= 0.0f) {
     if (slope <= 1.0f) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], slope * v[i]);
+      for (int i = 0; i < N; ++i) v[i] = sr_vmax(v[i], slope * v[i]);
     } else {
 #pragma unroll
-      for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], 0.0f) + slope * fminf(v[i], 0.0f);
+      for (int i = 0; i < N; ++i) v[i] = sr_vmax(v[i], 0.0f) + slope * sr_vmin(v[i], 0.0f);
     }
   } else if (slope < -1.5f) {
 #pragma unroll

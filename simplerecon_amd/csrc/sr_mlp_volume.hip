@@ -295,16 +295,21 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
       rsd = fmaxf(sqrtf((rv0 * rv0 + rv1 * rv1) + rv2 * rv2), 1e-12f);                         \
       (o)[23] = ((kview) == 0) ? d : 0.0f; /* plane depth rides in view 0's spare slot */      \
     }
+  // (r03) the source ray F.normalize(X - t_k) (cost_volume.py:654-669) and the ray angle F.cosine_similarity(...)
+  // (:683-688) divide three components by one norm each: ONE IEEE reciprocal + three multiplies per normalisation
+  // instead of three IEEE divisions (10 VALU instructions apiece beside the MFMAs).  x * (1/n) differs from x / n by at
+  // most one ulp; these channels only feed the MLP (parity bar 1e-4, tests: 2e-5 vs the oracle's true divisions).
 #define SR_RAY_B(o)                                                                           \
     {                                                                                         \
       _Pragma("clang fp contract(off)")                                                       \
-      (o)[20] = rv0 / rsd; (o)[21] = rv1 / rsd; (o)[22] = rv2 / rsd;                           \
+      const float rinv = 1.0f / rsd;                                                          \
+      (o)[20] = rv0 * rinv; (o)[21] = rv1 * rinv; (o)[22] = rv2 * rinv;                        \
     }
 #define SR_RAY_C(o)                                                                           \
     {                                                                                         \
       _Pragma("clang fp contract(off)")                                                       \
       const float n2 = fmaxf(sqrtf(((o)[20] * (o)[20] + (o)[21] * (o)[21]) + (o)[22] * (o)[22]), 1e-5f); \
-      (o)[19] = (crn0 * ((o)[20] / n2) + crn1 * ((o)[21] / n2)) + crn2 * ((o)[22] / n2);       \
+      (o)[19] = ((crn0 * (o)[20] + crn1 * (o)[21]) + crn2 * (o)[22]) * (1.0f / n2);            \
     }
 #define SR_INTERP2(o, i, lo)  /* channels 4i+2lo, 4i+2lo+1 as one packed fp32 pair (v_pk_fma_f32) */       \
     {                                                                                         \
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
         wn1 = wn2;
         if (!SR_MLP_DBG(1)) wn2 = w2[(size_t)min(t + 3, 64) * 64];
         const float aP = acc[0][t >> 4][t & 15], aQ = acc[1][t >> 4][t & 15];
-        const float bP = fmaxf(aP, p.slope * aP), bQ = fmaxf(aQ, p.slope * aQ);
+        const float bP = sr_vmax_mfma(aP, p.slope * aP), bQ = sr_vmax_mfma(aQ, p.slope * aQ);
         acc2[0][0] = SR_MFMA(wA.x, bP, acc2[0][0]);
         acc2[1][0] = SR_MFMA(wA.x, bQ, acc2[1][0]);
         acc2[0][1] = SR_MFMA(wA.y, bP, acc2[0][1]);
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
           for (int i = 0; i < 4; ++i) {
             const sr_f2v h2 = {acc2[0][m][4 * q + i], acc2[1][m][4 * q + i]};
             const sr_f2v s2 = slope2 * h2;
-            oPQ = __builtin_elementwise_fma(sr_f2v{wr[i], wr[i]}, sr_f2v{fmaxf(h2.x, s2.x), fmaxf(h2.y, s2.y)}, oPQ);
+            oPQ = __builtin_elementwise_fma(sr_f2v{wr[i], wr[i]}, sr_f2v{sr_vmax(h2.x, s2.x), sr_vmax(h2.y, s2.y)}, oPQ);
           }
         }
       float oP = oPQ.x, oQ = oPQ.y;
