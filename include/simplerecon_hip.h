@@ -468,6 +468,73 @@ int sr_scale_channels_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_
                                float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int C,
                                void* stream);
 
+/* ------------------------------------------------------ encoder training path -----------
+ *
+ * Backward (and training-mode forward) pieces of the two encoders, csrc/sr_train.hip: the reference trains
+ * ResnetMatchingEncoder (modules/networks.py:149-205) and the timm EfficientNetV2-S pyramid (depth_model.py:110-116) end
+ * to end with BatchNorm in training mode (train.py:126-145).  Channels-last fp32 views (batch stride, pixel stride);
+ * `act_code` as `leaky_slope` above (>= 0 LeakyReLU slope, SR_ACT_NONE, SR_ACT_SILU; SR_ACT_SIGMOID for the small dense
+ * layers).  Column reductions are two-stage and deterministic (no atomics).
+ *
+ *  sr_norm_stats_nhwc        mean / biased variance per (group, channel) over pixels; per_image = 0: one group = the whole
+ *                            batch (BatchNorm2d training statistics), 1: one group per image (InstanceNorm2d)
+ *  sr_norm_act_fwd_nhwc      y = act(gamma * (x - mean) / sqrt(var + eps) + beta); gamma / beta [C] or null
+ *  sr_norm_act_bwd_nhwc      dx (+ d_gamma, d_beta [C] when non-null); train_stats = 1: the statistics are functions of x
+ *  sr_rowsum_nhwc            out[b, c] = scale * sum over pixels of x (g null) or of x * g
+ *  sr_maxblurpool_bwd_nhwc   adjoint of sr_maxblurpool_nhwc_fwd (first maximum of a window receives its gradient)
+ *  sr_replicate_pad_nhwc_fwd / _bwd   y [B,H+2p,W+2p,C] dense <- x clamped at the borders; adjoint (dense in / out)
+ *  sr_im2col7x7s2_nhwc       col [B,Ho,Wo,Kp] of the 7x7 / stride-2 / pad-3 stem over a strided 3-channel image: with
+ *                            sr_conv_wgrad_nhwc (1x1) it yields the stem's weight gradient
+ *  sr_dwconv3x3_bwd_nhwc     depthwise 3x3 (weight [C][3][3], explicit top / left pad): d_in dense and / or d_weight
+ *  sr_scale_bwd_nhwc         d_in = grad_out * gate[b, c] (+ pool_scale * d_pool[b, c]): backward of the squeeze-excite scaling
+ *  sr_small_linear_fwd / _bwd   y = act(x W^T + b) on [B, K] -> [B, N] (the two dense layers of squeeze-excite)
+ *  sr_act_in_bwd             grad * act'(saved input)
+ *  sr_conv_wgrad_padded_nhwc sr_conv_wgrad_nhwc with explicit top / left zero padding and gradient size Ho x Wo */
+#define SR_ACT_SIGMOID (-3.0f)
+size_t sr_norm_workspace_bytes(int B, int HW, int C, int per_image);
+int sr_norm_stats_nhwc(const float* x, int64_t x_batch_stride, int x_pix_stride, int B, int HW, int C, int per_image,
+                       float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream);
+int sr_norm_act_fwd_nhwc(const float* x, int64_t x_batch_stride, int x_pix_stride, const float* mean, const float* var,
+                         float eps, const float* gamma, const float* beta, float act_code, int per_image, float* y,
+                         int64_t y_batch_stride, int y_pix_stride, int B, int HW, int C, void* stream);
+int sr_norm_act_bwd_nhwc(const float* grad_out, int64_t g_batch_stride, int g_pix_stride, const float* x,
+                         int64_t x_batch_stride, int x_pix_stride, const float* mean, const float* var, float eps,
+                         const float* gamma, const float* beta, float act_code, int per_image, int train_stats,
+                         float* d_in, int64_t d_batch_stride, int d_pix_stride, float* d_gamma, float* d_beta, int B,
+                         int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
+int sr_rowsum_nhwc(const float* x, int64_t x_batch_stride, int x_pix_stride, const float* g, int64_t g_batch_stride,
+                   int g_pix_stride, int B, int HW, int C, float scale, float* out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+size_t sr_maxblurpool_bwd_workspace_bytes(int B, int H, int W, int C);
+int sr_maxblurpool_bwd_nhwc(const float* grad_out, int64_t g_batch_stride, int g_pix_stride, const float* x,
+                            int64_t x_batch_stride, int x_pix_stride, float* grad_in, int64_t d_batch_stride,
+                            int d_pix_stride, int B, int H, int W, int C, void* workspace, size_t workspace_bytes,
+                            void* stream);
+int sr_replicate_pad_nhwc_fwd(const float* x, int64_t x_batch_stride, int x_pix_stride, float* y, int B, int H, int W,
+                              int C, int pad, void* stream);
+int sr_replicate_pad_nhwc_bwd(const float* grad_padded, float* grad_in, int B, int H, int W, int C, int pad, void* stream);
+int sr_im2col7x7s2_nhwc(const float* image, int64_t batch_stride, int64_t chan_stride, int64_t row_stride,
+                        int64_t col_stride, float* col, int B, int H, int W, int Kp, void* stream);
+size_t sr_dwconv3x3_bwd_workspace_bytes(int B, int Ho, int Wo, int C);
+int sr_dwconv3x3_bwd_nhwc(const float* grad_out, int64_t g_batch_stride, int g_pix_stride, const float* x,
+                          int64_t x_batch_stride, int x_pix_stride, const float* weight, float* d_in, float* d_weight,
+                          int B, int H, int W, int C, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int sr_scale_bwd_nhwc(const float* grad_out, int64_t g_batch_stride, int g_pix_stride, const float* gate,
+                      const float* d_pool, float pool_scale, float* d_in, int B, int HW, int C, void* stream);
+int sr_small_linear_fwd(const float* x, const float* W, const float* bias, float* pre, float* y, int B, int K, int N,
+                        float act_code, void* stream);
+int sr_small_linear_bwd(const float* dy, const float* pre, const float* x, const float* W, float* dx, float* dW, float* db,
+                        int B, int K, int N, float act_code, void* stream);
+int sr_act_in_bwd(const float* grad, const float* pre, float* grad_pre, int64_t n, float act_code, void* stream);
+/* out = act(a + b) on dense arrays (b null: act(a)); pre (optional) = a + b */
+int sr_add_act_fwd(const float* a, const float* b, float* pre, float* out, int64_t n, float act_code, void* stream);
+size_t sr_conv_wgrad_padded_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize);
+int sr_conv_wgrad_padded_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* grad_out,
+                              int64_t g_batch_stride, int g_pix_stride, float* d_weight, int B, int H, int W, int Cin,
+                              int Cout, int ksize, int stride, int pad_top, int pad_left, int Ho, int Wo, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

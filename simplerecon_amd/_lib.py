@@ -75,6 +75,28 @@ SIGNATURES = {
     "sr_upsample2x_bwd_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "sr_conv_flip_transpose_weights": (_i, [_p, _i, _i, _i, _p, _p]),
     "sr_mul_fwd": (_i, [_p, _p, _p, _i64, _p]),
+    "sr_norm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "sr_norm_stats_nhwc": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "sr_norm_act_fwd_nhwc": (_i, [_p, _i64, _i, _p, _p, _f, _p, _p, _f, _i, _p, _i64, _i, _i, _i, _i, _p]),
+    "sr_norm_act_bwd_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _p, _p, _f, _p, _p, _f, _i, _i, _p, _i64, _i, _p, _p,
+                                  _i, _i, _i, _p, _sz, _p]),
+    "sr_rowsum_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _f, _p, _p, _sz, _p]),
+    "sr_maxblurpool_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "sr_maxblurpool_bwd_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "sr_replicate_pad_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "sr_replicate_pad_nhwc_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "sr_im2col7x7s2_nhwc": (_i, [_p, _i64, _i64, _i64, _i64, _p, _i, _i, _i, _i, _p]),
+    "sr_dwconv3x3_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "sr_dwconv3x3_bwd_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz,
+                                   _p]),
+    "sr_scale_bwd_nhwc": (_i, [_p, _i64, _i, _p, _p, _f, _p, _i, _i, _i, _p]),
+    "sr_small_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "sr_small_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
+    "sr_act_in_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
+    "sr_add_act_fwd": (_i, [_p, _p, _p, _p, _i64, _f, _p]),
+    "sr_conv_wgrad_padded_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "sr_conv_wgrad_padded_nhwc": (_i, [_p, _i64, _i, _p, _i64, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p,
+                                       _sz, _p]),
     "sr_conv_splitk_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_conv2d_splitk_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i,
                                        _f, _p, _sz, _p]),

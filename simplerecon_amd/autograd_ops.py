@@ -47,21 +47,22 @@ def _dense_nhwc(t):
     return t
 
 
-def _conv_raw(x, weight, bias, stride, residual=None, slope=None):
+def _conv_raw(x, weight, bias, stride, residual=None, slope=None, pads=None):
     """act(conv(x, weight) + bias [+ residual]) on the inference kernels with a weight TENSOR [Co, Ci, k, k]
-    (packed on the fly; padding k // 2)."""
+    (packed on the fly; padding k // 2, or explicit (top, left, bottom, right) zero `pads`)."""
     lib = _lib.lib()
     x = as_nhwc(x, "conv input")
     b, ci, h, w = x.shape
     co, ci_w, k, _ = weight.shape
     if ci_w != ci:
         raise ValueError(f"conv weight expects {ci_w} input channels, got {ci}")
-    ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+    pt, pl, pb, pr = pads if pads is not None else (k // 2,) * 4
+    ho, wo = (h + pt + pb - k) // stride + 1, (w + pl + pr - k) // stride + 1
     out = empty_nhwc(b, co, ho, wo, x.device)
     if b == 0:
         return out
     wd = weight.detach().contiguous()
-    use_wino = stride == 1 and k == 3 and bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, stride))
+    use_wino = pads is None and stride == 1 and k == 3 and bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, stride))
     st = _lib.stream_ptr(x.device)
     with torch.cuda.device(x.device):
         if use_wino:
@@ -80,6 +81,10 @@ def _conv_raw(x, weight, bias, stride, residual=None, slope=None):
         if use_wino:
             rc = lib.sr_conv3x3_wino_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bd), _lib.ptr(residual), rsb,
                                               rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, sl, st)
+        elif pads is not None:
+            rc = lib.sr_conv2d_padded_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bd), _lib.ptr(residual), rsb,
+                                               rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, stride, pt, pl, pb, pr, sl,
+                                               st)
         else:
             rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bd), _lib.ptr(residual), rsb, rsp,
                                         _lib.ptr(out), osb, osp, b, h, w, ci, co, k, stride, sl, st)
@@ -88,15 +93,17 @@ def _conv_raw(x, weight, bias, stride, residual=None, slope=None):
 
 
 class _ConvBiasAct(torch.autograd.Function):
-    """y = act(conv(x, W, stride, pad = k // 2) + b [+ residual]), act = LeakyReLU(slope) or identity (slope None)."""
+    """y = act(conv(x, W, stride, pad = k // 2 or explicit `pads`) + b [+ residual]), act = LeakyReLU(slope) or identity
+    (slope None).  `pads` = (top, left, bottom, right) zero padding (TF-"SAME" convolutions of the image-prior encoder,
+    the valid convolution behind the matching encoder's replicate pad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, slope):
+    def forward(ctx, x, weight, bias, residual, stride, slope, pads=None):
         for name, t in (("conv input", x), ("conv weight", weight)):
             _lib.require_device_f32(name, t)
         x = as_nhwc(x, "conv input")
-        out = _conv_raw(x, weight, bias, stride, residual, slope)
-        ctx.stride, ctx.slope = stride, slope
+        out = _conv_raw(x, weight, bias, stride, residual, slope, pads)
+        ctx.stride, ctx.slope, ctx.pads = stride, slope, pads
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(x, weight, out if slope is not None else None)
         return out
@@ -137,14 +144,22 @@ class _ConvBiasAct(torch.autograd.Function):
                 gp = g
             d_x = d_w = None
             gsb, gsp = _strides(gp)
+            pads = ctx.pads
             if need_w and b > 0:
                 # dense [Co][Ci][k][k]: what sr_conv_wgrad_nhwc writes -- NOT empty_like (a channels_last weight's strides)
                 d_w = torch.empty(weight.shape, dtype=torch.float32, device=dev)
                 xsb, xsp = _strides(x)
-                nws = lib.sr_conv_wgrad_workspace_bytes(b, h, w, ci, co, k, s)
-                ws = _workspace(dev, "wgrad", nws)
-                _lib.check(lib.sr_conv_wgrad_nhwc(_lib.ptr(x), xsb, xsp, _lib.ptr(gp), gsb, gsp, _lib.ptr(d_w), b, h, w, ci,
-                                                  co, k, s, _lib.ptr(ws), nws, st), "sr_conv_wgrad_nhwc")
+                if pads is None:
+                    nws = lib.sr_conv_wgrad_workspace_bytes(b, h, w, ci, co, k, s)
+                    ws = _workspace(dev, "wgrad", nws)
+                    _lib.check(lib.sr_conv_wgrad_nhwc(_lib.ptr(x), xsb, xsp, _lib.ptr(gp), gsb, gsp, _lib.ptr(d_w), b, h, w,
+                                                      ci, co, k, s, _lib.ptr(ws), nws, st), "sr_conv_wgrad_nhwc")
+                else:
+                    nws = lib.sr_conv_wgrad_padded_workspace_bytes(b, ho, wo, ci, co, k)
+                    ws = _workspace(dev, "wgrad", nws)
+                    _lib.check(lib.sr_conv_wgrad_padded_nhwc(_lib.ptr(x), xsb, xsp, _lib.ptr(gp), gsb, gsp, _lib.ptr(d_w), b,
+                                                             h, w, ci, co, k, s, pads[0], pads[1], ho, wo, _lib.ptr(ws), nws,
+                                                             st), "sr_conv_wgrad_padded_nhwc")
             elif need_w:
                 d_w = torch.zeros(weight.shape, dtype=torch.float32, device=dev)
             if want_b and d_b is None:
@@ -162,8 +177,13 @@ class _ConvBiasAct(torch.autograd.Function):
                     if b > 0:
                         _lib.check(lib.sr_zero_stuff2x_nhwc(_lib.ptr(gp), gsb, gsp, _lib.ptr(src), b, ho, wo, h, w, co, st),
                                    "sr_zero_stuff2x_nhwc")
-                d_x = _conv_raw(src, wt, None, 1)
-        return d_x, d_w, d_b, (gp if (ctx.has_res and need_r) else None), None, None
+                if pads is None:
+                    d_x = _conv_raw(src, wt, None, 1)
+                elif s == 1:   # full correlation: pads k-1-p on the opposite roles
+                    d_x = _conv_raw(src, wt, None, 1, pads=(k - 1 - pads[0], k - 1 - pads[1], k - 1 - pads[2], k - 1 - pads[3]))
+                else:          # the stuffed gradient lives on the input's H x W grid: output H x W needs (k-1-pt, k-1-pl, pt, pl)
+                    d_x = _conv_raw(src, wt, None, 1, pads=(k - 1 - pads[0], k - 1 - pads[1], pads[0], pads[1]))
+        return d_x, d_w, d_b, (gp if (ctx.has_res and need_r) else None), None, None, None
 
 
 class _Upsample2x(torch.autograd.Function):

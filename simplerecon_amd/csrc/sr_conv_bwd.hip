@@ -28,7 +28,7 @@ struct SrWgradParams {
   const float* x; int64_t x_sb; int x_sp;      // input  [B, H, W, Cin]  (channels-last view)
   const float* g; int64_t g_sb; int g_sp;      // dL/dy  [B, Ho, Wo, Cout]
   float* part;                                  // [blocks][wgs_per_block][k*k][64 co][64 ci] partial slabs
-  int B, H, W, Cin, Cout, Ho, Wo, stride, pad;
+  int B, H, W, Cin, Cout, Ho, Wo, stride, pad, pad_x;   // pad = rows above, pad_x = columns left of the image
   int co_blocks, ci_blocks, items, wgs_per_block;
   int vec_x, vec_g;   // input / gradient rows are whole 16-byte aligned channel quads: float4 staging loads
 };
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void sr_conv_wgrad_kernel(SrWgradParams p) {
     for (int e = tid; e < KS * span * (WG_CT / 4); e += 256) {
       const int q = e & 15;
       const int col = (e >> 4) % span, ky = (e >> 4) / span;
-      const int iy = p.stride * oy + ky - p.pad, ix = p.stride * ox0 + col - p.pad, c = ci0 + 4 * q;
+      const int iy = p.stride * oy + ky - p.pad, ix = p.stride * ox0 + col - p.pad_x, c = ci0 + 4 * q;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin) {
         const float* src = p.x + (int64_t)b * p.x_sb + ((int64_t)iy * p.W + ix) * p.x_sp + c;
@@ -146,11 +146,7 @@ __global__ __launch_bounds__(256) void sr_conv_wgrad_reduce_kernel(const float* 
   }
 }
 
-static void sr_wgrad_plan(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int& Ho, int& Wo, int& blocks,
-                          int& per, int& items) {
-  const int pad = ksize / 2;
-  Ho = (H + 2 * pad - ksize) / stride + 1;
-  Wo = (W + 2 * pad - ksize) / stride + 1;
+static void sr_wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int& blocks, int& per, int& items) {
   blocks = ((Cout + WG_CT - 1) / WG_CT) * ((Cin + WG_CT - 1) / WG_CT);
   items = B * Ho * ((Wo + WG_P - 1) / WG_P);
   per = (2 * 256 + blocks - 1) / blocks;   // ~2 workgroups per CU in total
@@ -158,33 +154,48 @@ static void sr_wgrad_plan(int B, int H, int W, int Cin, int Cout, int ksize, int
   if (per < 1) per = 1;
 }
 
-extern "C" size_t sr_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
-    return 0;
-  int Ho, Wo, blocks, per, items;
-  sr_wgrad_plan(B, H, W, Cin, Cout, ksize, stride, Ho, Wo, blocks, per, items);
+static size_t sr_wgrad_ws(int B, int Ho, int Wo, int Cin, int Cout, int ksize) {
+  int blocks, per, items;
+  sr_wgrad_plan(B, Ho, Wo, Cin, Cout, blocks, per, items);
   return (size_t)blocks * per * ksize * ksize * WG_CT * WG_CT * sizeof(float);
 }
 
-extern "C" int sr_conv_wgrad_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* grad_out,
-                                  int64_t g_batch_stride, int g_pix_stride, float* d_weight, int B, int H, int W, int Cin,
-                                  int Cout, int ksize, int stride, void* workspace, size_t workspace_bytes, void* stream_) {
-  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
+extern "C" size_t sr_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
+    return 0;
+  const int pad = ksize / 2;
+  return sr_wgrad_ws(B, (H + 2 * pad - ksize) / stride + 1, (W + 2 * pad - ksize) / stride + 1, Cin, Cout, ksize);
+}
+
+// explicit-padding form (TF-"SAME" convolutions, the valid convolution behind a replicate pad): Ho x Wo is the
+// gradient's size, `pad_top` / `pad_left` the zero rows / columns in front of the image
+extern "C" size_t sr_conv_wgrad_padded_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
+  return sr_wgrad_ws(B, Ho, Wo, Cin, Cout, ksize);
+}
+
+extern "C" int sr_conv_wgrad_padded_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* grad_out,
+                                         int64_t g_batch_stride, int g_pix_stride, float* d_weight, int B, int H, int W,
+                                         int Cin, int Cout, int ksize, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                                         void* workspace, size_t workspace_bytes, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || pad_top < 0 || pad_left < 0)
+    return SR_ERR_INVALID_ARGUMENT;
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return SR_ERR_UNSUPPORTED;
   if (!d_weight) return SR_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return sr_hip_rc(hipMemsetAsync(d_weight, 0, (size_t)Cout * Cin * ksize * ksize * sizeof(float), stream));
   if (!in || !grad_out || !workspace) return SR_ERR_INVALID_ARGUMENT;
-  if (workspace_bytes < sr_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, ksize, stride)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  if (workspace_bytes < sr_wgrad_ws(B, Ho, Wo, Cin, Cout, ksize)) return SR_ERR_WORKSPACE_TOO_SMALL;
   SrWgradParams p;
   p.x = in; p.x_sb = in_batch_stride; p.x_sp = in_pix_stride;
   p.g = grad_out; p.g_sb = g_batch_stride; p.g_sp = g_pix_stride;
   p.part = (float*)workspace;
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.pad = ksize / 2;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.stride = stride; p.pad = pad_top; p.pad_x = pad_left;
+  p.Ho = Ho; p.Wo = Wo;
   p.co_blocks = (Cout + WG_CT - 1) / WG_CT;
   p.ci_blocks = (Cin + WG_CT - 1) / WG_CT;
   int blocks, per;
-  sr_wgrad_plan(B, H, W, Cin, Cout, ksize, stride, p.Ho, p.Wo, blocks, per, p.items);
+  sr_wgrad_plan(B, Ho, Wo, Cin, Cout, blocks, per, p.items);
   p.wgs_per_block = per;
   p.vec_x = Cin % 4 == 0 && in_pix_stride % 4 == 0 && in_batch_stride % 4 == 0 && (((uintptr_t)in) & 15) == 0;
   p.vec_g = Cout % 4 == 0 && g_pix_stride % 4 == 0 && g_batch_stride % 4 == 0 && (((uintptr_t)grad_out) & 15) == 0;
@@ -206,6 +217,17 @@ extern "C" int sr_conv_wgrad_nhwc(const float* in, int64_t in_batch_stride, int 
   hipLaunchKernelGGL(sr_conv_wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, (const float*)workspace, d_weight,
                      Cout, Cin, ksize * ksize, p.ci_blocks, per, blocks);
   return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" int sr_conv_wgrad_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* grad_out,
+                                  int64_t g_batch_stride, int g_pix_stride, float* d_weight, int B, int H, int W, int Cin,
+                                  int Cout, int ksize, int stride, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (H <= 0 || W <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return SR_ERR_UNSUPPORTED;
+  const int pad = ksize / 2;
+  return sr_conv_wgrad_padded_nhwc(in, in_batch_stride, in_pix_stride, grad_out, g_batch_stride, g_pix_stride, d_weight, B, H,
+                                   W, Cin, Cout, ksize, stride, pad, pad, (H + 2 * pad - ksize) / stride + 1,
+                                   (W + 2 * pad - ksize) / stride + 1, workspace, workspace_bytes, stream_);
 }
 
 // ------------------------------------------------------------------------------------------ bias gradient ------

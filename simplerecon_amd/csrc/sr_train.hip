@@ -1,0 +1,668 @@
+// sr_train.hip -- backward (and training-mode forward) pieces of the two encoders, so that DepthModel.forward trains end
+// to end like the reference (train.py:126-145: autograd through modules/networks.py:149-205 ResnetMatchingEncoder and the
+// timm EfficientNetV2-S pyramid of depth_model.py:110-116, BatchNorm in training mode).  gfx950, fp32, channels-last.
+//
+//   normalisation   sr_norm_stats_nhwc / sr_norm_act_fwd_nhwc / sr_norm_act_bwd_nhwc: per-(group, channel) statistics over
+//                   pixels, group = the whole batch (BatchNorm2d: training statistics, or given running statistics) or one
+//                   image (InstanceNorm2d), optional affine, activation fused (ReLU / LeakyReLU / SiLU / none);
+//                   backward = the textbook formulas with the two column sums sum(g'), sum(g' xhat) reduced in two
+//                   deterministic stages (per-chunk partials, added in index order: no atomics, bit-reproducible);
+//   pooling         sr_maxblurpool_bwd_nhwc: adjoint of MaxPool2d(2, stride 1) -> BlurPool(filt 4, stride 2, reflect)
+//                   (networks.py:176-183 via antialiased_cnns), gather form (no atomics), first maximum wins like ATen;
+//   depthwise       sr_dwconv3x3_bwd_nhwc: data gradient (gather) + weight gradient (column sums) of a depthwise 3x3;
+//   squeeze-excite  sr_rowsum_nhwc (per-(image, channel) sums of x or of g*x), sr_scale_bwd_nhwc, and small dense layers
+//                   sr_small_linear_fwd / _bwd on [B, C] activations;
+//   padding         sr_replicate_pad_nhwc_fwd / _bwd (the 128 -> 16 conv of the matching encoder pads by replication,
+//                   networks.py:196-199: training runs it as pad + valid convolution), sr_im2col7x7s2_nhwc (the 7x7 /
+//                   stride-2 stem's weight gradient as a 1x1-conv weight gradient over its unfolded input).
+// Dense-convolution gradients reuse the forward MFMA kernels (flipped weights, explicit pads) and sr_conv_wgrad_*.
+// These kernels are plain grid-stride HBM-bound byte work (float4 where alignment allows) -- the training step is not
+// the benchmarked path; correctness against the reference's autograd is what tests/ pin.
+#include "sr_common.h"
+
+#define SR_TR_CHUNK_PIX 512   // pixels per partial of a column reduction
+
+__device__ __forceinline__ float sr_act_fwd1(float z, float code) {
+  if (code >= 0.0f) return z >= 0.0f ? z : z * code;
+  if (code < -1.5f) return z / (1.0f + __expf(-z));
+  return z;
+}
+__device__ __forceinline__ float sr_act_grad1(float z, float code) {   // d act(z) / dz
+  if (code >= 0.0f) return z > 0.0f ? 1.0f : code;      // torch: LeakyReLU' = slope for z <= 0, ReLU' = 0 at 0
+  if (code < -1.5f) { const float s = 1.0f / (1.0f + __expf(-z)); return s * (1.0f + z * (1.0f - s)); }
+  return 1.0f;
+}
+
+// ---------------------------------------------------------------------------- column reductions ----------------
+// part[(chunk * G + n) * C + c] (and a second array for MODE 2) over the pixels of chunk `chunk` of group n.
+// MODE 0: sum x.  MODE 1: sum (x - mean)^2.  MODE 2: sum g', sum g' * xhat with g' = g * act'(gamma xhat + beta).
+// MODE 3: sum a * b (squeeze-excite: dL/dgate).
+struct SrColRed {
+  const float* x; int64_t x_sb; int x_sp;
+  const float* g; int64_t g_sb; int g_sp;
+  const float* mean; const float* var; const float* gamma; const float* beta;
+  float eps, act;
+  int B, HW, C, per_image, chunks;   // chunks per group
+  float* part0; float* part1;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sr_colreduce_kernel(SrColRed p) {
+  __shared__ float red0[4][64], red1[4][64];
+  const int G = p.per_image ? p.B : 1;
+  const int64_t npix = p.per_image ? p.HW : (int64_t)p.B * p.HW;   // pixels per group
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
+  const int64_t p0 = (int64_t)chunk * SR_TR_CHUNK_PIX, p1 = min(p0 + SR_TR_CHUNK_PIX, npix);
+  for (int c0 = 0; c0 < p.C; c0 += 64) {
+    const int c = c0 + cl;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (c < p.C) {
+      const int sc = n * p.C + c;
+      float m = 0.0f, r = 1.0f, ga = 1.0f, be = 0.0f;
+      if (MODE == 1 || MODE == 2) m = p.mean[sc];
+      if (MODE == 2) {
+        r = 1.0f / sqrtf(p.var[sc] + p.eps);
+        if (p.gamma) ga = p.gamma[c];
+        if (p.beta) be = p.beta[c];
+      }
+      for (int64_t px = p0 + row; px < p1; px += 4) {
+        const int64_t b = p.per_image ? n : px / p.HW, q = p.per_image ? px : px - b * p.HW;
+        const float xv = p.x[b * p.x_sb + q * p.x_sp + c];
+        if (MODE == 0) s0 += xv;
+        else if (MODE == 1) { const float d = xv - m; s0 += d * d; }
+        else if (MODE == 2) {
+          const float xh = (xv - m) * r;
+          const float gp = p.g[b * p.g_sb + q * p.g_sp + c] * sr_act_grad1(ga * xh + be, p.act);
+          s0 += gp; s1 += gp * xh;
+        } else { s0 += xv * p.g[b * p.g_sb + q * p.g_sp + c]; }
+      }
+    }
+    red0[row][cl] = s0; red1[row][cl] = s1;
+    __syncthreads();
+    if (row == 0 && c < p.C) {
+      const size_t o = ((size_t)chunk * G + n) * p.C + c;
+      p.part0[o] = (red0[0][cl] + red0[1][cl]) + (red0[2][cl] + red0[3][cl]);
+      if (MODE == 2) p.part1[o] = (red1[0][cl] + red1[1][cl]) + (red1[2][cl] + red1[3][cl]);
+    }
+    __syncthreads();
+  }
+}
+
+// out[i] = scale * sum_chunk part[chunk * n_out + i], chunks added in index order (deterministic)
+__global__ void sr_colreduce_finish_kernel(const float* __restrict__ part, int chunks, int n_out, float scale,
+                                           float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  float s = 0.0f;
+  for (int k = 0; k < chunks; ++k) s += part[(size_t)k * n_out + i];
+  out[i] = s * scale;
+}
+
+static int sr_tr_chunks(int B, int HW, int per_image) {
+  const int64_t npix = per_image ? HW : (int64_t)B * HW;
+  return (int)((npix + SR_TR_CHUNK_PIX - 1) / SR_TR_CHUNK_PIX);
+}
+
+extern "C" size_t sr_norm_workspace_bytes(int B, int HW, int C, int per_image) {
+  if (B <= 0 || HW <= 0 || C <= 0) return 0;
+  const size_t G = per_image ? B : 1;
+  return 2 * (size_t)sr_tr_chunks(B, HW, per_image) * G * C * sizeof(float) + 2 * G * C * sizeof(float);
+}
+
+template <int MODE>
+static int sr_colreduce(SrColRed p, float* out0, float scale0, float* out1, float scale1, hipStream_t stream) {
+  const int G = p.per_image ? p.B : 1;
+  hipLaunchKernelGGL(sr_colreduce_kernel<MODE>, dim3(p.chunks, G), dim3(256), 0, stream, p);
+  const int n_out = G * p.C;
+  hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, p.part0, p.chunks, n_out,
+                     scale0, out0);
+  if (MODE == 2)
+    hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, p.part1, p.chunks,
+                       n_out, scale1, out1);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// mean / biased variance per (group, channel): two passes (sum, then sum of squared deviations -- no cancellation)
+extern "C" int sr_norm_stats_nhwc(const float* x, int64_t x_sb, int x_sp, int B, int HW, int C, int per_image, float* mean,
+                                  float* var, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (B <= 0 || HW <= 0 || C <= 0 || !x || !mean || !var || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < sr_norm_workspace_bytes(B, HW, C, per_image)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  SrColRed p = {};
+  p.x = x; p.x_sb = x_sb; p.x_sp = x_sp; p.B = B; p.HW = HW; p.C = C; p.per_image = per_image;
+  p.chunks = sr_tr_chunks(B, HW, per_image);
+  p.part0 = (float*)workspace; p.part1 = nullptr;
+  const float inv_n = 1.0f / (float)(per_image ? (int64_t)HW : (int64_t)B * HW);
+  int rc = sr_colreduce<0>(p, mean, inv_n, nullptr, 0.f, stream);
+  if (rc) return rc;
+  p.mean = mean;
+  return sr_colreduce<1>(p, var, inv_n, nullptr, 0.f, stream);
+}
+
+// ---------------------------------------------------------------------------- normalise + activation ------------
+struct SrNormEw {
+  const float* x; int64_t x_sb; int x_sp;
+  const float* g; int64_t g_sb; int g_sp;
+  float* y; int64_t y_sb; int y_sp;
+  const float* mean; const float* var; const float* gamma; const float* beta;
+  const float* s0; const float* s1;     // backward: per-(group, channel) MEANS of g' and g' * xhat (training statistics)
+  float eps, act;
+  int B, HW, C, per_image, train_stats;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void sr_norm_ew_kernel(SrNormEw p) {
+  const int64_t total = (int64_t)p.B * p.HW * p.C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % p.C);
+    const int64_t px = e / p.C, b = px / p.HW, q = px - b * p.HW;
+    const int sc = (p.per_image ? (int)b : 0) * p.C + c;
+    const float r = 1.0f / sqrtf(p.var[sc] + p.eps);
+    const float ga = p.gamma ? p.gamma[c] : 1.0f, be = p.beta ? p.beta[c] : 0.0f;
+    const float xh = (p.x[b * p.x_sb + q * p.x_sp + c] - p.mean[sc]) * r;
+    const float z = ga * xh + be;
+    if (!BWD) {
+      p.y[b * p.y_sb + q * p.y_sp + c] = sr_act_fwd1(z, p.act);
+    } else {
+      const float gp = p.g[b * p.g_sb + q * p.g_sp + c] * sr_act_grad1(z, p.act);
+      float dx = gp;
+      if (p.train_stats) dx = gp - p.s0[sc] - xh * p.s1[sc];
+      p.y[b * p.y_sb + q * p.y_sp + c] = ga * r * dx;
+    }
+  }
+}
+
+static int sr_ew_blocks(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b < 8192 ? (b < 1 ? 1 : b) : 8192);
+}
+
+extern "C" int sr_norm_act_fwd_nhwc(const float* x, int64_t x_sb, int x_sp, const float* mean, const float* var, float eps,
+                                    const float* gamma, const float* beta, float act_code, int per_image, float* y,
+                                    int64_t y_sb, int y_sp, int B, int HW, int C, void* stream_) {
+  if (B < 0 || HW <= 0 || C <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!x || !mean || !var || !y) return SR_ERR_INVALID_ARGUMENT;
+  SrNormEw p = {};
+  p.x = x; p.x_sb = x_sb; p.x_sp = x_sp; p.y = y; p.y_sb = y_sb; p.y_sp = y_sp;
+  p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.eps = eps; p.act = act_code;
+  p.B = B; p.HW = HW; p.C = C; p.per_image = per_image;
+  hipLaunchKernelGGL(sr_norm_ew_kernel<false>, dim3(sr_ew_blocks((int64_t)B * HW * C)), dim3(256), 0, (hipStream_t)stream_, p);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// dx (and d_gamma, d_beta when non-null; [C], summed over the groups) of y = act(gamma * (x - mean) / sqrt(var + eps) + beta).
+// train_stats = 1: mean / var were computed from x itself (BatchNorm in training mode, InstanceNorm): the gradient flows
+// through them; 0: they are constants (BatchNorm in eval mode).
+extern "C" int sr_norm_act_bwd_nhwc(const float* g, int64_t g_sb, int g_sp, const float* x, int64_t x_sb, int x_sp,
+                                    const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                                    float act_code, int per_image, int train_stats, float* dx, int64_t dx_sb, int dx_sp,
+                                    float* d_gamma, float* d_beta, int B, int HW, int C, void* workspace,
+                                    size_t workspace_bytes, void* stream_) {
+  if (B <= 0 || HW <= 0 || C <= 0 || !g || !x || !mean || !var || !dx || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < sr_norm_workspace_bytes(B, HW, C, per_image)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  if ((d_gamma || d_beta) && per_image) return SR_ERR_UNSUPPORTED;   // InstanceNorm2d of the reference has no affine
+  hipStream_t stream = (hipStream_t)stream_;
+  const int G = per_image ? B : 1;
+  SrColRed r = {};
+  r.x = x; r.x_sb = x_sb; r.x_sp = x_sp; r.g = g; r.g_sb = g_sb; r.g_sp = g_sp;
+  r.mean = mean; r.var = var; r.gamma = gamma; r.beta = beta; r.eps = eps; r.act = act_code;
+  r.B = B; r.HW = HW; r.C = C; r.per_image = per_image; r.chunks = sr_tr_chunks(B, HW, per_image);
+  const size_t part = (size_t)r.chunks * G * C;
+  r.part0 = (float*)workspace; r.part1 = r.part0 + part;
+  float* s0 = r.part1 + part; float* s1 = s0 + (size_t)G * C;   // column SUMS of g', g' * xhat
+  int rc = sr_colreduce<2>(r, s0, 1.0f, s1, 1.0f, stream);
+  if (rc) return rc;
+  if (d_beta) (void)hipMemcpyAsync(d_beta, s0, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, stream);
+  if (d_gamma) (void)hipMemcpyAsync(d_gamma, s1, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, stream);
+  if (train_stats) {   // sums -> means (after the copies above, same stream)
+    const float inv_n = 1.0f / (float)(per_image ? (int64_t)HW : (int64_t)B * HW);
+    hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((2 * G * C + 255) / 256), dim3(256), 0, stream, s0, 1, 2 * G * C, inv_n, s0);
+  }
+  SrNormEw p = {};
+  p.x = x; p.x_sb = x_sb; p.x_sp = x_sp; p.g = g; p.g_sb = g_sb; p.g_sp = g_sp; p.y = dx; p.y_sb = dx_sb; p.y_sp = dx_sp;
+  p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.s0 = s0; p.s1 = s1; p.eps = eps; p.act = act_code;
+  p.B = B; p.HW = HW; p.C = C; p.per_image = per_image; p.train_stats = train_stats;
+  hipLaunchKernelGGL(sr_norm_ew_kernel<true>, dim3(sr_ew_blocks((int64_t)B * HW * C)), dim3(256), 0, stream, p);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// per-(image, channel) sums over pixels of x (g = null) or of x * g -> out[B, C] (deterministic two-stage sum)
+extern "C" int sr_rowsum_nhwc(const float* x, int64_t x_sb, int x_sp, const float* g, int64_t g_sb, int g_sp, int B, int HW,
+                              int C, float scale, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (B <= 0 || HW <= 0 || C <= 0 || !x || !out || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < sr_norm_workspace_bytes(B, HW, C, 1)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  SrColRed p = {};
+  p.x = x; p.x_sb = x_sb; p.x_sp = x_sp; p.g = g; p.g_sb = g_sb; p.g_sp = g_sp;
+  p.B = B; p.HW = HW; p.C = C; p.per_image = 1; p.chunks = sr_tr_chunks(B, HW, 1);
+  p.part0 = (float*)workspace;
+  return g ? sr_colreduce<3>(p, out, scale, nullptr, 0.f, (hipStream_t)stream_)
+           : sr_colreduce<0>(p, out, scale, nullptr, 0.f, (hipStream_t)stream_);
+}
+
+// ---------------------------------------------------------------------------- MaxPool(2,1) + BlurPool(4,2) ------
+// forward (sr_maxblurpool_kernel, sr_matching.hip): m[y,x] = max x[y..y+1, x..x+1] on (H-1) x (W-1); reflect-pad m by
+// (1, 2) and blur with outer([1,3,3,1])/64 at stride 2 -> Ho x Wo, Ho = (H - 1 + 3 - 4) / 2 + 1.
+__device__ __forceinline__ int sr_reflect(int i, int n) {   // index into [0, n) of padded coordinate i (pad < n)
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// stage 1: dL/dm[b, y, x, c] = sum over output taps that read m[y, x] (through the reflection)
+__global__ __launch_bounds__(256) void sr_blurpool_bwd_kernel(const float* __restrict__ g, int64_t g_sb, int g_sp,
+                                                             float* __restrict__ dm, int B, int Hm, int Wm, int Ho, int Wo,
+                                                             int C) {
+  const float f[4] = {1.0f / 8.0f, 3.0f / 8.0f, 3.0f / 8.0f, 1.0f / 8.0f};
+  const int64_t total = (int64_t)B * Hm * Wm * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t r = e / C;
+    const int x = (int)(r % Wm); r /= Wm;
+    const int y = (int)(r % Hm);
+    const int b = (int)(r / Hm);
+    // padded coordinates (1 row / column in front, 2 behind) that reflect onto (y, x): the direct one, y + 1, plus
+    // the mirror images: padded 0 <- m[1]; padded Hm + 1 <- m[Hm - 2]; padded Hm + 2 <- m[Hm - 3]
+    int cy[3], cx[3], ny = 0, nx = 0;
+    cy[ny++] = y + 1;
+    if (y == 1) cy[ny++] = 0;
+    if (y == Hm - 2) cy[ny++] = Hm + 1;
+    if (y == Hm - 3) cy[ny++] = Hm + 2;
+    cx[nx++] = x + 1;
+    if (x == 1) cx[nx++] = 0;
+    if (x == Wm - 2) cx[nx++] = Wm + 1;
+    if (x == Wm - 3) cx[nx++] = Wm + 2;
+    float s = 0.0f;
+    for (int a = 0; a < ny; ++a) {
+      const int py = cy[a];
+      for (int bq = 0; bq < nx; ++bq) {
+        const int px = cx[bq];
+        // output (oy, ox) reads padded (2 oy + ky, 2 ox + kx)
+        for (int ky = (py & 1); ky < 4; ky += 2) {
+          const int oy = (py - ky) / 2;
+          if (py - ky < 0 || oy >= Ho) continue;
+          for (int kx = (px & 1); kx < 4; kx += 2) {
+            const int ox = (px - kx) / 2;
+            if (px - kx < 0 || ox >= Wo) continue;
+            s += f[ky] * f[kx] * g[(int64_t)b * g_sb + ((int64_t)oy * Wo + ox) * g_sp + c];
+          }
+        }
+      }
+    }
+    dm[e] = s;
+  }
+}
+
+// stage 2: dL/dx[y, x] = sum of dL/dm over the (up to 4) 2x2 windows whose FIRST maximum (row-major scan, NaN wins,
+// like ATen's max_pool2d) is (y, x)
+__global__ __launch_bounds__(256) void sr_maxpool2_bwd_kernel(const float* __restrict__ xin, int64_t x_sb, int x_sp,
+                                                             const float* __restrict__ dm, float* __restrict__ dx,
+                                                             int64_t dx_sb, int dx_sp, int B, int H, int W, int C) {
+  const int Hm = H - 1, Wm = W - 1;
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t r = e / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const float* xb = xin + (int64_t)b * x_sb + c;
+    float s = 0.0f;
+    for (int wy = y - 1; wy <= y; ++wy) {
+      if (wy < 0 || wy >= Hm) continue;
+      for (int wx = x - 1; wx <= x; ++wx) {
+        if (wx < 0 || wx >= Wm) continue;
+        float best = xb[((int64_t)wy * W + wx) * x_sp];
+        int bi = 0;
+        for (int k = 1; k < 4; ++k) {
+          const float v = xb[((int64_t)(wy + (k >> 1)) * W + wx + (k & 1)) * x_sp];
+          if (v > best || (v != v && best == best)) { best = v; bi = k; }
+        }
+        if (wy + (bi >> 1) == y && wx + (bi & 1) == x) s += dm[(((int64_t)b * Hm + wy) * Wm + wx) * C + c];
+      }
+    }
+    dx[(int64_t)b * dx_sb + ((int64_t)y * W + x) * dx_sp + c] = s;
+  }
+}
+
+extern "C" size_t sr_maxblurpool_bwd_workspace_bytes(int B, int H, int W, int C) {
+  if (B <= 0 || H < 2 || W < 2 || C <= 0) return 0;
+  return (size_t)B * (H - 1) * (W - 1) * C * sizeof(float);
+}
+
+extern "C" int sr_maxblurpool_bwd_nhwc(const float* grad_out, int64_t g_sb, int g_sp, const float* x, int64_t x_sb, int x_sp,
+                                       float* grad_in, int64_t dx_sb, int dx_sp, int B, int H, int W, int C, void* workspace,
+                                       size_t workspace_bytes, void* stream_) {
+  if (B < 0 || H < 4 || W < 4 || C <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!grad_out || !x || !grad_in || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < sr_maxblurpool_bwd_workspace_bytes(B, H, W, C)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  const int Hm = H - 1, Wm = W - 1, Ho = (Hm + 3 - 4) / 2 + 1, Wo = (Wm + 3 - 4) / 2 + 1;
+  hipStream_t stream = (hipStream_t)stream_;
+  float* dm = (float*)workspace;
+  hipLaunchKernelGGL(sr_blurpool_bwd_kernel, dim3(sr_ew_blocks((int64_t)B * Hm * Wm * C)), dim3(256), 0, stream, grad_out,
+                     g_sb, g_sp, dm, B, Hm, Wm, Ho, Wo, C);
+  hipLaunchKernelGGL(sr_maxpool2_bwd_kernel, dim3(sr_ew_blocks((int64_t)B * H * W * C)), dim3(256), 0, stream, x, x_sb, x_sp,
+                     dm, grad_in, dx_sb, dx_sp, B, H, W, C);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------- replicate padding ------------------
+__global__ __launch_bounds__(256) void sr_replicate_pad_kernel(const float* __restrict__ x, int64_t x_sb, int x_sp,
+                                                              float* __restrict__ y, int B, int H, int W, int C, int pad) {
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int64_t total = (int64_t)B * Hp * Wp * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t r = e / C;
+    const int xp = (int)(r % Wp); r /= Wp;
+    const int yp = (int)(r % Hp);
+    const int b = (int)(r / Hp);
+    const int iy = min(max(yp - pad, 0), H - 1), ix = min(max(xp - pad, 0), W - 1);
+    y[e] = x[(int64_t)b * x_sb + ((int64_t)iy * W + ix) * x_sp + c];
+  }
+}
+
+// adjoint: dx[y, x] = sum of dyp over the padded positions that replicate (y, x) (gather form)
+__global__ __launch_bounds__(256) void sr_replicate_pad_bwd_kernel(const float* __restrict__ gp, float* __restrict__ dx,
+                                                                  int B, int H, int W, int C, int pad) {
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t r = e / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const int y0 = y == 0 ? 0 : y + pad, y1 = y == H - 1 ? Hp - 1 : y + pad;
+    const int x0 = x == 0 ? 0 : x + pad, x1 = x == W - 1 ? Wp - 1 : x + pad;
+    float s = 0.0f;
+    for (int yy = y0; yy <= y1; ++yy)
+      for (int xx = x0; xx <= x1; ++xx) s += gp[(((int64_t)b * Hp + yy) * Wp + xx) * C + c];
+    dx[e] = s;
+  }
+}
+
+extern "C" int sr_replicate_pad_nhwc_fwd(const float* x, int64_t x_sb, int x_sp, float* y, int B, int H, int W, int C, int pad,
+                                         void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!x || !y) return SR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sr_replicate_pad_kernel, dim3(sr_ew_blocks((int64_t)B * (H + 2 * pad) * (W + 2 * pad) * C)), dim3(256), 0,
+                     (hipStream_t)stream_, x, x_sb, x_sp, y, B, H, W, C, pad);
+  return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" int sr_replicate_pad_nhwc_bwd(const float* grad_padded, float* grad_in, int B, int H, int W, int C, int pad,
+                                         void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!grad_padded || !grad_in) return SR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sr_replicate_pad_bwd_kernel, dim3(sr_ew_blocks((int64_t)B * H * W * C)), dim3(256), 0,
+                     (hipStream_t)stream_, grad_padded, grad_in, B, H, W, C, pad);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------- 7x7 / stride-2 stem: unfolded input --
+// col[b, oy, ox, (c*7 + ky)*7 + kx] = x[b, c, 2 oy + ky - 3, 2 ox + kx - 3] (0 outside), padded to Kp columns: the stem's
+// weight gradient is then the 1x1-conv weight gradient dW[co][Kp] = sum_px g[px][co] col[px][k] (sr_conv_wgrad_nhwc).
+__global__ __launch_bounds__(256) void sr_im2col7_kernel(const float* __restrict__ x, int64_t x_sb, int64_t x_sc, int64_t x_sy,
+                                                        int64_t x_sx, float* __restrict__ col, int B, int H, int W, int Ho,
+                                                        int Wo, int Kp) {
+  const int64_t total = (int64_t)B * Ho * Wo * Kp;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e % Kp);
+    int64_t r = e / Kp;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float v = 0.0f;
+    if (k < 147) {
+      const int c = k / 49, ky = (k % 49) / 7, kx = k % 7;
+      const int iy = 2 * oy + ky - 3, ix = 2 * ox + kx - 3;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(int64_t)b * x_sb + c * x_sc + iy * x_sy + ix * x_sx];
+    }
+    col[e] = v;
+  }
+}
+
+extern "C" int sr_im2col7x7s2_nhwc(const float* image, int64_t sb, int64_t sc, int64_t sy, int64_t sx, float* col, int B,
+                                   int H, int W, int Kp, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || Kp < 147) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!image || !col) return SR_ERR_INVALID_ARGUMENT;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(sr_im2col7_kernel, dim3(sr_ew_blocks((int64_t)B * Ho * Wo * Kp)), dim3(256), 0, (hipStream_t)stream_, image,
+                     sb, sc, sy, sx, col, B, H, W, Ho, Wo, Kp);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------- depthwise 3x3 backward -------------
+// forward: y[oy, ox, c] = sum_{ky,kx} w[c][ky][kx] x[s oy + ky - pt, s ox + kx - pl, c]
+__global__ __launch_bounds__(256) void sr_dw_dgrad_kernel(const float* __restrict__ g, int64_t g_sb, int g_sp,
+                                                         const float* __restrict__ w, float* __restrict__ dx, int B, int H,
+                                                         int W, int Ho, int Wo, int C, int s, int pt, int pl) {
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t r = e / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc = 0.0f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ty = y + pt - ky;
+      if (ty < 0 || ty % s) continue;
+      const int oy = ty / s;
+      if (oy >= Ho) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tx = x + pl - kx;
+        if (tx < 0 || tx % s) continue;
+        const int ox = tx / s;
+        if (ox >= Wo) continue;
+        acc += w[c * 9 + ky * 3 + kx] * g[(int64_t)b * g_sb + ((int64_t)oy * Wo + ox) * g_sp + c];
+      }
+    }
+    dx[e] = acc;
+  }
+}
+
+// weight gradient: part[chunk][tap][c] over the output pixels of a chunk, then sr_colreduce_finish_kernel
+__global__ __launch_bounds__(256) void sr_dw_wgrad_kernel(const float* __restrict__ g, int64_t g_sb, int g_sp,
+                                                         const float* __restrict__ x, int64_t x_sb, int x_sp,
+                                                         float* __restrict__ part, int B, int H, int W, int Ho, int Wo, int C,
+                                                         int s, int pt, int pl) {
+  __shared__ float red[4][9][64];
+  const int chunk = blockIdx.x;
+  const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  const int64_t p0 = (int64_t)chunk * SR_TR_CHUNK_PIX, p1 = min(p0 + SR_TR_CHUNK_PIX, npix);
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + cl;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
+    if (c < C) {
+      for (int64_t px = p0 + row; px < p1; px += 4) {
+        const int b = (int)(px / ((int64_t)Ho * Wo));
+        const int q = (int)(px - (int64_t)b * Ho * Wo), oy = q / Wo, ox = q - oy * Wo;
+        const float gv = g[(int64_t)b * g_sb + (int64_t)q * g_sp + c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = s * oy + t / 3 - pt, ix = s * ox + t % 3 - pl;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc[t] += gv * x[(int64_t)b * x_sb + ((int64_t)iy * W + ix) * x_sp + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[row][t][cl] = acc[t];
+    __syncthreads();
+    if (row == 0 && c < C) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)   // part layout [chunk][c][tap] = the weight's own [C][3][3] layout per chunk
+        part[((size_t)chunk * C + c) * 9 + t] = (red[0][t][cl] + red[1][t][cl]) + (red[2][t][cl] + red[3][t][cl]);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" size_t sr_dwconv3x3_bwd_workspace_bytes(int B, int Ho, int Wo, int C) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return 0;
+  const int64_t chunks = ((int64_t)B * Ho * Wo + SR_TR_CHUNK_PIX - 1) / SR_TR_CHUNK_PIX;
+  return (size_t)chunks * C * 9 * sizeof(float);
+}
+
+// weight [C][3][3] (PyTorch depthwise layout [C,1,3,3]); d_in dense channels-last [B,H,W,C]; either output may be null
+extern "C" int sr_dwconv3x3_bwd_nhwc(const float* grad_out, int64_t g_sb, int g_sp, const float* x, int64_t x_sb, int x_sp,
+                                     const float* weight, float* d_in, float* d_weight, int B, int H, int W, int C, int stride,
+                                     int pad_top, int pad_left, int Ho, int Wo, void* workspace, size_t workspace_bytes,
+                                     void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (stride != 1 && stride != 2) || Ho <= 0 || Wo <= 0) return SR_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B == 0) {
+    if (d_weight) return sr_hip_rc(hipMemsetAsync(d_weight, 0, (size_t)C * 9 * sizeof(float), stream));
+    return SR_OK;
+  }
+  if (!grad_out) return SR_ERR_INVALID_ARGUMENT;
+  if (d_in) {
+    if (!weight) return SR_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(sr_dw_dgrad_kernel, dim3(sr_ew_blocks((int64_t)B * H * W * C)), dim3(256), 0, stream, grad_out, g_sb, g_sp,
+                       weight, d_in, B, H, W, Ho, Wo, C, stride, pad_top, pad_left);
+  }
+  if (d_weight) {
+    if (!x || !workspace) return SR_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < sr_dwconv3x3_bwd_workspace_bytes(B, Ho, Wo, C)) return SR_ERR_WORKSPACE_TOO_SMALL;
+    const int chunks = (int)(((int64_t)B * Ho * Wo + SR_TR_CHUNK_PIX - 1) / SR_TR_CHUNK_PIX);
+    hipLaunchKernelGGL(sr_dw_wgrad_kernel, dim3(chunks), dim3(256), 0, stream, grad_out, g_sb, g_sp, x, x_sb, x_sp,
+                       (float*)workspace, B, H, W, Ho, Wo, C, stride, pad_top, pad_left);
+    hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, stream, (const float*)workspace,
+                       chunks, C * 9, 1.0f, d_weight);
+  }
+  return sr_hip_rc(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------- squeeze-excite pieces --------------
+// dx = g * gate[b, c] + pool_scale * dpool[b, c]   (y = x * gate; the gate is a function of mean_hw(x): pool_scale = 1 / HW)
+__global__ __launch_bounds__(256) void sr_scale_bwd_kernel(const float* __restrict__ g, int64_t g_sb, int g_sp,
+                                                          const float* __restrict__ gate, const float* __restrict__ dpool,
+                                                          float pool_scale, float* __restrict__ dx, int B, int HW, int C) {
+  const int64_t total = (int64_t)B * HW * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int64_t px = e / C, b = px / HW, q = px - b * HW;
+    dx[e] = g[b * g_sb + q * g_sp + c] * gate[b * C + c] + (dpool ? pool_scale * dpool[b * C + c] : 0.0f);
+  }
+}
+
+extern "C" int sr_scale_bwd_nhwc(const float* grad_out, int64_t g_sb, int g_sp, const float* gate, const float* d_pool,
+                                 float pool_scale, float* d_in, int B, int HW, int C, void* stream_) {
+  if (B < 0 || HW <= 0 || C <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!grad_out || !gate || !d_in) return SR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sr_scale_bwd_kernel, dim3(sr_ew_blocks((int64_t)B * HW * C)), dim3(256), 0, (hipStream_t)stream_, grad_out,
+                     g_sb, g_sp, gate, d_pool, pool_scale, d_in, B, HW, C);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// y[b, n] = act(sum_k x[b, k] W[n, k] + bias[n]); act_code as elsewhere, SR_ACT_SIGMOID = -3 for the gate
+#define SR_ACT_SIGMOID_CODE (-3.0f)
+__device__ __forceinline__ float sr_small_act(float z, float code) {
+  if (code < -2.5f) return 1.0f / (1.0f + __expf(-z));
+  return sr_act_fwd1(z, code);
+}
+__device__ __forceinline__ float sr_small_act_grad(float z, float code) {
+  if (code < -2.5f) { const float s = 1.0f / (1.0f + __expf(-z)); return s * (1.0f - s); }
+  return sr_act_grad1(z, code);
+}
+
+__global__ void sr_small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                           const float* __restrict__ bias, float* __restrict__ pre, float* __restrict__ y,
+                                           int B, int K, int N, float act) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * N) return;
+  const int b = i / N, n = i - b * N;
+  float s = bias ? bias[n] : 0.0f;
+  for (int k = 0; k < K; ++k) s = fmaf(x[b * K + k], W[n * K + k], s);
+  if (pre) pre[i] = s;
+  y[i] = sr_small_act(s, act);
+}
+
+// dpre = dy * act'(pre); dx[b,k] = sum_n dpre[b,n] W[n,k]; dW[n,k] = sum_b dpre[b,n] x[b,k]; db[n] = sum_b dpre[b,n]
+__global__ void sr_small_linear_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
+                                           const float* __restrict__ x, const float* __restrict__ W, float* __restrict__ dx,
+                                           float* __restrict__ dW, float* __restrict__ db, int B, int K, int N, float act) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_dx = B * K, n_dw = N * K;
+  if (i < n_dx) {
+    const int b = i / K, k = i - b * K;
+    float s = 0.0f;
+    for (int n = 0; n < N; ++n) s = fmaf(dy[b * N + n] * sr_small_act_grad(pre[b * N + n], act), W[n * K + k], s);
+    dx[i] = s;
+  } else if (i < n_dx + n_dw) {
+    const int j = i - n_dx, n = j / K, k = j - n * K;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s = fmaf(dy[b * N + n] * sr_small_act_grad(pre[b * N + n], act), x[b * K + k], s);
+    dW[j] = s;
+  } else if (i < n_dx + n_dw + N) {
+    const int n = i - n_dx - n_dw;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += dy[b * N + n] * sr_small_act_grad(pre[b * N + n], act);
+    db[n] = s;
+  }
+}
+
+extern "C" int sr_small_linear_fwd(const float* x, const float* W, const float* bias, float* pre, float* y, int B, int K, int N,
+                                   float act_code, void* stream_) {
+  if (B < 0 || K <= 0 || N <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!x || !W || !y) return SR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sr_small_linear_fwd_kernel, dim3((B * N + 127) / 128), dim3(128), 0, (hipStream_t)stream_, x, W, bias, pre, y,
+                     B, K, N, act_code);
+  return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" int sr_small_linear_bwd(const float* dy, const float* pre, const float* x, const float* W, float* dx, float* dW,
+                                   float* db, int B, int K, int N, float act_code, void* stream_) {
+  if (B <= 0 || K <= 0 || N <= 0 || !dy || !pre || !x || !W || !dx || !dW || !db) return SR_ERR_INVALID_ARGUMENT;
+  const int total = B * K + N * K + N;
+  hipLaunchKernelGGL(sr_small_linear_bwd_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream_, dy, pre, x, W, dx,
+                     dW, db, B, K, N, act_code);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------- generic elementwise ----------------
+// dx = g * act'(z) for a standalone activation whose INPUT z was saved (SiLU after a conv without normalisation)
+__global__ __launch_bounds__(256) void sr_act_in_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                           float* __restrict__ dx, int64_t n, float act) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    dx[e] = g[e] * sr_act_grad1(z[e], act);
+}
+
+extern "C" int sr_act_in_bwd(const float* grad, const float* pre, float* grad_pre, int64_t n, float act_code, void* stream_) {
+  if (n < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (n == 0) return SR_OK;
+  if (!grad || !pre || !grad_pre) return SR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sr_act_in_bwd_kernel, dim3(sr_ew_blocks(n)), dim3(256), 0, (hipStream_t)stream_, grad, pre, grad_pre, n,
+                     act_code);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// out = act(a + b) (b may be null) on dense arrays: the residual join of a ResNet block in training (the inference path
+// has it in the conv epilogue); `pre` (optional) receives a + b for the backward
+__global__ __launch_bounds__(256) void sr_add_act_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ pre, float* __restrict__ out, int64_t n, float act) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float z = a[e] + (b ? b[e] : 0.0f);
+    if (pre) pre[e] = z;
+    out[e] = sr_act_fwd1(z, act);
+  }
+}
+
+extern "C" int sr_add_act_fwd(const float* a, const float* b, float* pre, float* out, int64_t n, float act_code, void* stream_) {
+  if (n < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (n == 0) return SR_OK;
+  if (!a || !out) return SR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sr_add_act_kernel, dim3(sr_ew_blocks(n)), dim3(256), 0, (hipStream_t)stream_, a, b, pre, out, n, act_code);
+  return sr_hip_rc(hipGetLastError());
+}

@@ -14,7 +14,6 @@ pluggable (`image_encoder=`, `matching_encoder=`); `timm_image_encoder()` builds
 constructor call when timm is importable.  `hot_path()` starts from the encoders' outputs.
 """
 import contextlib
-import warnings
 from dataclasses import dataclass
 
 import torch
@@ -90,7 +89,6 @@ def timm_image_encoder(pretrained=True):
 
 
 class DepthModel(nn.Module):
-    _warned_frozen = False
 
     def __init__(self, opts, image_encoder=None, matching_encoder=None):
         super().__init__()
@@ -147,6 +145,8 @@ class DepthModel(nn.Module):
         # run the image-prior encoder on a side HIP stream, concurrently with matching encoder + plane sweep
         self.prior_on_side_stream = True
         self._prior_streams = {}
+        # opt-in: run both encoders under no_grad when autograd is recording (frozen-encoder fine-tune)
+        self.freeze_encoders = False
 
     # ---- reference depth_model.py:191-245 ----------------------------------------------------
     def compute_matching_feats(self, cur_image, src_image, unbatched_matching_encoder_forward):
@@ -281,7 +281,8 @@ class DepthModel(nn.Module):
     def image_prior_pyramid(self, cur_image):
         """`self.encoder(cur_image)` (reference depth_model.py:358), launched on a side HIP stream when the encoder
         runs HIP kernels on the GPU: returns a PendingPyramid that hot_path() joins where the pyramid is consumed."""
-        if not (self.prior_on_side_stream and cur_image.is_cuda and isinstance(self.encoder, EfficientNetV2SFeatures)):
+        if not (self.prior_on_side_stream and cur_image.is_cuda and isinstance(self.encoder, EfficientNetV2SFeatures)) \
+                or self.encoder._train_path(cur_image):   # the differentiable path stays on the caller's stream
             return list(self.encoder(cur_image))
         dev = cur_image.device
         side = self._prior_streams.get(dev)
@@ -296,14 +297,11 @@ class DepthModel(nn.Module):
                         unbatched_matching_encoder_forward=False, return_mask=False, flip=False):
         """DepthModel.forward after the dict unpacking / relative-pose step (reference depth_model.py:358-405):
         image-prior encoder, matching encoder, cost volume, CVEncoder, decoder, exp -- every stage on HIP kernels."""
-        # Training (grad mode): cost volume, CVEncoder and DepthDecoderPP are differentiable on HIP kernels
-        # (autograd_ops, cost_volume._*VolumeFunction); the two encoders have no backward kernels yet, so their outputs
-        # enter the graph as constants (a frozen-encoder fine-tune; stated once).
-        frozen = torch.is_grad_enabled()
-        if frozen and not DepthModel._warned_frozen:
-            DepthModel._warned_frozen = True
-            warnings.warn("simplerecon_amd: the image-prior and matching encoders are inference-only on the HIP path; "
-                          "under autograd their outputs are treated as constants (frozen encoders)")
+        # Training (grad mode): every stage is differentiable on HIP kernels -- the two encoders through train_ops
+        # (BatchNorm per its own mode), the cost volume, CVEncoder and DepthDecoderPP through autograd_ops -- like the
+        # reference's train.py.  `freeze_encoders = True` is the explicit opt-in for a frozen-encoder fine-tune: both
+        # encoders then run under no_grad and their outputs enter the graph as constants.
+        frozen = torch.is_grad_enabled() and self.freeze_encoders
         with torch.no_grad() if frozen else contextlib.nullcontext():
             cur_feats = self.image_prior_pyramid(cur_image)
             matching_cur_feats, matching_src_feats = self.compute_matching_feats(

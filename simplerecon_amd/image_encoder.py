@@ -14,14 +14,23 @@ blocks.<stage>.<i>.{conv, conv_exp, conv_pw, conv_dw, conv_pwl, bn1-3, se.conv_r
 source, no weights in this container): tests compare the HIP path with oracle/ and a torch restatement of the same
 public definition.
 
-The modules only hold parameters.  Every forward runs HIP kernels (ops.conv2d with folded eval-mode BatchNorm and
-SiLU epilogue, ops.dwconv3x3, ops.se_scale_, ops.add_); there is no torch fallback."""
+The modules only hold parameters.  Every forward runs HIP kernels (inference: ops.conv2d with folded eval-mode
+BatchNorm and SiLU epilogue, ops.dwconv3x3, ops.se_scale_, ops.add_; training -- a gradient is wanted or a BatchNorm
+layer is in training mode: the differentiable operators of train_ops, forward and backward on HIP kernels); there is no
+torch fallback."""
 from typing import List
 
 import torch
 from torch import nn
 
 from . import ops
+from . import train_ops as T
+
+
+def _tf_pads(x, conv):
+    """TF-"SAME" pads of a 3x3 conv for this input (None = the symmetric pad 1)."""
+    pads = ops.tf_same_pads(x.shape[2], x.shape[3], conv.kernel_size[0], conv.stride[0])
+    return None if pads == (1, 1, 1, 1) else pads
 
 BN_EPS = 1e-3          # tf_* models
 STEM_CHANNELS = 24
@@ -51,6 +60,10 @@ class ConvBnAct(nn.Module):
         y = ops.conv2d(x, self.conv, bn=self.bn1, act="silu", tf_same=True)
         return ops.add_(y, x) if self.has_skip else y   # the sum follows the activation: not a conv epilogue
 
+    def forward_train(self, x):
+        y = T.batch_norm_act(T.conv(x, self.conv, pads=_tf_pads(x, self.conv)), self.bn1, act=T.ACT_SILU)
+        return T.add(y, x) if self.has_skip else y
+
 
 class EdgeResidual(nn.Module):
     """FusedMBConv: 3x3 expansion conv + BN + SiLU, 1x1 projection + BN, identity skip (stages 1-2)."""
@@ -66,6 +79,11 @@ class EdgeResidual(nn.Module):
     def forward(self, x):
         t = ops.conv2d(x, self.conv_exp, bn=self.bn1, act="silu", tf_same=True)
         return ops.conv2d(t, self.conv_pwl, bn=self.bn2, residual=x if self.has_skip else None, library_gemm=True)
+
+    def forward_train(self, x):
+        t = T.batch_norm_act(T.conv(x, self.conv_exp, pads=_tf_pads(x, self.conv_exp)), self.bn1, act=T.ACT_SILU)
+        y = T.batch_norm_act(T.conv(t, self.conv_pwl), self.bn2)
+        return T.add(y, x) if self.has_skip else y
 
 
 class SqueezeExcite(nn.Module):
@@ -92,6 +110,14 @@ class InvertedResidual(nn.Module):
         d, pool = ops.dwconv3x3(t, self.conv_dw, bn=self.bn2, act="silu", tf_same=True, want_pool=True)
         ops.se_scale_(d, pool, self.se.conv_reduce, self.se.conv_expand)
         return ops.conv2d(d, self.conv_pwl, bn=self.bn3, residual=x if self.has_skip else None, library_gemm=True)
+
+    def forward_train(self, x):
+        t = T.batch_norm_act(T.conv(x, self.conv_pw), self.bn1, act=T.ACT_SILU)
+        pads = ops.tf_same_pads(t.shape[2], t.shape[3], 3, self.conv_dw.stride[0])
+        d = T.batch_norm_act(T.dwconv3x3(t, self.conv_dw, pads), self.bn2, act=T.ACT_SILU)
+        d = T.squeeze_excite(d, self.se.conv_reduce, self.se.conv_expand)
+        y = T.batch_norm_act(T.conv(d, self.conv_pwl), self.bn3)
+        return T.add(y, x) if self.has_skip else y
 
 
 class _FeatureInfo:
@@ -130,10 +156,24 @@ class EfficientNetV2SFeatures(nn.Module):
         self.feature_info = _FeatureInfo(self.num_ch_enc, [2, 4, 8, 16, 32])
         self.eval()
 
+    def _train_path(self, image):
+        from . import autograd_ops
+        return autograd_ops.grad_wanted([image], self) or any(
+            m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+
     def forward(self, image: torch.Tensor) -> List[torch.Tensor]:
-        if self.training:
-            raise NotImplementedError("the HIP image-prior encoder runs eval-mode BatchNorm only (inference path): "
-                                      "call .eval()")
+        if self._train_path(image):
+            # training: the same graph on the differentiable operators of train_ops (conv -> BatchNorm per its own mode ->
+            # SiLU unfused; drop-path rate 0 like timm's default for this model)
+            x = T.batch_norm_act(T.conv(image, self.conv_stem, pads=_tf_pads(image, self.conv_stem)), self.bn1,
+                                 act=T.ACT_SILU)
+            feats = []
+            for i, stage in enumerate(self.blocks):
+                for blk in stage:
+                    x = blk.forward_train(x)
+                if i in FEATURE_STAGES:
+                    feats.append(x)
+            return feats
         x = ops.conv2d(image, self.conv_stem, bn=self.bn1, act="silu", tf_same=True)
         feats = []
         for i, stage in enumerate(self.blocks):

@@ -256,8 +256,9 @@ class ResnetMatchingEncoder(nn.Module):
     conv1x1 64->128, InstanceNorm, LeakyReLU(0.2), conv3x3 128->num_ch_out (replicate padding), InstanceNorm.
 
     `net` has the reference's nn.Sequential numbering (net.0 conv1, net.1 bn1, net.3.1 blur, net.4 layer1,
-    net.5 / net.8 tail convs) so its checkpoints load unchanged.  Inference only: BatchNorm uses running
-    statistics (folded into the conv weights at pack time).  The backbone definition follows the public
+    net.5 / net.8 tail convs) so its checkpoints load unchanged.  Inference (eval mode, no gradient wanted): BatchNorm
+    uses running statistics folded into the conv weights at pack time, fused kernels.  Training: `_forward_train`, the
+    same graph on differentiable operators, BatchNorm per its own mode.  The backbone definition follows the public
     antialiased_cnns package, which is not available here -- parity for it is pinned against a torch.nn
     restatement only (oracle/refshim.py)."""
 
@@ -294,6 +295,12 @@ class ResnetMatchingEncoder(nn.Module):
         from . import ops
         b, k = src_image.shape[:2]
         h, w = cur_image.shape[-2:]
+        if self._train_path(cur_image, src_image):
+            # training: one batch of B(1+K) images like the reference's TensorFormatter call (depth_model.py:234-240);
+            # BatchNorm statistics run over all of them
+            feats = self._forward_train(torch.cat([cur_image.unsqueeze(1), src_image], dim=1).flatten(0, 1))
+            feats = feats.unflatten(0, (b, 1 + k))
+            return feats[:, 0], feats[:, 1:]
         ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         stem = ops.empty_nhwc(b * (1 + k), 64, ho, wo, cur_image.device)
         ops.stem7x7(cur_image, self.net[0], self.net[1], out=stem[:b])
@@ -301,18 +308,42 @@ class ResnetMatchingEncoder(nn.Module):
         feats = self._after_stem(stem)
         return feats[:b], feats[b:].unflatten(0, (b, k))
 
+    def _train_path(self, *tensors):
+        """Training / differentiable path: autograd is recording and something wants a gradient, or a BatchNorm layer is
+        in training mode (batch statistics cannot be folded into the conv weights)."""
+        from . import autograd_ops
+        return autograd_ops.grad_wanted(list(tensors), self) or any(
+            m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+
+    def _forward_train(self, image):
+        """The reference's nn.Sequential (networks.py:176-201) operator by operator on the differentiable HIP operators
+        of train_ops: conv1 -> bn1 (batch statistics when the layer is in training mode) + ReLU -> MaxPool(2,1) +
+        BlurPool -> layer1 (two BasicBlocks with BatchNorm) -> conv1x1 -> InstanceNorm + LeakyReLU -> replicate-padded
+        conv3x3 -> InstanceNorm."""
+        from . import train_ops as T
+        net = self.net
+        x = T.stem7x7(image, net[0])
+        x = T.batch_norm_act(x, net[1], act=0.0)
+        x = T.maxblurpool(x)
+        for blk in net[4]:
+            t = T.batch_norm_act(T.conv(x, blk.conv1), blk.bn1, act=0.0)
+            t = T.batch_norm_act(T.conv(t, blk.conv2), blk.bn2)
+            x = T.add(t, x, act=0.0)
+        x = T.conv(x, net[5])
+        x = T.instance_norm_act(x, eps=net[6].eps, leaky=net[7].negative_slope)
+        x = T.conv(T.replicate_pad(x, 1), net[8], pads=(0, 0, 0, 0))
+        return T.instance_norm_act(x, eps=net[9].eps)
+
     def forward(self, input_image):
         """input_image [B,3,H,W] (H, W multiples of 4) -> [B,num_ch_out,H/4,W/4] (channels_last memory)."""
         from . import ops
-        if self.training:
-            raise RuntimeError("ResnetMatchingEncoder on the HIP path is inference-only (call .eval())")
+        if self._train_path(input_image):
+            return self._forward_train(input_image)
         return self._after_stem(ops.stem7x7(input_image, self.net[0], self.net[1]))   # conv1 + bn1 + relu
 
     def _after_stem(self, x):
         from . import ops
         net = self.net
-        if self.training:
-            raise RuntimeError("ResnetMatchingEncoder on the HIP path is inference-only (call .eval())")
         x = ops.maxblurpool(x)                                              # MaxPool(2,1) + BlurPool(4,2)
         for blk in net[4]:
             t = ops.conv2d(x, blk.conv1, bn=blk.bn1, leaky=0.0)

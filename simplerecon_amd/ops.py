@@ -637,7 +637,7 @@ def packed_dw_weight(conv: nn.Conv2d, bn=None):
     return w9c, bias
 
 
-def dwconv3x3(x, conv: nn.Conv2d, bn=None, leaky=None, act=None, tf_same=False, want_pool=False):
+def dwconv3x3(x, conv: nn.Conv2d, bn=None, leaky=None, act=None, tf_same=False, want_pool=False, pads=None):
     """act(bn(depthwise_conv3x3(x))) on a channels-last view; with want_pool also returns the per-band partial sums
     of the result ([B, bands, C]) from which `se_gate` finishes the squeeze-excite average pool."""
     _lib.refuse_autograd(x, conv.weight)
@@ -648,9 +648,10 @@ def dwconv3x3(x, conv: nn.Conv2d, bn=None, leaky=None, act=None, tf_same=False, 
     s = conv.stride[0]
     if conv.stride[0] != conv.stride[1] or s not in (1, 2):
         raise _lib.HipLibraryError(f"unsupported stride {conv.stride}")
-    if not tf_same and tuple(conv.padding) != (1, 1):
+    if pads is None and not tf_same and tuple(conv.padding) != (1, 1):
         raise _lib.HipLibraryError(f"unsupported padding {conv.padding}")
-    pads = tf_same_pads(h, w, 3, s) if tf_same else (1, 1, 1, 1)
+    if pads is None:
+        pads = tf_same_pads(h, w, 3, s) if tf_same else (1, 1, 1, 1)
     ho, wo = (h + pads[0] + pads[2] - 3) // s + 1, (w + pads[1] + pads[3] - 3) // s + 1
     w9c, bias = packed_dw_weight(conv, bn)
     lib = _lib.lib()

@@ -21,13 +21,21 @@ def _conv_same(x, w, s=1, groups=1):
     return F.conv2d(_same(x, w.shape[-1], s), w, None, stride=s, groups=groups)
 
 
+_TRAINING = False
+
+
 def _bn(x, sd, pre, act):
-    y = F.batch_norm(x, sd[pre + "running_mean"], sd[pre + "running_var"], sd[pre + "weight"], sd[pre + "bias"],
-                     training=False, eps=1e-3)
+    rm, rv = sd[pre + "running_mean"], sd[pre + "running_var"]
+    if _TRAINING:   # batch statistics; the running buffers are updated on clones (callers compare gradients / outputs)
+        rm, rv = rm.detach().clone(), rv.detach().clone()
+    y = F.batch_norm(x, rm, rv, sd[pre + "weight"], sd[pre + "bias"], training=_TRAINING, eps=1e-3)
     return F.silu(y) if act else y
 
 
-def features(img, sd):
+def features(img, sd, training=False):
+    """training=True: BatchNorm with batch statistics (what the reference's train.py runs); differentiable either way."""
+    global _TRAINING
+    _TRAINING = training
     x = _bn(_conv_same(img, sd["conv_stem.weight"], 2), sd, "bn1.", True)
     feats, cin = [], 24
     for si, (kind, reps, stride, _e, cout) in enumerate(ARCH):

@@ -174,6 +174,11 @@ def matching_input(case, device="cpu"):
     return torch.from_numpy(x).to(device)
 
 
+def encoder_cotangent(case, shape):
+    """Seeded cotangent of an encoder output (gradient goldens of the training path)."""
+    return np.random.default_rng(case["seed"] + 500).standard_normal(shape).astype(np.float32)
+
+
 # ------------------------------------------------------------ TSDF fusion (§8f "next" #2)
 
 TSDF_CASES = {
