@@ -20,7 +20,12 @@
 // the benchmarked path; correctness against the reference's autograd is what tests/ pin.
 #include "sr_common.h"
 
-#define SR_TR_CHUNK_PIX 512   // pixels per partial of a column reduction
+// pixels per partial of a column reduction (grid = chunks x groups x 64-channel blocks): 256, or more so that the
+// serial finishing loop over the chunks stays <= 1024 long
+static inline int sr_tr_chunk_pix(int64_t npix) {
+  const int64_t c = (npix + 1023) / 1024;
+  return (int)(c < 256 ? 256 : c);
+}
 
 __device__ __forceinline__ float sr_act_fwd1(float z, float code) {
   if (code >= 0.0f) return z >= 0.0f ? z : z * code;
@@ -42,7 +47,7 @@ struct SrColRed {
   const float* g; int64_t g_sb; int g_sp;
   const float* mean; const float* var; const float* gamma; const float* beta;
   float eps, act;
-  int B, HW, C, per_image, chunks;   // chunks per group
+  int B, HW, C, per_image, chunks, chunk_pix;   // chunks per group, pixels per chunk
   float* part0; float* part1;
 };
 
@@ -53,9 +58,9 @@ __global__ __launch_bounds__(256) void sr_colreduce_kernel(SrColRed p) {
   const int64_t npix = p.per_image ? p.HW : (int64_t)p.B * p.HW;   // pixels per group
   const int chunk = blockIdx.x, n = blockIdx.y;
   const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
-  const int64_t p0 = (int64_t)chunk * SR_TR_CHUNK_PIX, p1 = min(p0 + SR_TR_CHUNK_PIX, npix);
-  for (int c0 = 0; c0 < p.C; c0 += 64) {
-    const int c = c0 + cl;
+  const int64_t p0 = (int64_t)chunk * p.chunk_pix, p1 = min(p0 + p.chunk_pix, npix);
+  {
+    const int c = blockIdx.z * 64 + cl;
     float s0 = 0.0f, s1 = 0.0f;
     if (c < p.C) {
       const int sc = n * p.C + c;
@@ -85,7 +90,6 @@ __global__ __launch_bounds__(256) void sr_colreduce_kernel(SrColRed p) {
       p.part0[o] = (red0[0][cl] + red0[1][cl]) + (red0[2][cl] + red0[3][cl]);
       if (MODE == 2) p.part1[o] = (red1[0][cl] + red1[1][cl]) + (red1[2][cl] + red1[3][cl]);
     }
-    __syncthreads();
   }
 }
 
@@ -101,7 +105,8 @@ __global__ void sr_colreduce_finish_kernel(const float* __restrict__ part, int c
 
 static int sr_tr_chunks(int B, int HW, int per_image) {
   const int64_t npix = per_image ? HW : (int64_t)B * HW;
-  return (int)((npix + SR_TR_CHUNK_PIX - 1) / SR_TR_CHUNK_PIX);
+  const int cp = sr_tr_chunk_pix(npix);
+  return (int)((npix + cp - 1) / cp);
 }
 
 extern "C" size_t sr_norm_workspace_bytes(int B, int HW, int C, int per_image) {
@@ -113,7 +118,7 @@ extern "C" size_t sr_norm_workspace_bytes(int B, int HW, int C, int per_image) {
 template <int MODE>
 static int sr_colreduce(SrColRed p, float* out0, float scale0, float* out1, float scale1, hipStream_t stream) {
   const int G = p.per_image ? p.B : 1;
-  hipLaunchKernelGGL(sr_colreduce_kernel<MODE>, dim3(p.chunks, G), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(sr_colreduce_kernel<MODE>, dim3(p.chunks, G, (p.C + 63) / 64), dim3(256), 0, stream, p);
   const int n_out = G * p.C;
   hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, p.part0, p.chunks, n_out,
                      scale0, out0);
@@ -132,6 +137,7 @@ extern "C" int sr_norm_stats_nhwc(const float* x, int64_t x_sb, int x_sp, int B,
   SrColRed p = {};
   p.x = x; p.x_sb = x_sb; p.x_sp = x_sp; p.B = B; p.HW = HW; p.C = C; p.per_image = per_image;
   p.chunks = sr_tr_chunks(B, HW, per_image);
+  p.chunk_pix = sr_tr_chunk_pix(per_image ? (int64_t)HW : (int64_t)B * HW);
   p.part0 = (float*)workspace; p.part1 = nullptr;
   const float inv_n = 1.0f / (float)(per_image ? (int64_t)HW : (int64_t)B * HW);
   int rc = sr_colreduce<0>(p, mean, inv_n, nullptr, 0.f, stream);
@@ -209,6 +215,7 @@ extern "C" int sr_norm_act_bwd_nhwc(const float* g, int64_t g_sb, int g_sp, cons
   r.x = x; r.x_sb = x_sb; r.x_sp = x_sp; r.g = g; r.g_sb = g_sb; r.g_sp = g_sp;
   r.mean = mean; r.var = var; r.gamma = gamma; r.beta = beta; r.eps = eps; r.act = act_code;
   r.B = B; r.HW = HW; r.C = C; r.per_image = per_image; r.chunks = sr_tr_chunks(B, HW, per_image);
+  r.chunk_pix = sr_tr_chunk_pix(per_image ? (int64_t)HW : (int64_t)B * HW);
   const size_t part = (size_t)r.chunks * G * C;
   r.part0 = (float*)workspace; r.part1 = r.part0 + part;
   float* s0 = r.part1 + part; float* s1 = s0 + (size_t)G * C;   // column SUMS of g', g' * xhat
@@ -235,7 +242,7 @@ extern "C" int sr_rowsum_nhwc(const float* x, int64_t x_sb, int x_sp, const floa
   if (workspace_bytes < sr_norm_workspace_bytes(B, HW, C, 1)) return SR_ERR_WORKSPACE_TOO_SMALL;
   SrColRed p = {};
   p.x = x; p.x_sb = x_sb; p.x_sp = x_sp; p.g = g; p.g_sb = g_sb; p.g_sp = g_sp;
-  p.B = B; p.HW = HW; p.C = C; p.per_image = 1; p.chunks = sr_tr_chunks(B, HW, 1);
+  p.B = B; p.HW = HW; p.C = C; p.per_image = 1; p.chunks = sr_tr_chunks(B, HW, 1); p.chunk_pix = sr_tr_chunk_pix(HW);
   p.part0 = (float*)workspace;
   return g ? sr_colreduce<3>(p, out, scale, nullptr, 0.f, (hipStream_t)stream_)
            : sr_colreduce<0>(p, out, scale, nullptr, 0.f, (hipStream_t)stream_);
@@ -472,14 +479,14 @@ __global__ __launch_bounds__(256) void sr_dw_dgrad_kernel(const float* __restric
 __global__ __launch_bounds__(256) void sr_dw_wgrad_kernel(const float* __restrict__ g, int64_t g_sb, int g_sp,
                                                          const float* __restrict__ x, int64_t x_sb, int x_sp,
                                                          float* __restrict__ part, int B, int H, int W, int Ho, int Wo, int C,
-                                                         int s, int pt, int pl) {
+                                                         int s, int pt, int pl, int chunk_pix) {
   __shared__ float red[4][9][64];
   const int chunk = blockIdx.x;
   const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
   const int64_t npix = (int64_t)B * Ho * Wo;
-  const int64_t p0 = (int64_t)chunk * SR_TR_CHUNK_PIX, p1 = min(p0 + SR_TR_CHUNK_PIX, npix);
-  for (int c0 = 0; c0 < C; c0 += 64) {
-    const int c = c0 + cl;
+  const int64_t p0 = (int64_t)chunk * chunk_pix, p1 = min(p0 + chunk_pix, npix);
+  {
+    const int c = blockIdx.y * 64 + cl;
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
@@ -503,14 +510,13 @@ __global__ __launch_bounds__(256) void sr_dw_wgrad_kernel(const float* __restric
       for (int t = 0; t < 9; ++t)   // part layout [chunk][c][tap] = the weight's own [C][3][3] layout per chunk
         part[((size_t)chunk * C + c) * 9 + t] = (red[0][t][cl] + red[1][t][cl]) + (red[2][t][cl] + red[3][t][cl]);
     }
-    __syncthreads();
   }
 }
 
 extern "C" size_t sr_dwconv3x3_bwd_workspace_bytes(int B, int Ho, int Wo, int C) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return 0;
-  const int64_t chunks = ((int64_t)B * Ho * Wo + SR_TR_CHUNK_PIX - 1) / SR_TR_CHUNK_PIX;
-  return (size_t)chunks * C * 9 * sizeof(float);
+  const int64_t npix = (int64_t)B * Ho * Wo, cp = sr_tr_chunk_pix(npix);
+  return (size_t)((npix + cp - 1) / cp) * C * 9 * sizeof(float);
 }
 
 // weight [C][3][3] (PyTorch depthwise layout [C,1,3,3]); d_in dense channels-last [B,H,W,C]; either output may be null
@@ -533,9 +539,10 @@ extern "C" int sr_dwconv3x3_bwd_nhwc(const float* grad_out, int64_t g_sb, int g_
   if (d_weight) {
     if (!x || !workspace) return SR_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < sr_dwconv3x3_bwd_workspace_bytes(B, Ho, Wo, C)) return SR_ERR_WORKSPACE_TOO_SMALL;
-    const int chunks = (int)(((int64_t)B * Ho * Wo + SR_TR_CHUNK_PIX - 1) / SR_TR_CHUNK_PIX);
-    hipLaunchKernelGGL(sr_dw_wgrad_kernel, dim3(chunks), dim3(256), 0, stream, grad_out, g_sb, g_sp, x, x_sb, x_sp,
-                       (float*)workspace, B, H, W, Ho, Wo, C, stride, pad_top, pad_left);
+    const int64_t npix = (int64_t)B * Ho * Wo;
+    const int cp = sr_tr_chunk_pix(npix), chunks = (int)((npix + cp - 1) / cp);
+    hipLaunchKernelGGL(sr_dw_wgrad_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, stream, grad_out, g_sb, g_sp, x, x_sb, x_sp,
+                       (float*)workspace, B, H, W, Ho, Wo, C, stride, pad_top, pad_left, cp);
     hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, stream, (const float*)workspace,
                        chunks, C * 9, 1.0f, d_weight);
   }
