@@ -300,9 +300,13 @@ __global__ __launch_bounds__(256) void sr_act_bwd_bias_kernel(const float4* __re
                                                              int64_t pixels, int CQ, int LQ, int PB, float slope) {
   __shared__ float4 red[256];
   const int q0 = threadIdx.x % LQ, p0 = threadIdx.x / LQ;   // channel quad / pixel lane; lanes with p0 >= PB idle
-  for (int q = q0; q < CQ; q += LQ) {
+  // uniform trip count (the body holds workgroup barriers): every thread runs ceil(CQ / LQ) rounds, lanes whose quad is
+  // past CQ in the last round only take part in the barriers (C > 1024 with C % 1024 != 0 used to diverge here)
+  for (int qb = 0; qb < CQ; qb += LQ) {
+    const int q = qb + q0;
+    const bool live = q < CQ;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p0 < PB) {
+    if (p0 < PB && live) {
       // 8 pixels per trip, their loads issued together (one load in flight per lane made this pass latency-bound)
       constexpr int U = 8;
       const int64_t step = (int64_t)gridDim.x * PB;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256) void sr_act_bwd_bias_kernel(const float4* __re
     if (partial) {   // uniform
       red[threadIdx.x] = s;
       __syncthreads();
-      if (p0 == 0) {
+      if (p0 == 0 && live) {
         float4 t = red[q0];
         for (int k = 1; k < PB; ++k) { const float4 r = red[k * LQ + q0]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
         partial[(int64_t)blockIdx.x * CQ + q] = t;

@@ -8,8 +8,9 @@
 // Column-major view handed to hipBLASLt:  D (Cout x M, ld = out pixel stride) = op_T(A = W as Cin x Cout, ld = Cin) .
 // B (= X as Cin x M, ld = in pixel stride) [+ C = residual, beta = 1]; bias per row of D, SiLU = the SWISH_EXT epilogue.
 // fp32 in / out / accumulate (HIPBLAS_COMPUTE_32F: gfx950 has no xf32 path) -- same arithmetic class as sr_conv.hip.
-// The handle and the per-shape algorithm choices are process-wide caches (created on first use, under a mutex): the
-// one place where this library keeps state, never freed.  The choice per shape is made by timing hipBLASLt's heuristic
+// The handles (one per DEVICE) and the per-(device, shape) algorithm choices are process-wide caches (created on first use,
+// under a mutex): the one place where this library keeps state, never freed.  A shape hipBLASLt cannot serve is cached as
+// such (its descriptors released), so later calls fall back to the HIP kernel without repeating the heuristic query.  The choice per shape is made by timing hipBLASLt's heuristic
 // candidates once (first call with that shape; it synchronises the stream then and only then).
 #include <hipblaslt/hipblaslt.h>
 
@@ -24,17 +25,28 @@
 namespace {
 
 struct Plan {
-  hipblasLtMatmulDesc_t desc;
-  hipblasLtMatrixLayout_t la, lb, lc, ld;
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr, ld = nullptr;
   hipblasLtMatmulAlgo_t algo;
-  size_t workspace;
+  size_t workspace = 0;
+  bool ok = false;
 };
 
-typedef std::tuple<int, int, int, int, int, int, int, int> Key;   // M, Cin, Cout, in_sp, out_sp, res_sp, act, has_bias
+// M, Cin, Cout, in_sp, out_sp, res_sp, act, has_bias, device
+typedef std::tuple<int, int, int, int, int, int, int, int, int> Key;
 
 std::mutex g_mutex;
-hipblasLtHandle_t g_handle = nullptr;
+std::map<int, hipblasLtHandle_t> g_handles;   // per device
 std::map<Key, Plan> g_plans;
+
+void release(Plan& p) {
+  if (p.desc) hipblasLtMatmulDescDestroy(p.desc);
+  if (p.la) hipblasLtMatrixLayoutDestroy(p.la);
+  if (p.lb) hipblasLtMatrixLayoutDestroy(p.lb);
+  if (p.lc) hipblasLtMatrixLayoutDestroy(p.lc);
+  if (p.ld) hipblasLtMatrixLayoutDestroy(p.ld);
+  p.desc = nullptr; p.la = p.lb = p.lc = p.ld = nullptr;
+}
 
 constexpr size_t kWorkspace = 32u << 20;
 
@@ -46,7 +58,15 @@ struct TuneArgs {
 
 constexpr int kCandidates = 12;
 
-bool make_plan(const Key& key, Plan& plan, const TuneArgs& ta) {
+bool make_plan_impl(hipblasLtHandle_t g_handle, const Key& key, Plan& plan, const TuneArgs& ta);
+
+bool make_plan(hipblasLtHandle_t handle, const Key& key, Plan& plan, const TuneArgs& ta) {
+  plan.ok = make_plan_impl(handle, key, plan, ta);
+  if (!plan.ok) release(plan);   // nothing leaks; the negative result stays cached
+  return plan.ok;
+}
+
+bool make_plan_impl(hipblasLtHandle_t g_handle, const Key& key, Plan& plan, const TuneArgs& ta) {
   const int M = std::get<0>(key), Cin = std::get<1>(key), Cout = std::get<2>(key), in_sp = std::get<3>(key);
   const int out_sp = std::get<4>(key), res_sp = std::get<5>(key), act = std::get<6>(key), has_bias = std::get<7>(key);
   if (hipblasLtMatmulDescCreate(&plan.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return false;
@@ -129,25 +149,25 @@ extern "C" int sr_gemm1x1_nhwc_fwd(const float* in, int in_pix_stride, const flo
   if (!in || !weight || !out || in_pix_stride < Cin || out_pix_stride < Cout || (residual && res_pix_stride < Cout))
     return SR_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < kWorkspace || !workspace) return SR_ERR_WORKSPACE_TOO_SMALL;
-  const Key key(M, Cin, Cout, in_pix_stride, out_pix_stride, residual ? res_pix_stride : 0, act, bias ? 1 : 0);
-  Plan plan;
-  {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return SR_ERR_UNSUPPORTED;
-    auto it = g_plans.find(key);
-    if (it == g_plans.end()) {
-      Plan p{};
-      const TuneArgs ta = {in, weight, bias, residual, out, workspace, (hipStream_t)stream};
-      if (!make_plan(key, p, ta)) return SR_ERR_UNSUPPORTED;
-      it = g_plans.emplace(key, p).first;
-    }
-    plan = it->second;
-  }
-  // the bias pointer is an attribute of the (shared) descriptor: set it under the lock together with the launch
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return SR_ERR_UNSUPPORTED;
+  const Key key(M, Cin, Cout, in_pix_stride, out_pix_stride, residual ? res_pix_stride : 0, act, bias ? 1 : 0, device);
+  // one lock for the lookup AND the launch: the bias pointer is an attribute of the (shared) descriptor
   std::lock_guard<std::mutex> lock(g_mutex);
+  hipblasLtHandle_t& handle = g_handles[device];
+  if (!handle && hipblasLtCreate(&handle) != HIPBLAS_STATUS_SUCCESS) { handle = nullptr; return SR_ERR_UNSUPPORTED; }
+  auto it = g_plans.find(key);
+  if (it == g_plans.end()) {
+    Plan p;
+    const TuneArgs ta = {in, weight, bias, residual, out, workspace, (hipStream_t)stream};
+    make_plan(handle, key, p, ta);
+    it = g_plans.emplace(key, p).first;
+  }
+  const Plan& plan = it->second;
+  if (!plan.ok) return SR_ERR_UNSUPPORTED;
   if (bias) hipblasLtMatmulDescSetAttribute(plan.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
   const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
-  const hipblasStatus_t st = hipblasLtMatmul(g_handle, plan.desc, &alpha, weight, plan.la, in, plan.lb, &beta,
+  const hipblasStatus_t st = hipblasLtMatmul(handle, plan.desc, &alpha, weight, plan.la, in, plan.lb, &beta,
                                              residual ? residual : out, plan.lc, out, plan.ld, &plan.algo, workspace,
                                              kWorkspace, (hipStream_t)stream);
   return st == HIPBLAS_STATUS_SUCCESS ? SR_OK : SR_ERR_UNSUPPORTED;

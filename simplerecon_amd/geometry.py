@@ -66,7 +66,20 @@ class Project3D(nn.Module):
 
 def pose_distance(pose_b44):
     """DVMVS pose distance (reference geometry_utils.py:178-191): (combined, R_measure, t_measure), each [B] -- the very
-    values the metadata-MLP sweep computes for its pose channels (csrc/sr_dot_volume.hip: sr_geom_kernel)."""
+    values the metadata-MLP sweep computes for its pose channels (csrc/sr_dot_volume.hip: sr_geom_kernel).
+
+    HOST tensors take the host path: the reference calls this inside dataset workers on CPU poses to order the source
+    frames (generic_mvs_dataset.py:643-659) -- host-side data preparation like keyframes.py, a few scalar operations per
+    pose in numpy (float32, the reference's operation order), not a fallback of the device hot path."""
+    if isinstance(pose_b44, torch.Tensor) and not pose_b44.is_cuda:
+        import numpy as np
+        T = pose_b44.detach().to(torch.float32).numpy()
+        R = T[:, :3, :3]
+        tr = np.minimum(np.float32(3.0), R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2])
+        r_m = np.sqrt(np.float32(2.0) * (np.float32(1.0) - tr / np.float32(3.0)))
+        t_m = np.sqrt((T[:, :3, 3] ** 2).sum(1, dtype=np.float32))
+        d = np.sqrt(t_m * t_m + r_m * r_m)
+        return tuple(torch.from_numpy(np.ascontiguousarray(v.astype(np.float32))) for v in (d, r_m, t_m))
     T = _f32c("pose_b44", pose_b44)
     n = T.shape[0]
     out = torch.empty((n, 3), dtype=torch.float32, device=T.device)

@@ -184,10 +184,12 @@ def gemm_weight(conv: nn.Conv2d, bn=None):
     key = _state_key(conv, bn)
     hit = _GEMM_W.get(conv)
     if hit is not None and hit[0] == key:
+        _await_packed(conv, "gemm", conv.weight.device)   # folded on another stream's first call?  wait for it
         return hit[1], hit[2]
     w, bias = _effective_weight(conv, bn)
     w2d = w.reshape(w.shape[0], w.shape[1]).contiguous()
     bias = bias.contiguous() if bias is not None else None
+    _packed_here(conv, "gemm", conv.weight.device)
     _GEMM_W[conv] = (key, w2d, bias)
     return w2d, bias
 

@@ -106,3 +106,17 @@ def test_reference_matching_encoder_checkpoint_loads_strictly(ref):
     state-dict key are the reference's (networks.py:163-201)."""
     _assert_state_dicts_interchange(nets.ResnetMatchingEncoder(18, 16).eval(),
                                     ref["nets"].ResnetMatchingEncoder(18, 16, pretrained=False).eval())
+
+
+def test_pose_distance_on_host_tensors_matches_the_reference():
+    """The reference's dataset workers call pose_distance on CPU poses (generic_mvs_dataset.py:643-659): host tensors take
+    the host path and give the reference's values."""
+    import numpy as np
+    from simplerecon_amd import geometry
+    rgeo = refshim.import_reference()[3]
+    poses, _ = synthetic.poses(3, 5, seed=2)
+    T = torch.from_numpy(poses.reshape(-1, 4, 4))
+    ours, ref = geometry.pose_distance(T), rgeo.pose_distance(T)
+    for a, b in zip(ours, ref):
+        assert a.shape == b.shape and not a.is_cuda
+        assert np.allclose(a.numpy(), b.numpy(), rtol=1e-6, atol=1e-7)
