@@ -59,8 +59,11 @@ def test_geometry_helpers_on_hip():
     rays_c = geometry.get_camera_rays(None, wpts, in_camera_frame=True, cam_T_world_b44=T)
     ref_c = F.normalize(torch.matmul(T[:, :3, :4], torch.cat([wpts, torch.ones_like(wpts[:, :1])], 1)), dim=1)
     assert_close(rays_c, ref_c, tol=1e-6, what="get_camera_rays (camera frame)")
+    # host poses (the reference's dataset workers, generic_mvs_dataset.py:643-659) take the host path: same values
+    dist_h, rm_h, tm_h = geometry.pose_distance(poses.cpu())
+    assert not dist_h.is_cuda and torch.allclose(tm_h, tm.cpu(), rtol=1e-6) and torch.allclose(rm_h ** 2, rm.cpu() ** 2, atol=2e-7)
     with pytest.raises(Exception):
-        geometry.pose_distance(poses.cpu())   # no CPU fallback
+        geometry.BackprojectDepth(h, w)(depth.cpu(), inp["cur_invK"].cpu())   # device modules: no CPU fallback
 
 
 def _torch_warp(inp, planes_b1hw, h, w):
