@@ -128,11 +128,17 @@ def test_forward_api_signature_and_output_keys():
     assert {f"log_depth_pred_s{i}_b1hw" for i in range(4)} <= keys and {f"depth_pred_s{i}_b1hw" for i in range(4)} <= keys
     assert {"lowest_cost_bhw", "overall_mask_bhw"} <= keys
     assert out["depth_pred_s0_b1hw"].shape == (B, 1, H // 2, W // 2) and torch.isfinite(out["depth_pred_s0_b1hw"]).all()
+    # under autograd the same call is the training forward (every stage differentiable on HIP kernels): outputs carry a graph
+    with torch.enable_grad():
+        pyr = [t.detach().requires_grad_() for t in model.encoder(cur["image_b3hw"])]
+        tr = model.hot_path(pyr, inp["cur_feats"], inp["src_feats"].requires_grad_(), inp["src_extrinsics"], inp["src_poses"],
+                            inp["src_Ks"], inp["cur_invK"])
+    assert tr["depth_pred_s0_b1hw"].requires_grad and not tr["lowest_cost_bhw"].requires_grad
+    # geometry is data, as in the reference: a pose that asks for a gradient is refused
     with pytest.raises(NotImplementedError):
         with torch.enable_grad():
-            model.hot_path([t.requires_grad_() for t in model.encoder(cur["image_b3hw"])], inp["cur_feats"],
-                           inp["src_feats"].requires_grad_(), inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
-                           inp["cur_invK"])
+            model.hot_path(pyr, inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"].clone().requires_grad_(),
+                           inp["src_poses"], inp["src_Ks"], inp["cur_invK"])
 
 
 def test_full_size_hot_path_properties():
