@@ -56,8 +56,10 @@ def test_only_requested_gradients_and_geometry_is_data():
     assert_close(cur.grad, gold["d_cur_feats"], what="d cur_feats alone")
     with pytest.raises(NotImplementedError):
         mgr(**dict(inp, src_Ks=inp["src_Ks"].clone().requires_grad_()))
-    # the metadata-MLP manager has no backward kernel yet: it still refuses
+    # the metadata-MLP manager is differentiable out of the box too; opting out makes it refuse
     hero = FeatureVolumeManager(case["h"], case["w"], num_depth_bins=case["D"], num_source_views=case["K"]).to(DEV)
+    assert hero(**dict(inp, cur_feats=cur))[0].requires_grad
+    hero.differentiable = False
     with pytest.raises(NotImplementedError):
         hero(**dict(inp, cur_feats=cur))
     with torch.no_grad():

@@ -169,7 +169,8 @@ def test_refuses_training_mode_and_cpu():
     with pytest.raises(_lib.HipLibraryError):
         with torch.inference_mode():
             enc(torch.zeros(1, 3, 64, 64))
+    # training mode = the differentiable graph with batch-statistics BatchNorm (tests/test_gpu_encoder_training.py)
     enc = enc.to(DEV)
     enc.train()
-    with pytest.raises(NotImplementedError):
-        enc(torch.zeros(1, 3, 64, 64, device=DEV))
+    feats = enc(torch.randn(2, 3, 64, 64, device=DEV))
+    assert all(f.requires_grad for f in feats) and [f.shape[1] for f in feats] == [24, 48, 64, 160, 256]

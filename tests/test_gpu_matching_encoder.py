@@ -168,11 +168,12 @@ def test_forward_pair_equals_concatenated_forward():
 
 def test_training_mode_and_bad_configs_fail_loudly():
     enc = ResnetMatchingEncoder(18, 16).to(DEV)
-    with pytest.raises(RuntimeError):
-        enc.train()(torch.zeros(1, 3, 32, 32, device=DEV))
+    y = enc.train()(torch.randn(2, 3, 32, 32, device=DEV))   # training mode: the differentiable graph, batch-statistics BN
+    assert y.requires_grad and tuple(y.shape) == (2, 16, 8, 8)
     with pytest.raises(ValueError):
         ResnetMatchingEncoder(17, 16)
     with pytest.raises(ValueError), torch.inference_mode():
         ops.stem7x7(torch.zeros(1, 4, 32, 32, device=DEV), enc.net[0], enc.net[1])
-    with pytest.raises(NotImplementedError):  # autograd is refused, not silently ignored
-        enc.eval()(torch.zeros(1, 3, 32, 32, device=DEV))
+    assert enc.eval()(torch.randn(1, 3, 32, 32, device=DEV)).requires_grad   # eval-mode BatchNorm, gradients still flow
+    with torch.no_grad():
+        assert not enc(torch.randn(1, 3, 32, 32, device=DEV)).requires_grad   # the fused inference kernels
