@@ -19,6 +19,14 @@ from . import _lib
 from .ops import _is_nhwc_view, _strides, _workspace, as_nhwc, empty_nhwc
 
 
+# torch.autocast compatibility (the reference trains under 16-bit autocast, options.py:100-101, train.py:132): every
+# differentiable operator here runs its fp32 HIP kernels whatever the autocast state -- floating-point CUDA inputs that
+# arrive in fp16 / bf16 are cast to fp32 at the operator's entry (a differentiable cast: gradients go back in the caller's
+# dtype) and autocast is off inside.  fp32 compute and fp32 storage: more accurate than the reference's half-precision
+# convolutions, without their memory saving (an fp16-storage variant of the kernels is not built).
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 FUSED_ACT_BIAS = os.environ.get("SR_FUSED_ACT_BIAS", "1") != "0"   # 0: separate sr_act_bwd + sr_bias_grad_nhwc launches (r02 a/b)
 
 
@@ -98,6 +106,7 @@ class _ConvBiasAct(torch.autograd.Function):
     the valid convolution behind the matching encoder's replicate pad)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight, bias, residual, stride, slope, pads=None):
         for name, t in (("conv input", x), ("conv weight", weight)):
             _lib.require_device_f32(name, t)
@@ -109,6 +118,7 @@ class _ConvBiasAct(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         x, weight, out = ctx.saved_tensors
         lib = _lib.lib()
@@ -190,12 +200,14 @@ class _Upsample2x(torch.autograd.Function):
     """Bilinear x2, align_corners=False (reference generic_utils.py:96-105) with its adjoint as backward."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x):
         from . import ops
         with torch.no_grad():
             return ops.upsample2x(x.detach())
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         g = _dense_nhwc(g)
         b, c, h2, w2 = g.shape
@@ -215,6 +227,7 @@ class _Exp(torch.autograd.Function):
     """depth = exp(log_depth) (reference depth_model.py:392-400); backward = grad * depth."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x):
         from . import ops
         with torch.no_grad():
@@ -223,6 +236,7 @@ class _Exp(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         (y,) = ctx.saved_tensors
         g = g.contiguous() if y.is_contiguous() else g.contiguous(memory_format=torch.channels_last)

@@ -17,6 +17,7 @@ from . import _lib, autograd_ops, ops
 from .ops import _strides, _workspace, as_nhwc, empty_nhwc
 
 ACT_NONE, ACT_SILU, ACT_SIGMOID = -1.0, -2.0, -3.0
+_amp_fwd, _amp_bwd = autograd_ops._amp_fwd, autograd_ops._amp_bwd   # fp32 kernels under torch.autocast (see autograd_ops)
 
 
 def _dense(t, name="tensor"):
@@ -40,6 +41,7 @@ class _NormAct(torch.autograd.Function):
     otherwise the given tensors are used as constants (BatchNorm in eval mode)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, gamma, beta, mean, var, eps, act, per_image, train_stats):
         lib = _lib.lib()
         x = as_nhwc(x, "normalisation input")
@@ -73,6 +75,7 @@ class _NormAct(torch.autograd.Function):
         return out, mean, var
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g, _gm, _gv):
         x, gamma, beta, mean, var = ctx.saved_tensors
         eps, act, per_image, train_stats = ctx.cfg
@@ -132,6 +135,7 @@ def instance_norm_act(x, eps=1e-5, leaky=None):
 # ------------------------------------------------------------------------------------ pooling / padding / stem ----
 class _MaxBlurPool(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x):
         x = as_nhwc(x, "maxblurpool input")
         with torch.no_grad():
@@ -140,6 +144,7 @@ class _MaxBlurPool(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         lib = _lib.lib()
@@ -163,6 +168,7 @@ def maxblurpool(x):
 
 class _ReplicatePad(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, pad):
         x = as_nhwc(x, "replicate-pad input")
         b, c, h, w = x.shape
@@ -176,6 +182,7 @@ class _ReplicatePad(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         b, c, h, w = ctx.shape
         g = _dense(g)
@@ -197,6 +204,7 @@ class _Stem7x7(torch.autograd.Function):
     weight gradient is a 1x1-conv weight gradient over the unfolded input (sr_im2col7x7s2_nhwc + sr_conv_wgrad_nhwc)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, image, weight, conv):
         with torch.no_grad():
             y = ops.stem7x7(image.detach(), conv, bn=None, leaky=None)
@@ -204,6 +212,7 @@ class _Stem7x7(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         (image,) = ctx.saved_tensors
         lib = _lib.lib()
@@ -265,6 +274,7 @@ def conv(x, conv_mod: nn.Conv2d, pads=None, residual=None, slope=None):
 # ------------------------------------------------------------------------------------ depthwise 3x3 ---------------
 class _DwConv3x3(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight, conv, pads):
         x = as_nhwc(x, "depthwise conv input")
         with torch.no_grad():
@@ -274,6 +284,7 @@ class _DwConv3x3(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         s, pads = ctx.cfg
@@ -309,6 +320,7 @@ class _SqueezeExcite(torch.autograd.Function):
     """y = x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2) (timm SqueezeExcite: 1x1 convs on the pooled vector)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w1, b1, w2, b2):
         lib = _lib.lib()
         x = as_nhwc(x, "squeeze-excite input")
@@ -340,6 +352,7 @@ class _SqueezeExcite(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         x, w1d, w2d, pooled, pre1, hid, pre2, gate = ctx.saved_tensors
         lib = _lib.lib()
@@ -384,6 +397,7 @@ class _AddAct(torch.autograd.Function):
     """act(a + b): the residual join of a block (identity skip), activation optional."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, a, b, act):
         a, b = _dense(as_nhwc(a, "a")), _dense(as_nhwc(b, "b"))
         if a.shape != b.shape:
@@ -401,6 +415,7 @@ class _AddAct(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         if ctx.act == ACT_NONE:
             return g, g, None

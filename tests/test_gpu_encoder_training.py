@@ -305,3 +305,47 @@ def test_depth_model_trains_end_to_end_and_freeze_is_opt_in():
     assert all(p.grad is None for p in model.encoder.parameters())
     assert all(p.grad is None for p in model.matching_model.parameters())
     assert any(p.grad is not None for p in model.cost_volume_net.parameters())
+
+
+def test_training_step_under_autocast_runs_the_fp32_kernels():
+    """The reference trains under 16-bit autocast (options.py:100-101, train.py:132).  Inside torch.autocast every
+    differentiable HIP operator runs its fp32 kernels (half-precision inputs are upcast at the operator's entry): same
+    outputs and gradients as without autocast, fp32 results, GradScaler-compatible."""
+    B, K, H, W, D = 1, 2, 64, 96, 8
+    opts = dm.default_options(image_width=W, image_height=H, model_num_views=K + 1, matching_num_depth_bins=D)
+    model = dm.DepthModel(opts)
+    synthetic.seeded_fill_(model.encoder, seed=6, gain=1.0)
+    for i, m in enumerate((model.matching_model, model.cost_volume_net, model.depth_decoder, model.cost_volume.mlp)):
+        synthetic.seeded_fill_(m, seed=20 + i)
+    model = model.to(DEV).eval()   # eval-mode BatchNorm: two identical forward passes
+    inp = synthetic.cost_volume_inputs(B, K, 16, H // 4, W // 4, seed=4, device=DEV)
+    eye = torch.eye(4, device=DEV).expand(B, 4, 4).contiguous()
+    cur = {"image_b3hw": _randn((B, 3, H, W), 40).to(DEV), "invK_s1_b44": inp["cur_invK"], "cam_T_world_b44": eye,
+           "world_T_cam_b44": eye}
+    src = {"image_b3hw": _randn((B, K, 3, H, W), 41).to(DEV), "K_s1_b44": inp["src_Ks"],
+           "cam_T_world_b44": inp["src_extrinsics"], "world_T_cam_b44": inp["src_poses"]}
+
+    def step(autocast, half_images=False):
+        model.zero_grad(set_to_none=True)
+        c, s = dict(cur), dict(src)
+        if half_images:
+            c["image_b3hw"], s["image_b3hw"] = c["image_b3hw"].half(), s["image_b3hw"].half()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
+            out = model("val", c, s)
+            loss = sum(out[f"log_depth_pred_s{i}_b1hw"].abs().mean() for i in range(4))
+        scaler = torch.amp.GradScaler("cuda", enabled=autocast)
+        scaler.scale(loss).backward()
+        scale = float(scaler.get_scale()) if autocast else 1.0
+        return out, {n: p.grad.clone() / scale for n, p in model.named_parameters() if p.grad is not None}
+
+    ref_out, ref_g = step(False)
+    out, g = step(True)
+    assert out["depth_pred_s0_b1hw"].dtype == torch.float32
+    assert torch.equal(out["depth_pred_s0_b1hw"], ref_out["depth_pred_s0_b1hw"])
+    assert sorted(g) == sorted(ref_g)
+    for n in g:
+        assert torch.isfinite(g[n]).all() and rel_l2(g[n], ref_g[n], floor=1e-7) < 1e-3, n
+    # half-precision images (a caller that casts its batch): upcast at the first operator, fp32 from there on
+    out_h, _ = step(True, half_images=True)
+    assert out_h["depth_pred_s0_b1hw"].dtype == torch.float32 and torch.isfinite(out_h["depth_pred_s0_b1hw"]).all()
+    assert rel_err(out_h["depth_pred_s0_b1hw"], ref_out["depth_pred_s0_b1hw"]) < 5e-2   # fp16-rounded inputs
