@@ -343,8 +343,9 @@ def test_training_step_under_autocast_runs_the_fp32_kernels():
     assert out["depth_pred_s0_b1hw"].dtype == torch.float32
     assert torch.equal(out["depth_pred_s0_b1hw"], ref_out["depth_pred_s0_b1hw"])
     assert sorted(g) == sorted(ref_g)
-    for n in g:
-        assert torch.isfinite(g[n]).all() and rel_l2(g[n], ref_g[n], floor=1e-7) < 1e-3, n
+    scale = float(np.median([float(v.pow(2).mean().sqrt()) for v in ref_g.values()]))
+    for n in g:   # (scaled-loss gradients differ from the unscaled run by fp32 rounding; zero gradients by noise)
+        assert torch.isfinite(g[n]).all() and rel_l2(g[n], ref_g[n], floor=1e-3 * scale) < 1e-3, n
     # half-precision images (a caller that casts its batch): upcast at the first operator, fp32 from there on
     out_h, _ = step(True, half_images=True)
     assert out_h["depth_pred_s0_b1hw"].dtype == torch.float32 and torch.isfinite(out_h["depth_pred_s0_b1hw"]).all()
