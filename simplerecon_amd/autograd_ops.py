@@ -24,8 +24,54 @@ from .ops import _is_nhwc_view, _strides, _workspace, as_nhwc, empty_nhwc
 # arrive in fp16 / bf16 are cast to fp32 at the operator's entry (a differentiable cast: gradients go back in the caller's
 # dtype) and autocast is off inside.  fp32 compute and fp32 storage: more accurate than the reference's half-precision
 # convolutions, without their memory saving (an fp16-storage variant of the kernels is not built).
-_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_cast_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
+def _amp_fwd(fwd):
+    """custom_fwd(cast_inputs=fp32) that also records on ctx whether the caller was inside an autocast region (and its
+    dtype): `_stash` then keeps the saved activations in that 16-bit dtype."""
+    cast = _amp_cast_fwd(fwd)
+
+    def wrapper(ctx, *args, **kwargs):
+        on = torch.is_autocast_enabled("cuda")
+        ctx._sr_autocast = on
+        ctx._sr_autocast_dtype = torch.get_autocast_dtype("cuda") if on else None
+        return cast(ctx, *args, **kwargs)
+    wrapper.__name__, wrapper.__doc__ = getattr(fwd, "__name__", "forward"), fwd.__doc__
+    return wrapper
+
+
+# fp16 / bf16 STORAGE of the saved activations under torch.autocast (SR_AUTOCAST_HALF_STORAGE=0: keep fp32).  The
+# reference's autocast keeps activations in half precision (options.py:100-101); here the kernels compute and hand over
+# fp32, but what autograd SAVES for the backward pass -- the bulk of a training step's memory -- is stored in the autocast
+# dtype and widened again when the backward kernel needs it.  A tensor saved by several operators (a producer saves its
+# output for the activation's derivative, the consumer saves it as its input) is narrowed once and shared.
+STORE_HALF = os.environ.get("SR_AUTOCAST_HALF_STORAGE", "1") != "0"
+
+
+def _stash(ctx, *tensors):
+    half = STORE_HALF and getattr(ctx, "_sr_autocast", False)
+    dt = getattr(ctx, "_sr_autocast_dtype", None)
+    keep, flags = [], []
+    for t in tensors:
+        narrow = half and isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.dim() == 4 and \
+            not isinstance(t, nn.Parameter) and t.numel() >= 4096
+        if narrow:
+            h = getattr(t, "_sr_narrow", None)
+            if h is None or h.dtype != dt:
+                h = t.detach().to(dt)
+                t._sr_narrow = h
+            keep.append(h)
+        else:
+            keep.append(t)
+        flags.append(narrow)
+    ctx.save_for_backward(*keep)
+    ctx._sr_stash_flags = flags
+
+
+def _unstash(ctx):
+    return tuple(t.float() if (f and t is not None) else t for t, f in zip(ctx.saved_tensors, ctx._sr_stash_flags))
 
 FUSED_ACT_BIAS = os.environ.get("SR_FUSED_ACT_BIAS", "1") != "0"   # 0: separate sr_act_bwd + sr_bias_grad_nhwc launches (r02 a/b)
 
@@ -114,13 +160,13 @@ class _ConvBiasAct(torch.autograd.Function):
         out = _conv_raw(x, weight, bias, stride, residual, slope, pads)
         ctx.stride, ctx.slope, ctx.pads = stride, slope, pads
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
-        ctx.save_for_backward(x, weight, out if slope is not None else None)
+        _stash(ctx, x, weight, out if slope is not None else None)
         return out
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, g):
-        x, weight, out = ctx.saved_tensors
+        x, weight, out = _unstash(ctx)
         lib = _lib.lib()
         dev = x.device
         b, ci, h, w = x.shape

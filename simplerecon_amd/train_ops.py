@@ -18,6 +18,7 @@ from .ops import _strides, _workspace, as_nhwc, empty_nhwc
 
 ACT_NONE, ACT_SILU, ACT_SIGMOID = -1.0, -2.0, -3.0
 _amp_fwd, _amp_bwd = autograd_ops._amp_fwd, autograd_ops._amp_bwd   # fp32 kernels under torch.autocast (see autograd_ops)
+_stash, _unstash = autograd_ops._stash, autograd_ops._unstash       # 16-bit storage of saved activations under autocast
 
 
 def _dense(t, name="tensor"):
@@ -69,7 +70,7 @@ class _NormAct(torch.autograd.Function):
                 _lib.check(lib.sr_norm_act_fwd_nhwc(_lib.ptr(x), xsb, xsp, _lib.ptr(mean), _lib.ptr(var), C.c_float(eps),
                                                     _lib.ptr(gd), _lib.ptr(bd), C.c_float(act), int(per_image),
                                                     _lib.ptr(out), osb, osp, b, h * w, c, st), "sr_norm_act_fwd_nhwc")
-        ctx.save_for_backward(x, gamma, beta, mean, var)
+        _stash(ctx, x, gamma, beta, mean, var)
         ctx.cfg = (eps, act, per_image, train_stats)
         ctx.mark_non_differentiable(mean, var)
         return out, mean, var
@@ -77,7 +78,7 @@ class _NormAct(torch.autograd.Function):
     @staticmethod
     @_amp_bwd
     def backward(ctx, g, _gm, _gv):
-        x, gamma, beta, mean, var = ctx.saved_tensors
+        x, gamma, beta, mean, var = _unstash(ctx)
         eps, act, per_image, train_stats = ctx.cfg
         lib = _lib.lib()
         b, c, h, w = x.shape
@@ -140,13 +141,13 @@ class _MaxBlurPool(torch.autograd.Function):
         x = as_nhwc(x, "maxblurpool input")
         with torch.no_grad():
             y = ops.maxblurpool(x.detach())
-        ctx.save_for_backward(x)
+        _stash(ctx, x)
         return y
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
+        (x,) = _unstash(ctx)
         lib = _lib.lib()
         b, c, h, w = x.shape
         g = _dense(g)
@@ -279,14 +280,14 @@ class _DwConv3x3(torch.autograd.Function):
         x = as_nhwc(x, "depthwise conv input")
         with torch.no_grad():
             y = ops.dwconv3x3(x.detach(), conv, bn=None, tf_same=False, pads=pads)
-        ctx.save_for_backward(x, weight)
+        _stash(ctx, x, weight)
         ctx.cfg = (conv.stride[0], pads)
         return y
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x, weight = _unstash(ctx)
         s, pads = ctx.cfg
         lib = _lib.lib()
         b, c, h, w = x.shape
@@ -347,14 +348,14 @@ class _SqueezeExcite(torch.autograd.Function):
                            "sr_small_linear_fwd")
                 _lib.check(lib.sr_scale_channels_nhwc_fwd(_lib.ptr(x), *_strides(x), _lib.ptr(gate), _lib.ptr(y), *_strides(y),
                                                           b, h, w, c, st), "sr_scale_channels_nhwc_fwd")
-        ctx.save_for_backward(x, w1d, w2d, pooled, pre1, hid, pre2, gate)
+        _stash(ctx, x, w1d, w2d, pooled, pre1, hid, pre2, gate)
         ctx.shapes = (tuple(w1.shape), tuple(w2.shape))
         return y
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, g):
-        x, w1d, w2d, pooled, pre1, hid, pre2, gate = ctx.saved_tensors
+        x, w1d, w2d, pooled, pre1, hid, pre2, gate = _unstash(ctx)
         lib = _lib.lib()
         b, c, h, w = x.shape
         rd = w1d.shape[0]
@@ -411,7 +412,7 @@ class _AddAct(torch.autograd.Function):
             _lib.check(rc, "sr_add_act_fwd")
         ctx.act = act
         if pre is not None:
-            ctx.save_for_backward(pre)
+            _stash(ctx, pre)
         return out
 
     @staticmethod
@@ -419,7 +420,7 @@ class _AddAct(torch.autograd.Function):
     def backward(ctx, g):
         if ctx.act == ACT_NONE:
             return g, g, None
-        (pre,) = ctx.saved_tensors
+        (pre,) = _unstash(ctx)
         g = _dense(g)
         gz = torch.empty_like(pre)
         if pre.numel() > 0:

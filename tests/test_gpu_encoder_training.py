@@ -307,17 +307,21 @@ def test_depth_model_trains_end_to_end_and_freeze_is_opt_in():
     assert any(p.grad is not None for p in model.cost_volume_net.parameters())
 
 
-def test_training_step_under_autocast_runs_the_fp32_kernels():
+def test_training_step_under_autocast_runs_the_fp32_kernels(monkeypatch):
     """The reference trains under 16-bit autocast (options.py:100-101, train.py:132).  Inside torch.autocast every
     differentiable HIP operator runs its fp32 kernels (half-precision inputs are upcast at the operator's entry): same
-    outputs and gradients as without autocast, fp32 results, GradScaler-compatible."""
+    outputs as without autocast, fp32 results, GradScaler-compatible.  What autograd SAVES for the backward pass is kept
+    in the autocast dtype (autograd_ops._stash: the bulk of a training step's memory): less than 60 % of the fp32 bytes,
+    gradients within half-precision rounding of the fp32 ones; SR_AUTOCAST_HALF_STORAGE=0 keeps fp32 storage and then the
+    gradients equal the no-autocast ones up to summation order."""
+    from simplerecon_amd import autograd_ops
     B, K, H, W, D = 1, 2, 64, 96, 8
     opts = dm.default_options(image_width=W, image_height=H, model_num_views=K + 1, matching_num_depth_bins=D)
     model = dm.DepthModel(opts)
     synthetic.seeded_fill_(model.encoder, seed=6, gain=1.0)
     for i, m in enumerate((model.matching_model, model.cost_volume_net, model.depth_decoder, model.cost_volume.mlp)):
         synthetic.seeded_fill_(m, seed=20 + i)
-    model = model.to(DEV).eval()   # eval-mode BatchNorm: two identical forward passes
+    model = model.to(DEV).eval()   # eval-mode BatchNorm: identical forward passes
     inp = synthetic.cost_volume_inputs(B, K, 16, H // 4, W // 4, seed=4, device=DEV)
     eye = torch.eye(4, device=DEV).expand(B, 4, 4).contiguous()
     cur = {"image_b3hw": _randn((B, 3, H, W), 40).to(DEV), "invK_s1_b44": inp["cur_invK"], "cam_T_world_b44": eye,
@@ -330,23 +334,40 @@ def test_training_step_under_autocast_runs_the_fp32_kernels():
         c, s = dict(cur), dict(src)
         if half_images:
             c["image_b3hw"], s["image_b3hw"] = c["image_b3hw"].half(), s["image_b3hw"].half()
-        with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
-            out = model("val", c, s)
-            loss = sum(out[f"log_depth_pred_s{i}_b1hw"].abs().mean() for i in range(4))
+        saved = [0]
+
+        def pack(t):
+            if t.dim() == 4 and not isinstance(t, torch.nn.Parameter):
+                saved[0] += t.numel() * t.element_size()
+            return t
+        with torch.autograd.graph.saved_tensors_hooks(pack, lambda t: t):
+            with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
+                out = model("val", c, s)
+                loss = sum(out[f"log_depth_pred_s{i}_b1hw"].abs().mean() for i in range(4))
         scaler = torch.amp.GradScaler("cuda", enabled=autocast)
         scaler.scale(loss).backward()
         scale = float(scaler.get_scale()) if autocast else 1.0
-        return out, {n: p.grad.clone() / scale for n, p in model.named_parameters() if p.grad is not None}
+        return out, {n: p.grad.clone() / scale for n, p in model.named_parameters() if p.grad is not None}, saved[0]
 
-    ref_out, ref_g = step(False)
-    out, g = step(True)
-    assert out["depth_pred_s0_b1hw"].dtype == torch.float32
-    assert torch.equal(out["depth_pred_s0_b1hw"], ref_out["depth_pred_s0_b1hw"])
-    assert sorted(g) == sorted(ref_g)
+    ref_out, ref_g, bytes_fp32 = step(False)
     scale = float(np.median([float(v.pow(2).mean().sqrt()) for v in ref_g.values()]))
+    # (a) fp32 storage under autocast: the same numbers
+    monkeypatch.setattr(autograd_ops, "STORE_HALF", False)
+    out, g, bytes_a = step(True)
+    assert out["depth_pred_s0_b1hw"].dtype == torch.float32
+    assert torch.equal(out["depth_pred_s0_b1hw"], ref_out["depth_pred_s0_b1hw"]) and bytes_a == bytes_fp32
+    assert sorted(g) == sorted(ref_g)
     for n in g:   # (scaled-loss gradients differ from the unscaled run by fp32 rounding; zero gradients by noise)
         assert torch.isfinite(g[n]).all() and rel_l2(g[n], ref_g[n], floor=1e-3 * scale) < 1e-3, n
+    # (b) 16-bit storage of the saved activations (the default): same forward, less memory, gradients within fp16 rounding
+    monkeypatch.setattr(autograd_ops, "STORE_HALF", True)
+    out, g, bytes_b = step(True)
+    assert torch.equal(out["depth_pred_s0_b1hw"], ref_out["depth_pred_s0_b1hw"])
+    assert bytes_b < 0.6 * bytes_fp32, (bytes_b, bytes_fp32)
+    errs = {n: rel_l2(g[n], ref_g[n], floor=1e-2 * scale) for n in g}
+    assert all(torch.isfinite(v).all() for v in g.values()) and max(errs.values()) < 5e-2 and np.median(list(errs.values())) < 5e-3, \
+        (max(errs.values()), np.median(list(errs.values())))
     # half-precision images (a caller that casts its batch): upcast at the first operator, fp32 from there on
-    out_h, _ = step(True, half_images=True)
+    out_h, _, _ = step(True, half_images=True)
     assert out_h["depth_pred_s0_b1hw"].dtype == torch.float32 and torch.isfinite(out_h["depth_pred_s0_b1hw"]).all()
     assert rel_err(out_h["depth_pred_s0_b1hw"], ref_out["depth_pred_s0_b1hw"]) < 5e-2   # fp16-rounded inputs
