@@ -328,6 +328,16 @@ int sr_instance_norm_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_p
 int sr_instance_norm_stats_nhwc(const float* in, int64_t in_batch_stride, int in_pix_stride, int B, int H, int W, int C,
                                 float eps, float* stats, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Conv2d(64, 128, 1) + bias AND the InstanceNorm2d statistics of its output in one pass (reference
+ * modules/networks.py:187-188): `out` is the raw convolution, `stats` [B,2,128] = (mean, 1 / sqrt(var + eps)) as
+ * sr_instance_norm_stats_nhwc would compute them from `out`.  weight [128][64] (the module's own layout, no packing).
+ * Other channel counts: SR_ERR_UNSUPPORTED (callers run sr_conv1x1 + sr_instance_norm_stats_nhwc instead). */
+size_t sr_conv1x1_stats_workspace_bytes(int B, int H, int W, int Cout);
+int sr_conv1x1_stats_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* weight,
+                              const float* bias, float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H,
+                              int W, int Cin, int Cout, float eps, float* stats, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 /* nn.Conv2d(Cin, Cout <= 16, 3, padding=1, padding_mode = replicate ? "replicate" : "zeros") + bias [+ LeakyReLU] on
  * channels-last data, with an optional InstanceNorm (+ LeakyReLU(in_leaky_slope)) applied to the INPUT on the fly from
  * `in_stats` (sr_instance_norm_stats_nhwc; NULL = input used as is): the InstanceNorm -> LeakyReLU -> Conv2d(128, 16,

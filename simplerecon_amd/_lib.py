@@ -119,6 +119,8 @@ SIGNATURES = {
     "sr_instance_norm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sr_instance_norm_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
     "sr_instance_norm_stats_nhwc": (_i, [_p, _i64, _i, _i, _i, _i, _i, _f, _p, _p, _sz, _p]),
+    "sr_conv1x1_stats_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "sr_conv1x1_stats_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _p, _p, _sz, _p]),
     "sr_conv3x3_c16_packed_weight_floats": (_sz, [_i, _i]),
     "sr_conv3x3_c16_pack_weights": (_i, [_p, _i, _i, _p, _p]),
     "sr_conv3x3_c16_nhwc_fwd": (_i, [_p, _i64, _i, _p, _f, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _f, _p]),

@@ -339,6 +339,41 @@ __global__ void sr_inorm_finalize_kernel(SrInormParams p, int B) {
   p.stats[(int64_t)b * 2 * p.C + p.C + c] = 1.f / sqrtf(m2 / n + p.eps);
 }
 
+// The same merge for many small chunks (the 64-pixel tiles of sr_conv1x1_stats_kernel): a workgroup owns (image, 16
+// channels); 16 segments of consecutive chunks are merged concurrently, then the 16 segment records in order.
+__global__ __launch_bounds__(256) void sr_inorm_finalize_seg_kernel(SrInormParams p) {
+  __shared__ float sn[256], sm[256], sq[256];
+  const int b = blockIdx.y, c = blockIdx.x * 16 + (threadIdx.x & 15), seg = threadIdx.x >> 4;
+  const int per = (p.chunks + 15) / 16, k0 = seg * per, k1 = min(p.chunks, k0 + per);
+  const float* pb = p.partial + (int64_t)b * p.chunks * 2 * p.C + (c < p.C ? c : 0);
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll 4
+  for (int k = k0; k < k1; ++k) {
+    const int p0 = k * p.chunk_pix;
+    const float nk = (float)(min(p.HW, p0 + p.chunk_pix) - p0);
+    const float mk = pb[(int64_t)k * 2 * p.C], qk = pb[(int64_t)k * 2 * p.C + p.C];
+    const float nn = n + nk, d = mk - mean;
+    mean += d * (nk / nn);
+    m2 += qk + d * d * (n * nk / nn);
+    n = nn;
+  }
+  sn[threadIdx.x] = n; sm[threadIdx.x] = mean; sq[threadIdx.x] = m2;
+  __syncthreads();
+  if (seg == 0 && c < p.C) {
+    for (int s = 1; s < 16; ++s) {
+      const float nk = sn[16 * s + threadIdx.x];
+      if (nk == 0.f) continue;
+      const float mk = sm[16 * s + threadIdx.x], qk = sq[16 * s + threadIdx.x];
+      const float nn = n + nk, d = mk - mean;
+      mean += d * (nk / nn);
+      m2 += qk + d * d * (n * nk / nn);
+      n = nn;
+    }
+    p.stats[(int64_t)b * 2 * p.C + c] = mean;
+    p.stats[(int64_t)b * 2 * p.C + p.C + c] = 1.f / sqrtf(m2 / n + p.eps);
+  }
+}
+
 __global__ __launch_bounds__(256) void sr_inorm_apply_kernel(SrInormParams p) {
   const int b = blockIdx.y;
   const float* __restrict__ ib = p.in + (int64_t)b * p.in_sb;
@@ -357,6 +392,115 @@ __global__ __launch_bounds__(256) void sr_inorm_apply_kernel(SrInormParams p) {
       v.z = v.z >= 0.f ? v.z : v.z * p.slope; v.w = v.w >= 0.f ? v.w : v.w * p.slope;
     }
     *reinterpret_cast<float4*>(ob + px * p.out_sp + 4 * c4) = v;
+  }
+}
+
+// ------------------------------------------------------------------ conv 1x1 64 -> 128 + InstanceNorm statistics ----
+//
+// The first two operators of the matching encoder's tail (reference networks.py:187-188: Conv2d(64, 128, 1) ->
+// InstanceNorm2d) as one pass over the activation: the 1x1 convolution runs on the fp32 matrix cores and, while a
+// 64-pixel tile of its output is still in LDS on the way to coalesced stores, the tile's per-channel (mean, M2)
+// record is written in sr_inorm_partial_kernel's format -- sr_inorm_finalize_seg_kernel (chunk_pix = 64) then yields the
+// statistics without the separate read of the 128-channel map.  HBM-bound: 256 B in + 512 B out per pixel.
+//
+// Workgroup = 4 waves, persistent over (image, 64-pixel tile).  Wave w owns output channels 32w..32w+31 (M = co, its
+// 32 A fragments stay in registers for the whole kernel), N = pixels (two 32-pixel MFMA tiles per step), K = 64 input
+// channels as 32 k-steps of v_mfma_f32_32x32x2_f32 (k-step t multiplies channels t and 32+t).
+#define SR_C1S_PIX 64
+#define SR_C1S_XROW 68    // floats per staged input pixel (64 + 4: 16-lane float4 reads hit distinct banks)
+#define SR_C1S_YROW 132   // floats per staged output pixel (128 + 4)
+struct SrC1sParams {
+  const float* in; int64_t in_sb; int in_sp;
+  const float* w; const float* bias;       // [128][64], [128] or NULL
+  float* out; int64_t out_sb; int out_sp;
+  float* partial;                          // [B][tiles][{mean, M2}][128]
+  int HW, tiles, total;
+};
+
+__global__ __launch_bounds__(256) void sr_conv1x1_stats_kernel(SrC1sParams p) {
+  __shared__ __attribute__((aligned(16))) float xs[SR_C1S_PIX * SR_C1S_XROW];
+  __shared__ __attribute__((aligned(16))) float ys[SR_C1S_PIX * SR_C1S_YROW];
+  __shared__ float red[256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ln = lane & 31, kk = lane >> 5;
+  float a[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) a[t] = p.w[(32 * wave + ln) * 64 + 32 * kk + t];
+  float4 bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    bq[q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + 32 * wave + 8 * q + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int spx = tid >> 4, sc4 = tid & 15;   // staging: 16 pixels x 16 float4 per pass
+  float4 st[4];
+  auto stage_load = [&](int item) {
+    const int b = item / p.tiles, p0 = (item - b * p.tiles) * SR_C1S_PIX;
+    const float* ib = p.in + (int64_t)b * p.in_sb + 4 * sc4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int px = p0 + 16 * q + spx;
+      st[q] = px < p.HW ? *reinterpret_cast<const float4*>(ib + (int64_t)px * p.in_sp) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int item = blockIdx.x;
+  if (item < p.total) stage_load(item);
+  for (; item < p.total; item += gridDim.x) {
+    const int b = item / p.tiles, tile = item - b * p.tiles, p0 = tile * SR_C1S_PIX;
+    const int npx = min(SR_C1S_PIX, p.HW - p0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(&xs[(16 * q + spx) * SR_C1S_XROW + 4 * sc4]) = st[q];
+    __syncthreads();   // xs ready; everyone is done reading ys of the previous tile
+    if (item + (int)gridDim.x < p.total) stage_load(item + gridDim.x);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 xq[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        xq[q] = *reinterpret_cast<const float4*>(&xs[(32 * j + ln) * SR_C1S_XROW + 32 * kk + 4 * q]);
+      v16f acc = {0.f};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        acc = SR_MFMA(a[4 * q + 0], xq[q].x, acc);
+        acc = SR_MFMA(a[4 * q + 1], xq[q].y, acc);
+        acc = SR_MFMA(a[4 * q + 2], xq[q].z, acc);
+        acc = SR_MFMA(a[4 * q + 3], xq[q].w, acc);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(&ys[(32 * j + ln) * SR_C1S_YROW + 32 * wave + 8 * q + 4 * kk]) =
+            make_float4(acc[4 * q] + bq[q].x, acc[4 * q + 1] + bq[q].y, acc[4 * q + 2] + bq[q].z, acc[4 * q + 3] + bq[q].w);
+    }
+    __syncthreads();   // ys ready
+    {
+      float* ob = p.out + (int64_t)b * p.out_sb + 4 * (tid & 31);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int px = 8 * q + (tid >> 5);
+        if (px < npx)
+          *reinterpret_cast<float4*>(ob + (int64_t)(p0 + px) * p.out_sp) =
+              *reinterpret_cast<const float4*>(&ys[px * SR_C1S_YROW + 4 * (tid & 31)]);
+      }
+    }
+    // tile statistics: thread (half, co) sums 32 pixels of channel co
+    const int co = tid & 127, half = tid >> 7;
+    const int q0 = 32 * half, q1 = min(npx, q0 + 32);
+    float s = 0.f;
+    for (int px = q0; px < q1; ++px) s += ys[px * SR_C1S_YROW + co];
+    red[tid] = s;
+    __syncthreads();
+    const float mean = (red[co] + red[128 + co]) / (float)npx;
+    float m2 = 0.f;
+    for (int px = q0; px < q1; ++px) {
+      const float d = ys[px * SR_C1S_YROW + co] - mean;
+      m2 += d * d;
+    }
+    __syncthreads();
+    red[tid] = m2;
+    __syncthreads();
+    if (half == 0) {
+      float* o = p.partial + (int64_t)item * 2 * 128 + co;
+      o[0] = mean;
+      o[128] = red[co] + red[128 + co];
+    }
   }
 }
 
@@ -653,6 +797,41 @@ extern "C" int sr_instance_norm_stats_nhwc(const float* in, int64_t in_batch_str
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(sr_inorm_partial_kernel, dim3(p.chunks, B), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(sr_inorm_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, p, B);
+  return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" size_t sr_conv1x1_stats_workspace_bytes(int B, int H, int W, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout != 128) return 0;
+  const size_t tiles = ((size_t)H * W + SR_C1S_PIX - 1) / SR_C1S_PIX;
+  return (size_t)B * tiles * 2 * Cout * sizeof(float);
+}
+
+extern "C" int sr_conv1x1_stats_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                         const float* weight, const float* bias, float* out, int64_t out_batch_stride,
+                                         int out_pix_stride, int B, int H, int W, int Cin, int Cout, float eps,
+                                         float* stats, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!in || !weight || !out || !stats || !workspace) return SR_ERR_INVALID_ARGUMENT;
+  if (Cin != 64 || Cout != 128 || (in_pix_stride % 4) || (in_batch_stride % 4) || (out_pix_stride % 4) ||
+      (out_batch_stride % 4) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15)))
+    return SR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sr_conv1x1_stats_workspace_bytes(B, H, W, Cout)) return SR_ERR_WORKSPACE_TOO_SMALL;
+  SrC1sParams p;
+  p.in = in; p.in_sb = in_batch_stride; p.in_sp = in_pix_stride;
+  p.w = weight; p.bias = bias;
+  p.out = out; p.out_sb = out_batch_stride; p.out_sp = out_pix_stride;
+  p.partial = (float*)workspace;
+  p.HW = H * W; p.tiles = (p.HW + SR_C1S_PIX - 1) / SR_C1S_PIX; p.total = p.tiles * B;
+  int blocks = 3 * sr_cus();
+  if (blocks > p.total) blocks = p.total;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(sr_conv1x1_stats_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  SrInormParams q;
+  q.in = nullptr; q.in_sb = 0; q.in_sp = 0; q.out = nullptr; q.out_sb = 0; q.out_sp = 0;
+  q.HW = p.HW; q.C = Cout; q.C4 = Cout / 4; q.chunks = p.tiles; q.chunk_pix = SR_C1S_PIX;
+  q.partial = p.partial; q.stats = stats; q.eps = eps; q.slope = -1.0f;
+  hipLaunchKernelGGL(sr_inorm_finalize_seg_kernel, dim3(Cout / 16, B), dim3(256), 0, stream, q);
   return sr_hip_rc(hipGetLastError());
 }
 

@@ -348,13 +348,19 @@ class ResnetMatchingEncoder(nn.Module):
         for blk in net[4]:
             t = ops.conv2d(x, blk.conv1, bn=blk.bn1, leaky=0.0)
             x = ops.conv2d(t, blk.conv2, bn=blk.bn2, residual=x, leaky=0.0)
-        x = ops.conv2d(x, net[5])
-        if net[8].out_channels <= 16 and net[8].in_channels % 32 == 0:
-            # InstanceNorm + LeakyReLU of the 128-channel map are applied inside the last conv's input staging:
-            # the normalised tensor never goes to HBM
+        fused_in = net[8].out_channels <= 16 and net[8].in_channels % 32 == 0
+        if fused_in and (net[5].in_channels, net[5].out_channels) == (64, 128):
+            # the 1x1 conv leaves the InstanceNorm statistics of its output behind (no separate pass over it) ...
+            x, stats = ops.conv1x1_stats(x, net[5], eps=net[6].eps)
+            x = ops.conv3x3_c16(x, net[8], in_stats=stats, in_leaky=net[7].negative_slope)
+        elif fused_in:
+            # ... and InstanceNorm + LeakyReLU of the 128-channel map are applied inside the last conv's input
+            # staging: the normalised tensor never goes to HBM
+            x = ops.conv2d(x, net[5])
             stats = ops.instance_norm_stats(x, eps=net[6].eps)
             x = ops.conv3x3_c16(x, net[8], in_stats=stats, in_leaky=net[7].negative_slope)
         else:
+            x = ops.conv2d(x, net[5])
             x = ops.instance_norm(x, eps=net[6].eps, leaky=net[7].negative_slope, inplace=True)
             x = ops.conv2d(x, net[8])
         return ops.instance_norm(x, eps=net[9].eps, inplace=True)

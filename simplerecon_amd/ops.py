@@ -566,6 +566,42 @@ def instance_norm_stats(x, eps=1e-5):
     return stats
 
 
+def conv1x1_stats(x, conv: nn.Conv2d, eps=1e-5):
+    """(conv(x), InstanceNorm statistics [B,2,C] of conv(x)) for the matching encoder's Conv2d(64, 128, 1) ->
+    InstanceNorm2d pair (reference networks.py:187-188): the statistics come out of the convolution's own pass."""
+    _lib.refuse_autograd(x, conv.weight)
+    x = as_nhwc(x, "conv input")
+    b, ci, h, w = x.shape
+    co = conv.out_channels
+    if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or tuple(conv.padding) != (0, 0) or conv.groups != 1 \
+            or (ci, co) != (64, 128) or ci != conv.in_channels:
+        raise _lib.HipLibraryError(f"conv1x1_stats needs Conv2d(64, 128, 1), got {conv} for {ci} channels")
+    out = empty_nhwc(b, co, h, w, x.device)
+    stats = torch.empty((b, 2, co), dtype=torch.float32, device=x.device)
+    if b == 0:
+        return out, stats
+    lib = _lib.lib()
+    ws = _workspace(x.device, "c1s", lib.sr_conv1x1_stats_workspace_bytes(b, h, w, co))
+    weight = conv.weight.detach().reshape(co, ci)
+    bias = conv.bias.detach() if conv.bias is not None else None
+    isb, isp = _strides(x)
+    osb, osp = _strides(out)
+    prof = PROFILE
+    with torch.cuda.device(x.device):
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        rc = lib.sr_conv1x1_stats_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), osb,
+                                           osp, b, h, w, ci, co, C.c_float(eps), _lib.ptr(stats), _lib.ptr(ws),
+                                           ws.numel() * 4, _lib.stream_ptr(x.device))
+        if prof is not None:
+            ev1.record()
+            prof.append(("sr_conv1x1_stats_kernel", 2.0 * b * h * w * co * ci, ev0, ev1, (b, ci, h, w, co, 1, 1),
+                         2.0 * b * ((h * w + 63) // 64) * 64 * co * ci))
+    _lib.check(rc, "sr_conv1x1_stats_nhwc_fwd")
+    return out, stats
+
+
 def conv3x3_c16(x, conv: nn.Conv2d, in_stats=None, in_leaky=None, leaky=None):
     """conv3x3 (<= 16 output channels, zero or replicate padding) of act(InstanceNorm(x)) where the normalisation
     (statistics `in_stats` from instance_norm_stats) and its LeakyReLU are applied while the input is staged."""

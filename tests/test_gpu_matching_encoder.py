@@ -120,6 +120,30 @@ def test_conv3x3_c16_with_fused_input_norm(mode, with_norm):
         assert_close(stats[:, 0], m, tol=1e-5, what="instance_norm_stats mean")
 
 
+@pytest.mark.parametrize("shape,bias", [((2, 64, 11, 19), True), ((1, 64, 8, 8), False), ((3, 64, 120, 160), True),
+                                        ((1, 64, 1, 3), True)])
+def test_conv1x1_with_instance_norm_statistics(shape, bias):
+    """sr_conv1x1_stats_nhwc_fwd = Conv2d(64, 128, 1) and the InstanceNorm statistics of its output in one pass
+    (ragged last 64-pixel tile, a tile-sized image, no bias)."""
+    rng = np.random.default_rng(sum(shape))
+    x = (rng.standard_normal(shape, dtype=np.float32) * 1.3 + 0.2).astype(np.float32)
+    conv = synthetic.seeded_fill_(nn.Conv2d(64, 128, 1, bias=bias), seed=6).to(DEV)
+    xt = torch.from_numpy(x).to(DEV)
+    with torch.inference_mode():
+        y, stats = ops.conv1x1_stats(xt, conv, eps=1e-5)
+        y2, stats2 = ops.conv1x1_stats(xt, conv, eps=1e-5)
+        two_pass = ops.instance_norm_stats(y, eps=1e-5)
+    assert torch.equal(y, y2) and torch.equal(stats, stats2), "not deterministic"
+    ref = oracle.conv2d(x, _nchw(conv.weight), _nchw(conv.bias) if bias else None, pad=0)
+    assert_close(y, ref, tol=1e-5, what=f"conv1x1_stats output {shape}")
+    r64 = ref.astype(np.float64)
+    assert_close(stats[:, 0], r64.mean(axis=(2, 3)), tol=1e-5, what="fused mean")
+    assert_close(stats[:, 1], 1.0 / np.sqrt(r64.var(axis=(2, 3)) + 1e-5), tol=2e-5, what="fused rstd")
+    assert_close(stats, two_pass, tol=2e-5, what="fused vs two-pass statistics")
+    with pytest.raises(Exception, match="Conv2d\\(64, 128, 1\\)"), torch.inference_mode():
+        ops.conv1x1_stats(xt, nn.Conv2d(64, 64, 1).to(DEV))
+
+
 def test_batchnorm_fold_matches_unfolded_oracle():
     rng = np.random.default_rng(12)
     x = rng.standard_normal((1, 64, 12, 20), dtype=np.float32)
