@@ -546,9 +546,11 @@ extern "C" int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int 
 // Launch plan.  Output channels per workgroup: 64 (NT = 2) shares one transformed input slab between two N-tiles; 32
 // (NT = 1) makes twice as many, roughly 0.58x as long work items.  Split-K (ks > 1) cuts a work item's chain of input
 // slabs into ks independent items whose raw partial outputs a second kernel adds up -- for the deep low-resolution
-// layers (e.g. 384 channels at 15x20: 24 slabs in a row on a handful of workgroups).  Launch time ~
-//   max(rounds over the 2-per-CU slots x item length alone on a CU, items per CU x item length under sharing) (+ reduce),
-// item length ~ slabs + 2 (prologue / epilogue); constants fitted on r01 measurements, in units of a full NT = 2 item.
+// layers (e.g. 384 channels at 15x20: 24 slabs in a row on a handful of workgroups).  Launch time = the schedule of
+// the busiest CU (+ reduce): its two persistent workgroups own n1 >= n2 items; n2 pairs run concurrently (each item
+// then takes 2 x t_thr), the remaining n1 - n2 run alone (t_lat each).  Item length ~ slabs + 2 (prologue / epilogue);
+// constants in units of a full NT = 2 item, fitted on the r03 kernel (scripts/wino_plan_sweep.py,
+// profiles/r03_wino_plan_sweep.txt: every 3x3 shape of the hero conv stack at batch 8 and 1 under each forced plan).
 struct SrWinoPlan { int nt, ks; };
 static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allow_split) {
   const int co_pad = ((Cout + 31) / 32) * 32;
@@ -568,11 +570,11 @@ static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allo
       if (forced_ks > 0 && ks != forced_ks && allow_split && slabs % forced_ks == 0 && slabs / forced_ks >= 1) continue;
       const long items = regions * (co_pad / (32 * nt)) * ks;
       const double f = ((double)slabs / ks + 2.0) / ((double)slabs + 2.0);
-      const double t_lat = nt == 2 ? 1.0 : 0.62, t_thr = nt == 2 ? 0.8 : 0.5;
-      const double lat = (double)((items + slots - 1) / slots) * t_lat * f, thr = (double)items / (double)cus * t_thr * f;
-      double cost = lat > thr ? lat : thr;
+      const double t_lat = nt == 2 ? 1.0 : 0.6, t_thr = nt == 2 ? 0.82 : 0.46;
+      const long n1 = (items + slots - 1) / slots, n2 = items / slots + (items % slots > cus ? 1 : 0);
+      double cost = ((double)n2 * 2.0 * t_thr + (double)(n1 - n2) * t_lat) * f;
       if (ks > 1) cost += 2.7 / ((double)slabs + 2.0);            // the reduce launch
-      if (nt == 1 || ks > 1) cost *= 1.08;                         // deviate from the default only for a clear gain
+      if (nt == 1 || ks > 1) cost *= 1.03;                         // deviate from the default only for a gain
       if (best_cost < 0 || cost < best_cost) { best = {nt, ks}; best_cost = cost; }
     }
   }
