@@ -93,14 +93,23 @@ __global__ __launch_bounds__(256) void sr_colreduce_kernel(SrColRed p) {
   }
 }
 
-// out[i] = scale * sum_chunk part[chunk * n_out + i], chunks added in index order (deterministic)
-__global__ void sr_colreduce_finish_kernel(const float* __restrict__ part, int chunks, int n_out, float scale,
-                                           float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_out) return;
+// out[i] = scale * sum_chunk part[chunk * n_out + i]: a workgroup = 16 outputs x 16 chunk lanes (lane j adds chunks j, j + 16,
+// ... in index order, then the 16 lane sums are added in lane order: deterministic)
+__global__ __launch_bounds__(256) void sr_colreduce_finish_kernel(const float* __restrict__ part, int chunks, int n_out,
+                                                                 float scale, float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int il = threadIdx.x & 15, j = threadIdx.x >> 4, i = blockIdx.x * 16 + il;
   float s = 0.0f;
-  for (int k = 0; k < chunks; ++k) s += part[(size_t)k * n_out + i];
-  out[i] = s * scale;
+  if (i < n_out)
+    for (int k = j; k < chunks; k += 16) s += part[(size_t)k * n_out + i];
+  red[j][il] = s;
+  __syncthreads();
+  if (j == 0 && i < n_out) {
+    float t = red[0][il];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][il];
+    out[i] = t * scale;
+  }
 }
 
 static int sr_tr_chunks(int B, int HW, int per_image) {
@@ -120,10 +129,10 @@ static int sr_colreduce(SrColRed p, float* out0, float scale0, float* out1, floa
   const int G = p.per_image ? p.B : 1;
   hipLaunchKernelGGL(sr_colreduce_kernel<MODE>, dim3(p.chunks, G, (p.C + 63) / 64), dim3(256), 0, stream, p);
   const int n_out = G * p.C;
-  hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, p.part0, p.chunks, n_out,
+  hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((n_out + 15) / 16), dim3(256), 0, stream, p.part0, p.chunks, n_out,
                      scale0, out0);
   if (MODE == 2)
-    hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, p.part1, p.chunks,
+    hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((n_out + 15) / 16), dim3(256), 0, stream, p.part1, p.chunks,
                        n_out, scale1, out1);
   return sr_hip_rc(hipGetLastError());
 }
@@ -225,7 +234,7 @@ extern "C" int sr_norm_act_bwd_nhwc(const float* g, int64_t g_sb, int g_sp, cons
   if (d_gamma) (void)hipMemcpyAsync(d_gamma, s1, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, stream);
   if (train_stats) {   // sums -> means (after the copies above, same stream)
     const float inv_n = 1.0f / (float)(per_image ? (int64_t)HW : (int64_t)B * HW);
-    hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((2 * G * C + 255) / 256), dim3(256), 0, stream, s0, 1, 2 * G * C, inv_n, s0);
+    hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((2 * G * C + 15) / 16), dim3(256), 0, stream, s0, 1, 2 * G * C, inv_n, s0);
   }
   SrNormEw p = {};
   p.x = x; p.x_sb = x_sb; p.x_sp = x_sp; p.g = g; p.g_sb = g_sb; p.g_sp = g_sp; p.y = dx; p.y_sb = dx_sb; p.y_sp = dx_sp;
@@ -333,6 +342,55 @@ __global__ __launch_bounds__(256) void sr_maxpool2_bwd_kernel(const float* __res
   }
 }
 
+// the same on 4 channels per thread (16-byte loads; C % 4 == 0, aligned rows): the 3x3 neighbourhood of (y, x) is read once
+__device__ __forceinline__ bool sr_first_max_is(float v0, float v1, float v2, float v3, int want) {
+  float best = v0; int bi = 0;
+  if (v1 > best || (v1 != v1 && best == best)) { best = v1; bi = 1; }
+  if (v2 > best || (v2 != v2 && best == best)) { best = v2; bi = 2; }
+  if (v3 > best || (v3 != v3 && best == best)) { best = v3; bi = 3; }
+  return bi == want;
+}
+__global__ __launch_bounds__(256) void sr_maxpool2_bwd_vec4_kernel(const float* __restrict__ xin, int64_t x_sb, int x_sp,
+                                                                  const float* __restrict__ dm, float* __restrict__ dx,
+                                                                  int64_t dx_sb, int dx_sp, int B, int H, int W, int C4) {
+  const int Hm = H - 1, Wm = W - 1, C = 4 * C4;
+  const int64_t total = (int64_t)B * H * W * C4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = 4 * (int)(e % C4);
+    int64_t r = e / C4;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const float* xb = xin + (int64_t)b * x_sb + c;
+    float4 nb[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dxx = 0; dxx < 3; ++dxx) {
+        const int yy = y + dy - 1, xx = x + dxx - 1;
+        nb[dy][dxx] = (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                          ? *reinterpret_cast<const float4*>(xb + ((int64_t)yy * W + xx) * x_sp)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)        // window row wy = y - 1 + a
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {    // window column wx = x - 1 + q
+        const int wy = y - 1 + a, wx = x - 1 + q;
+        if (wy < 0 || wy >= Hm || wx < 0 || wx >= Wm) continue;
+        const float4 g = *reinterpret_cast<const float4*>(dm + (((int64_t)b * Hm + wy) * Wm + wx) * C + c);
+        const int want = (1 - a) * 2 + (1 - q);   // position of (y, x) inside that window
+        const float4 v0 = nb[a][q], v1 = nb[a][q + 1], v2 = nb[a + 1][q], v3 = nb[a + 1][q + 1];
+        if (sr_first_max_is(v0.x, v1.x, v2.x, v3.x, want)) s.x += g.x;
+        if (sr_first_max_is(v0.y, v1.y, v2.y, v3.y, want)) s.y += g.y;
+        if (sr_first_max_is(v0.z, v1.z, v2.z, v3.z, want)) s.z += g.z;
+        if (sr_first_max_is(v0.w, v1.w, v2.w, v3.w, want)) s.w += g.w;
+      }
+    *reinterpret_cast<float4*>(dx + (int64_t)b * dx_sb + ((int64_t)y * W + x) * dx_sp + c) = s;
+  }
+}
+
 extern "C" size_t sr_maxblurpool_bwd_workspace_bytes(int B, int H, int W, int C) {
   if (B <= 0 || H < 2 || W < 2 || C <= 0) return 0;
   return (size_t)B * (H - 1) * (W - 1) * C * sizeof(float);
@@ -350,8 +408,14 @@ extern "C" int sr_maxblurpool_bwd_nhwc(const float* grad_out, int64_t g_sb, int 
   float* dm = (float*)workspace;
   hipLaunchKernelGGL(sr_blurpool_bwd_kernel, dim3(sr_ew_blocks((int64_t)B * Hm * Wm * C)), dim3(256), 0, stream, grad_out,
                      g_sb, g_sp, dm, B, Hm, Wm, Ho, Wo, C);
-  hipLaunchKernelGGL(sr_maxpool2_bwd_kernel, dim3(sr_ew_blocks((int64_t)B * H * W * C)), dim3(256), 0, stream, x, x_sb, x_sp,
-                     dm, grad_in, dx_sb, dx_sp, B, H, W, C);
+  const bool vec4 = (C % 4 == 0) && (x_sp % 4 == 0) && (x_sb % 4 == 0) && (dx_sp % 4 == 0) && (dx_sb % 4 == 0) &&
+                    (((uintptr_t)x | (uintptr_t)grad_in | (uintptr_t)dm) & 15) == 0;
+  if (vec4)
+    hipLaunchKernelGGL(sr_maxpool2_bwd_vec4_kernel, dim3(sr_ew_blocks((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, x,
+                       x_sb, x_sp, dm, grad_in, dx_sb, dx_sp, B, H, W, C / 4);
+  else
+    hipLaunchKernelGGL(sr_maxpool2_bwd_kernel, dim3(sr_ew_blocks((int64_t)B * H * W * C)), dim3(256), 0, stream, x, x_sb, x_sp,
+                       dm, grad_in, dx_sb, dx_sp, B, H, W, C);
   return sr_hip_rc(hipGetLastError());
 }
 
@@ -543,7 +607,7 @@ extern "C" int sr_dwconv3x3_bwd_nhwc(const float* grad_out, int64_t g_sb, int g_
     const int cp = sr_tr_chunk_pix(npix), chunks = (int)((npix + cp - 1) / cp);
     hipLaunchKernelGGL(sr_dw_wgrad_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, stream, grad_out, g_sb, g_sp, x, x_sb, x_sp,
                        (float*)workspace, B, H, W, Ho, Wo, C, stride, pad_top, pad_left, cp);
-    hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, stream, (const float*)workspace,
+    hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((C * 9 + 15) / 16), dim3(256), 0, stream, (const float*)workspace,
                        chunks, C * 9, 1.0f, d_weight);
   }
   return sr_hip_rc(hipGetLastError());
@@ -583,36 +647,100 @@ __device__ __forceinline__ float sr_small_act_grad(float z, float code) {
   return sr_act_grad1(z, code);
 }
 
-__global__ void sr_small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                           const float* __restrict__ bias, float* __restrict__ pre, float* __restrict__ y,
-                                           int B, int K, int N, float act) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * N) return;
-  const int b = i / N, n = i - b * N;
-  float s = bias ? bias[n] : 0.0f;
-  for (int k = 0; k < K; ++k) s = fmaf(x[b * K + k], W[n * K + k], s);
-  if (pre) pre[i] = s;
-  y[i] = sr_small_act(s, act);
+// One wave per output column n, lanes stride k (coalesced rows of W and x), 8 batch rows per pass, wave tree sum.
+__global__ __launch_bounds__(256) void sr_small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                 const float* __restrict__ bias, float* __restrict__ pre,
+                                                                 float* __restrict__ y, int B, int K, int N, float act) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, b0 = blockIdx.y * 8;
+  if (n >= N) return;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(size_t)n * K + k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (b0 + j < B) acc[j] = fmaf(x[(size_t)(b0 + j) * K + k], w, acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+  }
+  if (lane == 0) {
+    const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (b0 + j < B) {
+        const float z = acc[j] + bv;
+        if (pre) pre[(size_t)(b0 + j) * N + n] = z;
+        y[(size_t)(b0 + j) * N + n] = sr_small_act(z, act);
+      }
+  }
 }
 
 // dpre = dy * act'(pre); dx[b,k] = sum_n dpre[b,n] W[n,k]; dW[n,k] = sum_b dpre[b,n] x[b,k]; db[n] = sum_b dpre[b,n]
-__global__ void sr_small_linear_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
-                                           const float* __restrict__ x, const float* __restrict__ W, float* __restrict__ dx,
-                                           float* __restrict__ dW, float* __restrict__ db, int B, int K, int N, float act) {
+// dx: a workgroup = 16 waves x 64 columns k, 8 batch rows; dpre of the 8 rows is staged through LDS in tiles of 512 n, wave
+// w takes n = w, w + 16, ... of a tile (one coalesced row of W per n), the 16 partial sums are added in wave order.
+#define SR_SL_TILE 512
+__global__ __launch_bounds__(1024) void sr_small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
+                                                                 const float* __restrict__ W, float* __restrict__ dx, int B,
+                                                                 int K, int N, float act) {
+  __shared__ float dp[8][SR_SL_TILE];
+  __shared__ float red[16][8][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, k = blockIdx.x * 64 + lane, b0 = blockIdx.y * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+  for (int n0 = 0; n0 < N; n0 += SR_SL_TILE) {
+    const int nn = min(SR_SL_TILE, N - n0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 8 * nn; e += 1024) {
+      const int j = e / nn, n = e - j * nn;
+      float v = 0.0f;
+      if (b0 + j < B) {
+        const size_t o = (size_t)(b0 + j) * N + n0 + n;
+        v = dy[o] * sr_small_act_grad(pre[o], act);
+      }
+      dp[j][n] = v;
+    }
+    __syncthreads();
+    if (k < K) {
+#pragma unroll 4
+      for (int n = wave; n < nn; n += 16) {
+        const float w = W[(size_t)(n0 + n) * K + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(dp[j][n], w, acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wave][j][lane] = acc[j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 8 * 64; e += 1024) {
+    const int j = e >> 6, l = e & 63, kk = blockIdx.x * 64 + l;
+    if (b0 + j < B && kk < K) {
+      float t = red[0][j][l];
+#pragma unroll
+      for (int w2 = 1; w2 < 16; ++w2) t += red[w2][j][l];
+      dx[(size_t)(b0 + j) * K + kk] = t;
+    }
+  }
+}
+
+// dW[n,k] = sum_b dpre[b,n] x[b,k], db[n] = sum_b dpre[b,n]: one thread per output, batch rows in index order
+__global__ void sr_small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
+                                          const float* __restrict__ x, float* __restrict__ dW, float* __restrict__ db, int B,
+                                          int K, int N, float act) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n_dx = B * K, n_dw = N * K;
-  if (i < n_dx) {
-    const int b = i / K, k = i - b * K;
-    float s = 0.0f;
-    for (int n = 0; n < N; ++n) s = fmaf(dy[b * N + n] * sr_small_act_grad(pre[b * N + n], act), W[n * K + k], s);
-    dx[i] = s;
-  } else if (i < n_dx + n_dw) {
-    const int j = i - n_dx, n = j / K, k = j - n * K;
+  const int n_dw = N * K;
+  if (i < n_dw) {
+    const int n = i / K, k = i - n * K;
     float s = 0.0f;
     for (int b = 0; b < B; ++b) s = fmaf(dy[b * N + n] * sr_small_act_grad(pre[b * N + n], act), x[b * K + k], s);
-    dW[j] = s;
-  } else if (i < n_dx + n_dw + N) {
-    const int n = i - n_dx - n_dw;
+    dW[i] = s;
+  } else if (i < n_dw + N) {
+    const int n = i - n_dw;
     float s = 0.0f;
     for (int b = 0; b < B; ++b) s += dy[b * N + n] * sr_small_act_grad(pre[b * N + n], act);
     db[n] = s;
@@ -624,17 +752,19 @@ extern "C" int sr_small_linear_fwd(const float* x, const float* W, const float* 
   if (B < 0 || K <= 0 || N <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (B == 0) return SR_OK;
   if (!x || !W || !y) return SR_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(sr_small_linear_fwd_kernel, dim3((B * N + 127) / 128), dim3(128), 0, (hipStream_t)stream_, x, W, bias, pre, y,
-                     B, K, N, act_code);
+  hipLaunchKernelGGL(sr_small_linear_fwd_kernel, dim3((N + 3) / 4, (B + 7) / 8), dim3(256), 0, (hipStream_t)stream_, x, W, bias,
+                     pre, y, B, K, N, act_code);
   return sr_hip_rc(hipGetLastError());
 }
 
 extern "C" int sr_small_linear_bwd(const float* dy, const float* pre, const float* x, const float* W, float* dx, float* dW,
                                    float* db, int B, int K, int N, float act_code, void* stream_) {
   if (B <= 0 || K <= 0 || N <= 0 || !dy || !pre || !x || !W || !dx || !dW || !db) return SR_ERR_INVALID_ARGUMENT;
-  const int total = B * K + N * K + N;
-  hipLaunchKernelGGL(sr_small_linear_bwd_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream_, dy, pre, x, W, dx,
-                     dW, db, B, K, N, act_code);
+  hipLaunchKernelGGL(sr_small_linear_dx_kernel, dim3((K + 63) / 64, (B + 7) / 8), dim3(1024), 0, (hipStream_t)stream_, dy, pre, W,
+                     dx, B, K, N, act_code);
+  const int total = N * K + N;
+  hipLaunchKernelGGL(sr_small_linear_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, dy, pre, x, dW, db,
+                     B, K, N, act_code);
   return sr_hip_rc(hipGetLastError());
 }
 
