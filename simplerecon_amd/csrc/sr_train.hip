@@ -51,44 +51,71 @@ struct SrColRed {
   float* part0; float* part1;
 };
 
-template <int MODE>
+// V channels per thread (V = 4: 16-byte loads, 16 pixel rows in flight per workgroup; V = 1: any alignment / channel count)
+template <int V> __device__ __forceinline__ void sr_ldv(const float* q, float (&a)[V]) {
+  if (V == 4) { const float4 t = *reinterpret_cast<const float4*>(q); a[0] = t.x; a[1 % V] = t.y; a[2 % V] = t.z; a[3 % V] = t.w; }
+  else a[0] = *q;
+}
+template <int V> __device__ __forceinline__ void sr_stv(float* q, const float (&a)[V]) {
+  if (V == 4) *reinterpret_cast<float4*>(q) = make_float4(a[0], a[1 % V], a[2 % V], a[3 % V]);
+  else *q = a[0];
+}
+
+template <int MODE, int V>
 __global__ __launch_bounds__(256) void sr_colreduce_kernel(SrColRed p) {
-  __shared__ float red0[4][64], red1[4][64];
+  constexpr int LC = 64 / V, ROWS = 256 / LC;   // lanes across the 64-channel block, pixel rows in flight
+  __shared__ float red0[ROWS][64 + V], red1[ROWS][64 + V];
   const int G = p.per_image ? p.B : 1;
   const int64_t npix = p.per_image ? p.HW : (int64_t)p.B * p.HW;   // pixels per group
   const int chunk = blockIdx.x, n = blockIdx.y;
-  const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
+  const int cl = threadIdx.x % LC, row = threadIdx.x / LC;
   const int64_t p0 = (int64_t)chunk * p.chunk_pix, p1 = min(p0 + p.chunk_pix, npix);
-  {
-    const int c = blockIdx.z * 64 + cl;
-    float s0 = 0.0f, s1 = 0.0f;
-    if (c < p.C) {
-      const int sc = n * p.C + c;
-      float m = 0.0f, r = 1.0f, ga = 1.0f, be = 0.0f;
-      if (MODE == 1 || MODE == 2) m = p.mean[sc];
-      if (MODE == 2) {
-        r = 1.0f / sqrtf(p.var[sc] + p.eps);
-        if (p.gamma) ga = p.gamma[c];
-        if (p.beta) be = p.beta[c];
-      }
-      for (int64_t px = p0 + row; px < p1; px += 4) {
-        const int64_t b = p.per_image ? n : px / p.HW, q = p.per_image ? px : px - b * p.HW;
-        const float xv = p.x[b * p.x_sb + q * p.x_sp + c];
-        if (MODE == 0) s0 += xv;
-        else if (MODE == 1) { const float d = xv - m; s0 += d * d; }
+  const int c = blockIdx.z * 64 + V * cl;
+  float s0[V], s1[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { s0[i] = 0.0f; s1[i] = 0.0f; }
+  if (c < p.C) {
+    const int sc = n * p.C + c;
+    float m[V], r[V], ga[V], be[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { m[i] = 0.0f; r[i] = 1.0f; ga[i] = 1.0f; be[i] = 0.0f; }
+    if (MODE == 1 || MODE == 2) sr_ldv<V>(p.mean + sc, m);
+    if (MODE == 2) {
+      sr_ldv<V>(p.var + sc, r);
+#pragma unroll
+      for (int i = 0; i < V; ++i) r[i] = 1.0f / sqrtf(r[i] + p.eps);
+      if (p.gamma) sr_ldv<V>(p.gamma + c, ga);
+      if (p.beta) sr_ldv<V>(p.beta + c, be);
+    }
+    for (int64_t px = p0 + row; px < p1; px += ROWS) {
+      const int64_t b = p.per_image ? n : px / p.HW, q = p.per_image ? px : px - b * p.HW;
+      float xv[V], gv[V];
+      sr_ldv<V>(p.x + b * p.x_sb + q * p.x_sp + c, xv);
+      if (MODE >= 2) sr_ldv<V>(p.g + b * p.g_sb + q * p.g_sp + c, gv);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        if (MODE == 0) s0[i] += xv[i];
+        else if (MODE == 1) { const float d = xv[i] - m[i]; s0[i] += d * d; }
         else if (MODE == 2) {
-          const float xh = (xv - m) * r;
-          const float gp = p.g[b * p.g_sb + q * p.g_sp + c] * sr_act_grad1(ga * xh + be, p.act);
-          s0 += gp; s1 += gp * xh;
-        } else { s0 += xv * p.g[b * p.g_sb + q * p.g_sp + c]; }
+          const float xh = (xv[i] - m[i]) * r[i];
+          const float gp = gv[i] * sr_act_grad1(ga[i] * xh + be[i], p.act);
+          s0[i] += gp; s1[i] += gp * xh;
+        } else { s0[i] += xv[i] * gv[i]; }
       }
     }
-    red0[row][cl] = s0; red1[row][cl] = s1;
-    __syncthreads();
-    if (row == 0 && c < p.C) {
-      const size_t o = ((size_t)chunk * G + n) * p.C + c;
-      p.part0[o] = (red0[0][cl] + red0[1][cl]) + (red0[2][cl] + red0[3][cl]);
-      if (MODE == 2) p.part1[o] = (red1[0][cl] + red1[1][cl]) + (red1[2][cl] + red1[3][cl]);
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) { red0[row][V * cl + i] = s0[i]; red1[row][V * cl + i] = s1[i]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int co = blockIdx.z * 64 + threadIdx.x;
+    if (co < p.C) {
+      float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+      for (int rr = 0; rr < ROWS; ++rr) { t0 += red0[rr][threadIdx.x]; t1 += red1[rr][threadIdx.x]; }
+      const size_t o = ((size_t)chunk * G + n) * p.C + co;
+      p.part0[o] = t0;
+      if (MODE == 2) p.part1[o] = t1;
     }
   }
 }
@@ -127,7 +154,12 @@ extern "C" size_t sr_norm_workspace_bytes(int B, int HW, int C, int per_image) {
 template <int MODE>
 static int sr_colreduce(SrColRed p, float* out0, float scale0, float* out1, float scale1, hipStream_t stream) {
   const int G = p.per_image ? p.B : 1;
-  hipLaunchKernelGGL(sr_colreduce_kernel<MODE>, dim3(p.chunks, G, (p.C + 63) / 64), dim3(256), 0, stream, p);
+  const uintptr_t bits = (uintptr_t)p.x | (uintptr_t)p.g | (uintptr_t)p.mean | (uintptr_t)p.var | (uintptr_t)p.gamma |
+                         (uintptr_t)p.beta;
+  const bool vec4 = (p.C % 4 == 0) && (bits & 15) == 0 && (p.x_sp % 4 == 0) && (p.x_sb % 4 == 0) && (p.g_sp % 4 == 0) &&
+                    (p.g_sb % 4 == 0);
+  if (vec4) hipLaunchKernelGGL((sr_colreduce_kernel<MODE, 4>), dim3(p.chunks, G, (p.C + 63) / 64), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((sr_colreduce_kernel<MODE, 1>), dim3(p.chunks, G, (p.C + 63) / 64), dim3(256), 0, stream, p);
   const int n_out = G * p.C;
   hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((n_out + 15) / 16), dim3(256), 0, stream, p.part0, p.chunks, n_out,
                      scale0, out0);
@@ -166,26 +198,48 @@ struct SrNormEw {
   int B, HW, C, per_image, train_stats;
 };
 
-template <bool BWD>
+template <bool BWD, int V>
 __global__ __launch_bounds__(256) void sr_norm_ew_kernel(SrNormEw p) {
-  const int64_t total = (int64_t)p.B * p.HW * p.C;
+  const int CV = p.C / V;
+  const int64_t total = (int64_t)p.B * p.HW * CV;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(e % p.C);
-    const int64_t px = e / p.C, b = px / p.HW, q = px - b * p.HW;
+    const int c = V * (int)(e % CV);
+    const int64_t px = e / CV, b = px / p.HW, q = px - b * p.HW;
     const int sc = (p.per_image ? (int)b : 0) * p.C + c;
-    const float r = 1.0f / sqrtf(p.var[sc] + p.eps);
-    const float ga = p.gamma ? p.gamma[c] : 1.0f, be = p.beta ? p.beta[c] : 0.0f;
-    const float xh = (p.x[b * p.x_sb + q * p.x_sp + c] - p.mean[sc]) * r;
-    const float z = ga * xh + be;
-    if (!BWD) {
-      p.y[b * p.y_sb + q * p.y_sp + c] = sr_act_fwd1(z, p.act);
-    } else {
-      const float gp = p.g[b * p.g_sb + q * p.g_sp + c] * sr_act_grad1(z, p.act);
-      float dx = gp;
-      if (p.train_stats) dx = gp - p.s0[sc] - xh * p.s1[sc];
-      p.y[b * p.y_sb + q * p.y_sp + c] = ga * r * dx;
+    float r[V], m[V], ga[V], be[V], xv[V], gv[V], t0[V], t1[V], out[V];
+    sr_ldv<V>(p.var + sc, r);
+    sr_ldv<V>(p.mean + sc, m);
+#pragma unroll
+    for (int i = 0; i < V; ++i) { ga[i] = 1.0f; be[i] = 0.0f; t0[i] = 0.0f; t1[i] = 0.0f; gv[i] = 0.0f; }
+    if (p.gamma) sr_ldv<V>(p.gamma + c, ga);
+    if (p.beta) sr_ldv<V>(p.beta + c, be);
+    sr_ldv<V>(p.x + b * p.x_sb + q * p.x_sp + c, xv);
+    if (BWD) {
+      sr_ldv<V>(p.g + b * p.g_sb + q * p.g_sp + c, gv);
+      if (p.train_stats) { sr_ldv<V>(p.s0 + sc, t0); sr_ldv<V>(p.s1 + sc, t1); }
     }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float ri = 1.0f / sqrtf(r[i] + p.eps);
+      const float xh = (xv[i] - m[i]) * ri;
+      const float z = ga[i] * xh + be[i];
+      if (!BWD) out[i] = sr_act_fwd1(z, p.act);
+      else {
+        const float gp = gv[i] * sr_act_grad1(z, p.act);
+        float dx = gp;
+        if (p.train_stats) dx = gp - t0[i] - xh * t1[i];
+        out[i] = ga[i] * ri * dx;
+      }
+    }
+    sr_stv<V>(p.y + b * p.y_sb + q * p.y_sp + c, out);
   }
+}
+
+static bool sr_norm_ew_vec4(const SrNormEw& p) {
+  const uintptr_t bits = (uintptr_t)p.x | (uintptr_t)p.g | (uintptr_t)p.y | (uintptr_t)p.mean | (uintptr_t)p.var |
+                         (uintptr_t)p.gamma | (uintptr_t)p.beta | (uintptr_t)p.s0 | (uintptr_t)p.s1;
+  return (p.C % 4 == 0) && (bits & 15) == 0 && (p.x_sp % 4 == 0) && (p.x_sb % 4 == 0) && (p.g_sp % 4 == 0) &&
+         (p.g_sb % 4 == 0) && (p.y_sp % 4 == 0) && (p.y_sb % 4 == 0);
 }
 
 static int sr_ew_blocks(int64_t total) {
@@ -203,7 +257,12 @@ extern "C" int sr_norm_act_fwd_nhwc(const float* x, int64_t x_sb, int x_sp, cons
   p.x = x; p.x_sb = x_sb; p.x_sp = x_sp; p.y = y; p.y_sb = y_sb; p.y_sp = y_sp;
   p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.eps = eps; p.act = act_code;
   p.B = B; p.HW = HW; p.C = C; p.per_image = per_image;
-  hipLaunchKernelGGL(sr_norm_ew_kernel<false>, dim3(sr_ew_blocks((int64_t)B * HW * C)), dim3(256), 0, (hipStream_t)stream_, p);
+  if (sr_norm_ew_vec4(p))
+    hipLaunchKernelGGL((sr_norm_ew_kernel<false, 4>), dim3(sr_ew_blocks((int64_t)B * HW * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream_, p);
+  else
+    hipLaunchKernelGGL((sr_norm_ew_kernel<false, 1>), dim3(sr_ew_blocks((int64_t)B * HW * C)), dim3(256), 0,
+                       (hipStream_t)stream_, p);
   return sr_hip_rc(hipGetLastError());
 }
 
@@ -240,7 +299,10 @@ extern "C" int sr_norm_act_bwd_nhwc(const float* g, int64_t g_sb, int g_sp, cons
   p.x = x; p.x_sb = x_sb; p.x_sp = x_sp; p.g = g; p.g_sb = g_sb; p.g_sp = g_sp; p.y = dx; p.y_sb = dx_sb; p.y_sp = dx_sp;
   p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.s0 = s0; p.s1 = s1; p.eps = eps; p.act = act_code;
   p.B = B; p.HW = HW; p.C = C; p.per_image = per_image; p.train_stats = train_stats;
-  hipLaunchKernelGGL(sr_norm_ew_kernel<true>, dim3(sr_ew_blocks((int64_t)B * HW * C)), dim3(256), 0, stream, p);
+  if (sr_norm_ew_vec4(p))
+    hipLaunchKernelGGL((sr_norm_ew_kernel<true, 4>), dim3(sr_ew_blocks((int64_t)B * HW * (C / 4))), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((sr_norm_ew_kernel<true, 1>), dim3(sr_ew_blocks((int64_t)B * HW * C)), dim3(256), 0, stream, p);
   return sr_hip_rc(hipGetLastError());
 }
 
