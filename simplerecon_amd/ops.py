@@ -176,6 +176,7 @@ def packed_weight(conv: nn.Conv2d, bn=None):
 _GEMM_W = weakref.WeakKeyDictionary()  # nn.Conv2d (1x1) -> (state key, [Cout, Cin] weight with BN folded, bias)
 USE_GEMM_1X1 = os.environ.get("SR_CONV1X1_GEMM", "1") != "0"   # 0: every 1x1 conv on the implicit-GEMM HIP kernel
 GEMM_1X1_MIN_PIXELS = 1024
+SHORTCUT_GEMM = os.environ.get("SR_SHORTCUT_GEMM", "1") != "0"   # BasicBlock's 1x1 skip conv as a library GEMM
 
 
 def gemm_weight(conv: nn.Conv2d, bn=None):
@@ -384,7 +385,7 @@ def basic_block(block, x, out=None):
     slope = block.relu.negative_slope
     x = as_nhwc(x, "BasicBlock input")
     t = conv2d(x, block.conv1, leaky=slope)
-    identity = x if block.downsample is None else conv2d(x, block.downsample[0])
+    identity = x if block.downsample is None else conv2d(x, block.downsample[0], library_gemm=SHORTCUT_GEMM)
     return conv2d(t, block.conv2, residual=identity, leaky=slope, out=out)
 
 
