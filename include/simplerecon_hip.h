@@ -94,6 +94,11 @@ int sr_gemm1x1_nhwc_fwd(const float* in, int in_pix_stride, const float* weight,
 int sr_backproject_fwd(const float* depth, const float* invK, float* out_points, int B, int h, int w, void* stream);
 int sr_project3d_fwd(const float* points, const float* K, const float* T, float* out, int B, int N, float eps,
                      void* stream);
+/* Adjoints for the training losses that call the two modules (reference losses.py via geometry_utils.py:51-59, 72-89):
+ * d_depth [B,h*w] from d_points [B,4,h*w]; d_points [B,4,N] from d_out [B,3,N].  Intrinsics / poses are data. */
+int sr_backproject_bwd(const float* grad_points, const float* invK, float* grad_depth, int B, int h, int w, void* stream);
+int sr_project3d_bwd(const float* grad_out, const float* points, const float* K, const float* T, float* grad_points, int B,
+                     int N, float eps, void* stream);
 int sr_pose_distance_fwd(const float* T, float* out, int n, void* stream);
 int sr_camera_rays_fwd(const float* points, const float* T, float* out, int B, int N, int in_camera_frame, void* stream);
 

@@ -8,6 +8,8 @@ SHAPES = [(64, 240, 320, 64), (192, 240, 320, 64), (128, 240, 320, 64), (24, 240
           (256, 30, 40, 128), (128, 30, 40, 128), (512, 30, 40, 256), (416, 30, 40, 256), (384, 15, 20, 384),
           (384, 15, 20, 256), (640, 15, 20, 384), (256, 15, 20, 256)]
 PLANS = [(0, 0), (2, 1), (1, 1), (2, 2), (1, 2), (2, 4), (1, 4), (2, 8), (1, 8)]
+if os.environ.get("SR_SWEEP_PLANS"):   # e.g. "0:0,2:1,1:1"
+    PLANS = [tuple(int(v) for v in t.split(":")) for t in os.environ["SR_SWEEP_PLANS"].split(",")]
 
 
 def child():

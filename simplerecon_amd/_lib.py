@@ -33,6 +33,8 @@ SIGNATURES = {
     "sr_gemm1x1_nhwc_fwd": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "sr_backproject_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "sr_project3d_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
+    "sr_backproject_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "sr_project3d_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "sr_pose_distance_fwd": (_i, [_p, _p, _i, _p]),
     "sr_camera_rays_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "sr_selftest_rcp": (_i, [_p, _p, _p, _i, _p]),

@@ -11,6 +11,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SR_WINO_WAVES 2  // waves per SIMD the register allocation must allow (2 = two workgroups per CU)
 #endif
 
+#ifndef SR_WINO_NT1_WAVES
+#define SR_WINO_NT1_WAVES 2  // the same for the 32-output-channel instantiation (64 accumulator registers, 46 KB of LDS)
+#endif
+
 #ifndef SR_WINO_NB
 #define SR_WINO_NB 4   // rotating weight-fragment register sets; must divide the 8 steps of a slab
 #define SR_WINO_PD 3   // prefetch distance in steps (< NB)
@@ -26,13 +30,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WN_PW (2 * WN_TC + 2)  // 18 patch cols
 #define WN_ROW 20              // floats per staged pixel / per V row (16 channels + 4 pad)
 #define WN_RAW_FLOATS (WN_PH * WN_PW * WN_ROW)
-#define WN_O_FLOATS (8 * 32 * 64)
+#define WN_O_FLOATS(nt) (8 * 32 * 32 * (nt))
 // Raw buffer A shares the first 64 KB with the epilogue slab O (A is dead by the epilogue); raw buffer B lives behind
 // them so that the NEXT region's first slab can be staged while the current region finishes (its last MFMA phase and
 // its epilogue): 78 KB, 2 workgroups per CU.
-#define WN_V_FLOATS (WN_O_FLOATS - WN_RAW_FLOATS)   // offset of raw A: the tail of the O area
-#define WN_VO_FLOATS WN_O_FLOATS
-#define WN_LDS_FLOATS (WN_VO_FLOATS + WN_RAW_FLOATS)
+#define WN_V_FLOATS(nt) (WN_O_FLOATS(nt) - WN_RAW_FLOATS)   // offset of raw A: the tail of the O area
+#define WN_LDS_FLOATS(nt) (WN_O_FLOATS(nt) + WN_RAW_FLOATS)
 #define WN_STAGE_ELEMS (WN_PH * WN_PW * 4)  // float4 elements per slab (720)
 #define WN_STAGE_PER_THREAD 3
 

@@ -58,11 +58,11 @@ __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restri
 }
 
 template <int NT, bool VEC4, bool VOUT>
-__global__ __launch_bounds__(256, SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
+__global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* O = lds;                     // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases raw A)
-  float* rawA = lds + WN_V_FLOATS;    // [10*18][20]  odd slabs  (inside the O area: dead by the epilogue)
-  float* rawB = lds + WN_VO_FLOATS;   // [10*18][20]  even slabs (behind it: survives the epilogue)
+  float* O = lds;                           // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases raw A)
+  float* rawA = lds + WN_V_FLOATS(NT);      // [10*18][20]  odd slabs  (inside the O area: dead by the epilogue)
+  float* rawB = lds + WN_O_FLOATS(NT);      // [10*18][20]  even slabs (behind it: survives the epilogue)
   const int tid = threadIdx.x;
   // (readfirstlane: the wave index is uniform, so everything derived from it -- the weight-record offsets of the MFMA
   // loop above all -- is scalar arithmetic; as a plain `tid >> 6` it cost 7 VALU instructions per MFMA step)
@@ -638,10 +638,10 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_WINO_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   { const char* e = getenv("SR_WINO_XCD"); p.xcd_order = e ? atoi(e) : 1; }
   hipStream_t stream = (hipStream_t)stream_;
-  int blocks = sr_wino_num_cus() * 2;
+  int blocks = sr_wino_num_cus() * (nt == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES);
   { const char* e = getenv("SR_WINO_WG_PER_CU"); if (e && atoi(e) == 1) blocks = sr_wino_num_cus(); }  // ablation
   if (blocks > p.total) blocks = p.total;
-  const size_t lds = (size_t)WN_LDS_FLOATS * sizeof(float);
+  const size_t lds = (size_t)WN_LDS_FLOATS(nt) * sizeof(float);
 #ifdef SR_WINO_TRACE
   static unsigned long long* trace_buf = nullptr;
   static int launches = 0;

@@ -3,7 +3,8 @@
 The modules hold the reference's buffers (`pix_coords_13N`, `eps`: checkpoints load with strict=True).  Inside the plane
 sweeps their arithmetic is fused into the HIP kernels (csrc/sr_common.h: sr_project_sample_xy); called on their own they
 run the standalone kernels of csrc/sr_geometry.hip, which use the same operation order -- there is no torch / CPU
-fallback (device fp32 tensors only, like the rest of the package)."""
+fallback (device fp32 tensors only, like the rest of the package).  BackprojectDepth is differentiable in the depth map
+and Project3D in the points, as the reference's multi-view losses need; cameras are data."""
 import ctypes as C
 
 import torch
@@ -18,6 +19,75 @@ def _f32c(name, t):
     return t.contiguous()
 
 
+def _data(name, t):
+    """Intrinsics / poses: data on this path (the reference does not optimise them either) -- no gradient is produced."""
+    _lib.require_device_f32(name, t)
+    if torch.is_grad_enabled() and t.requires_grad:
+        raise _lib.HipLibraryError(f"{name} requires a gradient: cameras are data for the HIP geometry helpers")
+    return t.detach().contiguous()
+
+
+def _diff(name, t):
+    _lib.require_device_f32(name, t)
+    return t.contiguous()
+
+
+class _Backproject(torch.autograd.Function):
+    """d cam_points / d depth (what the reference's multi-view losses differentiate); csrc/sr_geometry.hip."""
+
+    @staticmethod
+    def forward(ctx, depth, invK, height, width):
+        b = depth.shape[0]
+        out = torch.empty((b, 4, height * width), dtype=torch.float32, device=depth.device)
+        with torch.cuda.device(depth.device):
+            rc = _lib.lib().sr_backproject_fwd(_lib.ptr(depth), _lib.ptr(invK), _lib.ptr(out), b, height, width,
+                                               _lib.stream_ptr(depth.device))
+        _lib.check(rc, "sr_backproject_fwd")
+        ctx.save_for_backward(invK)
+        ctx.hw, ctx.depth_shape = (height, width), tuple(depth.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (invK,) = ctx.saved_tensors
+        g = g.contiguous()
+        h, w = ctx.hw
+        d_depth = torch.empty(ctx.depth_shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().sr_backproject_bwd(_lib.ptr(g), _lib.ptr(invK), _lib.ptr(d_depth), g.shape[0], h, w,
+                                               _lib.stream_ptr(g.device))
+        _lib.check(rc, "sr_backproject_bwd")
+        return d_depth, None, None, None
+
+
+class _Project(torch.autograd.Function):
+    """d (pixel x, pixel y, depth) / d points; csrc/sr_geometry.hip."""
+
+    @staticmethod
+    def forward(ctx, pts, K, T, eps):
+        b, _, n = pts.shape
+        out = torch.empty((b, 3, n), dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            rc = _lib.lib().sr_project3d_fwd(_lib.ptr(pts), _lib.ptr(K), _lib.ptr(T), _lib.ptr(out), b, n, C.c_float(eps),
+                                             _lib.stream_ptr(pts.device))
+        _lib.check(rc, "sr_project3d_fwd")
+        ctx.save_for_backward(pts, K, T)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pts, K, T = ctx.saved_tensors
+        g = g.contiguous()
+        b, _, n = pts.shape
+        d_pts = torch.empty_like(pts)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().sr_project3d_bwd(_lib.ptr(g), _lib.ptr(pts), _lib.ptr(K), _lib.ptr(T), _lib.ptr(d_pts), b, n,
+                                             C.c_float(ctx.eps), _lib.stream_ptr(g.device))
+        _lib.check(rc, "sr_project3d_bwd")
+        return d_pts, None, None, None
+
+
 class BackprojectDepth(nn.Module):
     """Holds `pix_coords_13N` (pixel centres at +0.5, reference geometry_utils.py:34-48)."""
 
@@ -30,16 +100,11 @@ class BackprojectDepth(nn.Module):
 
     def forward(self, depth_b1hw, invK_b44):
         """depth [B,1,h,w], invK [B,4,4] -> homogeneous camera points [B,4,h*w] (reference geometry_utils.py:51-59)."""
-        depth, invK = _f32c("depth_b1hw", depth_b1hw), _f32c("invK_b44", invK_b44)
+        depth, invK = _diff("depth_b1hw", depth_b1hw), _data("invK_b44", invK_b44)
         b = depth.shape[0]
         if tuple(depth.shape[-2:]) != (self.height, self.width) or depth.numel() != b * self.height * self.width:
             raise ValueError(f"depth map {tuple(depth.shape)} does not match {self.height}x{self.width}")
-        out = torch.empty((b, 4, self.height * self.width), dtype=torch.float32, device=depth.device)
-        with torch.cuda.device(depth.device):
-            rc = _lib.lib().sr_backproject_fwd(_lib.ptr(depth), _lib.ptr(invK), _lib.ptr(out), b, self.height, self.width,
-                                               _lib.stream_ptr(depth.device))
-        _lib.check(rc, "sr_backproject_fwd")
-        return out
+        return _Backproject.apply(depth, invK, self.height, self.width)   # differentiable in the depth map
 
 
 class Project3D(nn.Module):
@@ -52,16 +117,11 @@ class Project3D(nn.Module):
 
     def forward(self, points_b4N, K_b44, cam_T_world_b44):
         """points [B,4,N] -> [B,3,N] = (pixel x, pixel y, depth + eps) (reference geometry_utils.py:72-89)."""
-        pts, K, T = _f32c("points_b4N", points_b4N), _f32c("K_b44", K_b44), _f32c("cam_T_world_b44", cam_T_world_b44)
+        pts, K, T = _diff("points_b4N", points_b4N), _data("K_b44", K_b44), _data("cam_T_world_b44", cam_T_world_b44)
         b, four, n = pts.shape
         if four != 4 or tuple(K.shape) != (b, 4, 4) or tuple(T.shape) != (b, 4, 4):
             raise ValueError("expected points [B,4,N], K [B,4,4], cam_T_world [B,4,4]")
-        out = torch.empty((b, 3, n), dtype=torch.float32, device=pts.device)
-        with torch.cuda.device(pts.device):
-            rc = _lib.lib().sr_project3d_fwd(_lib.ptr(pts), _lib.ptr(K), _lib.ptr(T), _lib.ptr(out), b, n,
-                                             C.c_float(self._eps), _lib.stream_ptr(pts.device))
-        _lib.check(rc, "sr_project3d_fwd")
-        return out
+        return _Project.apply(pts, K, T, self._eps)   # differentiable in the points
 
 
 def pose_distance(pose_b44):

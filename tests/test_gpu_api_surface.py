@@ -66,6 +66,37 @@ def test_geometry_helpers_on_hip():
         geometry.BackprojectDepth(h, w)(depth.cpu(), inp["cur_invK"].cpu())   # device modules: no CPU fallback
 
 
+def test_geometry_modules_are_differentiable_like_the_reference():
+    """The reference's multi-view losses differentiate BackprojectDepth in the depth map and Project3D in the points
+    (geometry_utils.py:51-59, 72-89): the HIP adjoints equal torch autograd of the same composition; cameras are data."""
+    B, K, h, w = 2, 3, 9, 13
+    inp = {k: v.to(DEV) for k, v in synthetic.cost_volume_inputs(B, K, 16, h, w, seed=5).items()}
+    Ks, T = inp["src_Ks"][:, 0].contiguous(), inp["src_extrinsics"][:, 0].contiguous()
+    torch.manual_seed(3)
+    depth0 = 0.5 + 3.0 * torch.rand((B, 1, h, w), device=DEV)
+    cot = torch.randn((B, 3, h * w), device=DEV)
+    bp, pr = geometry.BackprojectDepth(h, w).to(DEV), geometry.Project3D().to(DEV)
+
+    depth = depth0.clone().requires_grad_(True)
+    pts = bp(depth, inp["cur_invK"])
+    cam = pr(pts, Ks, T)
+    (cam * cot).sum().backward()
+
+    depth_r = depth0.clone().requires_grad_(True)
+    pts_r = _torch_backproject(depth_r, inp["cur_invK"], h, w)
+    pts_r.retain_grad()
+    cam_r = _torch_project(pts_r, Ks, T)
+    (cam_r * cot).sum().backward()
+    assert_close(cam.detach(), cam_r.detach(), tol=1e-5, what="forward under autograd")
+    assert_close(depth.grad, depth_r.grad, tol=1e-5, what="d loss / d depth")
+
+    pts_leaf = pts_r.detach().clone().requires_grad_(True)
+    (pr(pts_leaf, Ks, T) * cot).sum().backward()
+    assert_close(pts_leaf.grad, pts_r.grad, tol=1e-5, what="d loss / d points")
+    with pytest.raises(Exception, match="cameras are data"):
+        bp(depth0, inp["cur_invK"].clone().requires_grad_(True))
+
+
 def _torch_warp(inp, planes_b1hw, h, w):
     """Plain PyTorch fp32 reference of the op (same composition as reference cost_volume.py:139-234)."""
     b, k, c = inp["src_feats"].shape[:3]
