@@ -33,12 +33,16 @@ struct SrWgradParams {
   int vec_x, vec_g;   // input / gradient rows are whole 16-byte aligned channel quads: float4 staging loads
 };
 
-template <int KS>
+// PIPE (stride 1): the staging loads of the NEXT item are issued into registers before the current item's MFMA loop and
+// stored to LDS after it (one float4 per slot, slot coordinates fixed per thread -- no divisions, no load -> store ->
+// load latency chain per item: the first version issued its 7 + 2 loads per item one at a time, each followed by its
+// LDS store, ~7 us of exposed latency against 3.8 us of MFMA work).  Stride 2 keeps the direct form.
+template <int KS, bool PIPE>
 __global__ __launch_bounds__(256) void sr_conv_wgrad_kernel(SrWgradParams p) {
   constexpr int TAPS = KS * KS;
   // LDS: gradient segment [WG_P][64 co] + input rows [KS][span][64 ci], span = stride*(WG_P-1) + KS (<= 65)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int span = p.stride * (WG_P - 1) + KS;
+  const int span = PIPE ? (WG_P - 1 + KS) : p.stride * (WG_P - 1) + KS;
   float* gs = lds;                       // [WG_P][WG_CT]
   float* xs = lds + WG_P * WG_CT;        // [KS][span][WG_CT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,13 +59,77 @@ __global__ __launch_bounds__(256) void sr_conv_wgrad_kernel(SrWgradParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  for (int item = sub; item < p.items; item += p.wgs_per_block) {
+  // register staging (PIPE): GS gradient slots + XS input slots of one float4 each
+  constexpr int SPAN1 = WG_P - 1 + KS;
+  constexpr int GS = WG_P * (WG_CT / 4) / 256;                       // 2
+  constexpr int XS = PIPE ? (KS * SPAN1 * (WG_CT / 4) + 255) / 256 : 1;   // 7 (3x3), 2 (1x1)
+  float4 gq[GS], xq[XS];
+  auto fetch = [&](int item) {
     int it = item;
     const int seg = it % segs; it /= segs;
     const int oy = it % p.Ho;
     const int b = it / p.Ho;
     const int ox0 = seg * WG_P;
+#pragma unroll
+    for (int u = 0; u < GS; ++u) {
+      const int e = tid + 256 * u, px = e >> 4, q = e & 15;
+      const int ox = ox0 + px, c = co0 + 4 * q;
+      const bool ok = ox < p.Wo && c < p.Cout;
+      const float* src = p.g + (int64_t)b * p.g_sb + (ok ? (oy * p.Wo + ox) * p.g_sp + c : 0);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.vec_g) { const float4 t = *reinterpret_cast<const float4*>(src); if (ok) v = t; }
+      else if (ok) {
+        v.x = src[0];
+        if (c + 1 < p.Cout) v.y = src[1];
+        if (c + 2 < p.Cout) v.z = src[2];
+        if (c + 3 < p.Cout) v.w = src[3];
+      }
+      gq[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < XS; ++u) {
+      const int e = tid + 256 * u, q = e & 15, pc = e >> 4;
+      const int col = pc % SPAN1, ky = pc / SPAN1;   // compile-time divisor
+      const int iy = oy + ky - p.pad, ix = ox0 + col - p.pad_x, c = ci0 + 4 * q;
+      const bool ok = ky < KS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin;
+      const float* src = p.x + (int64_t)b * p.x_sb + (ok ? (iy * p.W + ix) * p.x_sp + c : 0);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.vec_x) { const float4 t = *reinterpret_cast<const float4*>(src); if (ok) v = t; }
+      else if (ok) {
+        v.x = src[0];
+        if (c + 1 < p.Cin) v.y = src[1];
+        if (c + 2 < p.Cin) v.z = src[2];
+        if (c + 3 < p.Cin) v.w = src[3];
+      }
+      xq[u] = v;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int u = 0; u < GS; ++u) {
+      const int e = tid + 256 * u;
+      *reinterpret_cast<float4*>(&gs[(e >> 4) * WG_CT + 4 * (e & 15)]) = gq[u];
+    }
+#pragma unroll
+    for (int u = 0; u < XS; ++u) {
+      const int e = tid + 256 * u;
+      if (e < KS * SPAN1 * (WG_CT / 4)) *reinterpret_cast<float4*>(&xs[(e >> 4) * WG_CT + 4 * (e & 15)]) = xq[u];
+    }
+  };
+  if (PIPE && sub < p.items) fetch(sub);
+
+  for (int item = sub; item < p.items; item += p.wgs_per_block) {
     __syncthreads();  // previous item's fragments are consumed
+    if (PIPE) {
+      stash();
+      __syncthreads();
+      if (item + p.wgs_per_block < p.items) fetch(item + p.wgs_per_block);   // in flight under this item's MFMAs
+    } else {
+    int it = item;
+    const int seg = it % segs; it /= segs;
+    const int oy = it % p.Ho;
+    const int b = it / p.Ho;
+    const int ox0 = seg * WG_P;
     // stage dL/dy[b, oy, ox0 .. ox0+31, co0 .. co0+63] (zeros outside the map / the channel range)
     for (int e = tid; e < WG_P * (WG_CT / 4); e += 256) {
       const int px = e >> 4, q = e & 15;
@@ -98,14 +166,16 @@ __global__ __launch_bounds__(256) void sr_conv_wgrad_kernel(SrWgradParams p) {
       *reinterpret_cast<float4*>(&xs[(ky * span + col) * WG_CT + 4 * q]) = v;
     }
     __syncthreads();
+    }
     // K loop: two output pixels per MFMA step (lane half kk picks the pixel)
+    const int st = PIPE ? 1 : p.stride;
 #pragma unroll 4
     for (int ps = 0; ps < WG_P; ps += 2) {
       const float a = gs[(ps + kk) * WG_CT + 32 * coh + i];          // A[m = co][k = pixel]
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int ky = t / KS, kx = t - ky * KS;
-        const float bq = xs[(ky * span + p.stride * (ps + kk) + kx) * WG_CT + 32 * cih + i];   // B[k = pixel][n = ci]
+        const float bq = xs[(ky * span + st * (ps + kk) + kx) * WG_CT + 32 * cih + i];   // B[k = pixel][n = ci]
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
       }
     }
@@ -201,14 +271,20 @@ extern "C" int sr_conv_wgrad_padded_nhwc(const float* in, int64_t in_batch_strid
   p.vec_g = Cout % 4 == 0 && g_pix_stride % 4 == 0 && g_batch_stride % 4 == 0 && (((uintptr_t)grad_out) & 15) == 0;
   const int span = stride * (WG_P - 1) + ksize;
   const size_t lds = (size_t)(WG_P * WG_CT + ksize * span * WG_CT) * sizeof(float);
-  if (ksize == 3) {
-    hipError_t e = hipFuncSetAttribute((const void*)sr_conv_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return sr_hip_rc(e);
-    hipLaunchKernelGGL(sr_conv_wgrad_kernel<3>, dim3(blocks * per), dim3(256), lds, stream, p);
-  } else {
-    hipLaunchKernelGGL(sr_conv_wgrad_kernel<1>, dim3(blocks * per), dim3(256), lds, stream, p);
+  // pixel offsets are 32-bit in the pipelined form
+  const bool pipe = stride == 1 && (int64_t)H * W * in_pix_stride < 0x7fffffffLL && (int64_t)Ho * Wo * g_pix_stride < 0x7fffffffLL;
+#define SR_WGRAD_LAUNCH(KSV, PV)                                                                                     \
+  {                                                                                                                  \
+    hipError_t e = hipFuncSetAttribute((const void*)sr_conv_wgrad_kernel<KSV, PV>,                                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+    if (e != hipSuccess) return sr_hip_rc(e);                                                                        \
+    hipLaunchKernelGGL((sr_conv_wgrad_kernel<KSV, PV>), dim3(blocks * per), dim3(256), lds, stream, p);              \
   }
+  if (ksize == 3 && pipe) SR_WGRAD_LAUNCH(3, true)
+  else if (ksize == 3) SR_WGRAD_LAUNCH(3, false)
+  else if (pipe) SR_WGRAD_LAUNCH(1, true)
+  else SR_WGRAD_LAUNCH(1, false)
+#undef SR_WGRAD_LAUNCH
   int rc = sr_hip_rc(hipGetLastError());
   if (rc != SR_OK) return rc;
   const long total = (long)blocks * ksize * ksize * WG_CT * WG_CT;
