@@ -424,16 +424,23 @@ __global__ __launch_bounds__(256) void sr_act_bwd_bias_kernel(const float4* __re
   }
 }
 
+// a workgroup = 16 channels x 16 block lanes (lane j adds blocks j, j + 16, ... in index order, then the 16 lane sums in
+// lane order: deterministic; one workgroup of 4 lanes per channel walked up to 1024 partials per lane in a row)
 __global__ __launch_bounds__(256) void sr_bias_partial_reduce_kernel(const float* __restrict__ partial, int blocks, int C,
                                                                     float* __restrict__ db) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, j = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   float s = 0.0f;
   if (c < C)
-    for (int b = part; b < blocks; b += 4) s += partial[(int64_t)b * C + c];   // fixed order per lane
-  red[part][cl] = s;
+    for (int b = j; b < blocks; b += 16) s += partial[(int64_t)b * C + c];
+  red[j][cl] = s;
   __syncthreads();
-  if (part == 0 && c < C) db[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (j == 0 && c < C) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][cl];
+    db[c] = t;
+  }
 }
 
 static int sr_act_bwd_bias_blocks(int64_t pixels, int C) {
@@ -469,7 +476,7 @@ extern "C" int sr_act_bwd_bias_nhwc(const float* grad, const float* out_saved, f
                      (const float4*)out_saved, (float4*)grad_pre, d_bias ? (float4*)workspace : (float4*)nullptr, pixels, CQ,
                      LQ, PB, leaky_slope);
   if (d_bias)
-    hipLaunchKernelGGL(sr_bias_partial_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)workspace,
+    hipLaunchKernelGGL(sr_bias_partial_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, (const float*)workspace,
                        blocks, C, d_bias);
   return sr_hip_rc(hipGetLastError());
 }

@@ -602,39 +602,55 @@ __global__ __launch_bounds__(256) void sr_dw_dgrad_kernel(const float* __restric
 }
 
 // weight gradient: part[chunk][tap][c] over the output pixels of a chunk, then sr_colreduce_finish_kernel
+template <int V>
 __global__ __launch_bounds__(256) void sr_dw_wgrad_kernel(const float* __restrict__ g, int64_t g_sb, int g_sp,
                                                          const float* __restrict__ x, int64_t x_sb, int x_sp,
                                                          float* __restrict__ part, int B, int H, int W, int Ho, int Wo, int C,
                                                          int s, int pt, int pl, int chunk_pix) {
-  __shared__ float red[4][9][64];
+  constexpr int LC = 64 / V, ROWS = 256 / LC;   // V channels per thread (V = 4: 16-byte loads, 16 pixel rows in flight)
+  __shared__ float red[ROWS][9][64 + V];
   const int chunk = blockIdx.x;
-  const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
-  const int64_t npix = (int64_t)B * Ho * Wo;
+  const int cl = threadIdx.x % LC, row = threadIdx.x / LC;
+  const int HWo = Ho * Wo;
+  const int64_t npix = (int64_t)B * HWo;
   const int64_t p0 = (int64_t)chunk * chunk_pix, p1 = min(p0 + chunk_pix, npix);
-  {
-    const int c = blockIdx.y * 64 + cl;
-    float acc[9];
+  const int c = blockIdx.y * 64 + V * cl;
+  float acc[9][V];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.0f;
-    if (c < C) {
-      for (int64_t px = p0 + row; px < p1; px += 4) {
-        const int b = (int)(px / ((int64_t)Ho * Wo));
-        const int q = (int)(px - (int64_t)b * Ho * Wo), oy = q / Wo, ox = q - oy * Wo;
-        const float gv = g[(int64_t)b * g_sb + (int64_t)q * g_sp + c];
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int iy = s * oy + t / 3 - pt, ix = s * ox + t % 3 - pl;
-          if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc[t] += gv * x[(int64_t)b * x_sb + ((int64_t)iy * W + ix) * x_sp + c];
+    for (int i = 0; i < V; ++i) acc[t][i] = 0.0f;
+  if (c < C) {
+    for (int64_t px = p0 + row; px < p1; px += ROWS) {
+      const int b = (int)(px / HWo);
+      const int q = (int)(px - (int64_t)b * HWo), oy = q / Wo, ox = q - oy * Wo;
+      float gv[V];
+      sr_ldv<V>(g + (int64_t)b * g_sb + (int64_t)q * g_sp + c, gv);
+      const float* xb = x + (int64_t)b * x_sb + c;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = s * oy + t / 3 - pt, ix = s * ox + t % 3 - pl;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+          float xv[V];
+          sr_ldv<V>(xb + ((int64_t)iy * W + ix) * x_sp, xv);
+#pragma unroll
+          for (int i = 0; i < V; ++i) acc[t][i] += gv[i] * xv[i];
         }
       }
     }
+  }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[row][t][cl] = acc[t];
-    __syncthreads();
-    if (row == 0 && c < C) {
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int t = 0; t < 9; ++t)   // part layout [chunk][c][tap] = the weight's own [C][3][3] layout per chunk
-        part[((size_t)chunk * C + c) * 9 + t] = (red[0][t][cl] + red[1][t][cl]) + (red[2][t][cl] + red[3][t][cl]);
+    for (int i = 0; i < V; ++i) red[row][t][V * cl + i] = acc[t][i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 9 * 64; e += 256) {   // part layout [chunk][c][tap] = the weight's own [C][3][3] layout per chunk
+    const int cc = e / 9, t = e - cc * 9, co = blockIdx.y * 64 + cc;
+    if (co < C) {
+      float v = 0.0f;
+#pragma unroll
+      for (int rr = 0; rr < ROWS; ++rr) v += red[rr][t][cc];
+      part[((size_t)chunk * C + co) * 9 + t] = v;
     }
   }
 }
@@ -667,8 +683,14 @@ extern "C" int sr_dwconv3x3_bwd_nhwc(const float* grad_out, int64_t g_sb, int g_
     if (workspace_bytes < sr_dwconv3x3_bwd_workspace_bytes(B, Ho, Wo, C)) return SR_ERR_WORKSPACE_TOO_SMALL;
     const int64_t npix = (int64_t)B * Ho * Wo;
     const int cp = sr_tr_chunk_pix(npix), chunks = (int)((npix + cp - 1) / cp);
-    hipLaunchKernelGGL(sr_dw_wgrad_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, stream, grad_out, g_sb, g_sp, x, x_sb, x_sp,
-                       (float*)workspace, B, H, W, Ho, Wo, C, stride, pad_top, pad_left, cp);
+    const bool vec4 = (C % 4 == 0) && (g_sp % 4 == 0) && (g_sb % 4 == 0) && (x_sp % 4 == 0) && (x_sb % 4 == 0) &&
+                      (((uintptr_t)grad_out | (uintptr_t)x) & 15) == 0;
+    if (vec4)
+      hipLaunchKernelGGL(sr_dw_wgrad_kernel<4>, dim3(chunks, (C + 63) / 64), dim3(256), 0, stream, grad_out, g_sb, g_sp, x, x_sb,
+                         x_sp, (float*)workspace, B, H, W, Ho, Wo, C, stride, pad_top, pad_left, cp);
+    else
+      hipLaunchKernelGGL(sr_dw_wgrad_kernel<1>, dim3(chunks, (C + 63) / 64), dim3(256), 0, stream, grad_out, g_sb, g_sp, x, x_sb,
+                         x_sp, (float*)workspace, B, H, W, Ho, Wo, C, stride, pad_top, pad_left, cp);
     hipLaunchKernelGGL(sr_colreduce_finish_kernel, dim3((C * 9 + 15) / 16), dim3(256), 0, stream, (const float*)workspace,
                        chunks, C * 9, 1.0f, d_weight);
   }
