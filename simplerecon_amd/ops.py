@@ -583,7 +583,7 @@ def conv1x1_stats(x, conv: nn.Conv2d, eps=1e-5):
         return out, stats
     lib = _lib.lib()
     ws = _workspace(x.device, "c1s", lib.sr_conv1x1_stats_workspace_bytes(b, h, w, co))
-    weight = conv.weight.detach().reshape(co, ci)
+    weight = conv.weight.detach().reshape(co, ci).contiguous()   # [128][64] rows, whatever the module's memory format
     bias = conv.bias.detach() if conv.bias is not None else None
     isb, isp = _strides(x)
     osb, osp = _strides(out)
