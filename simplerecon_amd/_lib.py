@@ -2,6 +2,7 @@
 
 There is NO fallback: if the library is missing, was built for another architecture, or
 the tensors are not fp32 device tensors, the call fails loudly."""
+import contextlib
 import ctypes as C
 import os
 
@@ -176,16 +177,46 @@ def require_device_f32(name, t, allow_none=False):
 
 
 def ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    """Device address of a tensor for a `void*` / `float*` argument (a plain int: ctypes converts it; None = NULL)."""
+    return t.data_ptr() if t is not None else None
 
 
 def stream_ptr(device=None):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """torch's current HIP stream on `device` as the `void* stream` of the C ABI (the raw handle: no Stream object)."""
+    idx = -1 if device is None or device.index is None else device.index
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+
+
+def stream_id(device=None):
+    """The same handle as a plain int (dictionary keys of per-stream caches)."""
+    return stream_ptr(device).value or 0
+
+
+_CUDA_AVAILABLE = None
+
+
+def cuda_available():
+    """torch.cuda.is_available(), asked once (it re-reads the environment on every call: ~1 us on the launch path)."""
+    global _CUDA_AVAILABLE
+    if _CUDA_AVAILABLE is None:
+        _CUDA_AVAILABLE = torch.cuda.is_available()
+    return _CUDA_AVAILABLE
 
 
 def capturing():
     """True while torch's current stream is being captured into a HIP graph (False on a machine without a GPU)."""
-    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    return cuda_available() and torch.cuda.is_current_stream_capturing()
+
+
+_NULL_CONTEXT = contextlib.nullcontext()
+
+
+def on_device(device):
+    """Context that makes `device` the current HIP device around a launch -- nothing to do when it already is (the
+    single-GPU-per-process case: one process per GPU is the deployment model)."""
+    if device.type != "cuda" or device.index is None or device.index == torch.cuda.current_device():
+        return _NULL_CONTEXT
+    return torch.cuda.device(device)
 
 
 def refuse_autograd(*tensors):

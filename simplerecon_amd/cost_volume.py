@@ -79,7 +79,7 @@ class _DotVolumeFunction(torch.autograd.Function):
         nscratch = lib.sr_dot_volume_bwd_scratch_bytes(b, k, c, h, w) if need_src else 0
         scratch = torch.empty(nscratch // 4, dtype=torch.float32, device=dev) if need_src else None
         st = _lib.stream_ptr(dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             # the forward's workspace may have been reused since: rebuild the geometry records + channels-last sources
             _lib.check(lib.sr_volume_prepare(_lib.ptr(src), _lib.ptr(Ks), _lib.ptr(T), None, b, k, c, h, w, _lib.ptr(ws),
                                              ws.numel(), st), "sr_volume_prepare")
@@ -129,7 +129,7 @@ class _MlpVolumeFunction(torch.autograd.Function):
             scratch = torch.empty(lib.sr_mlp_volume_bwd_scratch_bytes(b, k, c, h, w, hidden), dtype=torch.uint8,
                                   device=dev)
             st = _lib.stream_ptr(dev)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 _lib.check(lib.sr_volume_prepare(_lib.ptr(src), _lib.ptr(Ks), _lib.ptr(T), _lib.ptr(Tp), b, k, c, h, w,
                                                  _lib.ptr(ws), ws.numel(), st), "sr_volume_prepare")
                 rc = lib.sr_mlp_volume_bwd(_lib.ptr(g), g.stride(0), g.stride(1), g.stride(3), _lib.ptr(cur),
@@ -229,7 +229,7 @@ class CostVolumeManager(nn.Module):
             return torch.empty(nbytes, dtype=torch.uint8, device=device)
         if self._workspace is None:
             self._workspace = {}
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, _lib.stream_id(device))
         ws = self._workspace.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -277,7 +277,7 @@ class CostVolumeManager(nn.Module):
         nws = lib.sr_volume_workspace_bytes(b, k, c, h, w)
         ws = self._get_workspace(nws, dev)
         sb, sd, sp = self._volume_strides(vol)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.sr_dot_volume_fwd(
                 _lib.ptr(cur), _lib.ptr(src), _lib.ptr(Ks), _lib.ptr(T), _lib.ptr(invK), _lib.ptr(planes),
                 *planes.stride(), b, k, c, h, w, self.num_depth_bins, _lib.ptr(vol), sb, sd, sp,
@@ -304,7 +304,7 @@ class CostVolumeManager(nn.Module):
             return world, depths, warped, mask, pix
         lib = _lib.lib()
         ws = self._get_workspace(lib.sr_volume_workspace_bytes(b, k, c, h, w), dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.sr_warp_features_fwd(
                 _lib.ptr(src_feats.contiguous()), _lib.ptr(src_Ks.contiguous()), _lib.ptr(src_extrinsics.contiguous()),
                 _lib.ptr(cur_invK.contiguous()), _lib.ptr(planes), *planes.stride(), b, k, c, h, w, dp,
@@ -420,7 +420,7 @@ class FeatureVolumeManager(CostVolumeManager):
         nws = lib.sr_mlp_volume_workspace_bytes(b, k, c, h, w, hidden)
         ws = self._get_workspace(nws, dev)
         sb, sd, sp = self._volume_strides(vol)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.sr_mlp_volume_fwd(
                 _lib.ptr(cur), _lib.ptr(src), _lib.ptr(Ks), _lib.ptr(T), _lib.ptr(Tp), _lib.ptr(invK),
                 _lib.ptr(planes), *planes.stride(), *[_lib.ptr(t) for t in params], hidden,

@@ -39,7 +39,7 @@ class _Backproject(torch.autograd.Function):
     def forward(ctx, depth, invK, height, width):
         b = depth.shape[0]
         out = torch.empty((b, 4, height * width), dtype=torch.float32, device=depth.device)
-        with torch.cuda.device(depth.device):
+        with _lib.on_device(depth.device):
             rc = _lib.lib().sr_backproject_fwd(_lib.ptr(depth), _lib.ptr(invK), _lib.ptr(out), b, height, width,
                                                _lib.stream_ptr(depth.device))
         _lib.check(rc, "sr_backproject_fwd")
@@ -53,7 +53,7 @@ class _Backproject(torch.autograd.Function):
         g = g.contiguous()
         h, w = ctx.hw
         d_depth = torch.empty(ctx.depth_shape, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             rc = _lib.lib().sr_backproject_bwd(_lib.ptr(g), _lib.ptr(invK), _lib.ptr(d_depth), g.shape[0], h, w,
                                                _lib.stream_ptr(g.device))
         _lib.check(rc, "sr_backproject_bwd")
@@ -67,7 +67,7 @@ class _Project(torch.autograd.Function):
     def forward(ctx, pts, K, T, eps):
         b, _, n = pts.shape
         out = torch.empty((b, 3, n), dtype=torch.float32, device=pts.device)
-        with torch.cuda.device(pts.device):
+        with _lib.on_device(pts.device):
             rc = _lib.lib().sr_project3d_fwd(_lib.ptr(pts), _lib.ptr(K), _lib.ptr(T), _lib.ptr(out), b, n, C.c_float(eps),
                                              _lib.stream_ptr(pts.device))
         _lib.check(rc, "sr_project3d_fwd")
@@ -81,7 +81,7 @@ class _Project(torch.autograd.Function):
         g = g.contiguous()
         b, _, n = pts.shape
         d_pts = torch.empty_like(pts)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             rc = _lib.lib().sr_project3d_bwd(_lib.ptr(g), _lib.ptr(pts), _lib.ptr(K), _lib.ptr(T), _lib.ptr(d_pts), b, n,
                                              C.c_float(ctx.eps), _lib.stream_ptr(g.device))
         _lib.check(rc, "sr_project3d_bwd")
@@ -143,7 +143,7 @@ def pose_distance(pose_b44):
     T = _f32c("pose_b44", pose_b44)
     n = T.shape[0]
     out = torch.empty((n, 3), dtype=torch.float32, device=T.device)
-    with torch.cuda.device(T.device):
+    with _lib.on_device(T.device):
         rc = _lib.lib().sr_pose_distance_fwd(_lib.ptr(T), _lib.ptr(out), n, _lib.stream_ptr(T.device))
     _lib.check(rc, "sr_pose_distance_fwd")
     return out[:, 0], out[:, 1], out[:, 2]
@@ -158,7 +158,7 @@ def get_camera_rays(world_T_cam_b44, world_points_b3N, in_camera_frame, cam_T_wo
     if three != 3 or tuple(T.shape) != (b, 4, 4):
         raise ValueError("expected points [B,3,N] and a [B,4,4] pose")
     out = torch.empty_like(pts)
-    with torch.cuda.device(pts.device):
+    with _lib.on_device(pts.device):
         rc = _lib.lib().sr_camera_rays_fwd(_lib.ptr(pts), _lib.ptr(T), _lib.ptr(out), b, n, int(bool(in_camera_frame)),
                                            _lib.stream_ptr(pts.device))
     _lib.check(rc, "sr_camera_rays_fwd")

@@ -158,8 +158,7 @@ class EfficientNetV2SFeatures(nn.Module):
 
     def _train_path(self, image):
         from . import autograd_ops
-        return autograd_ops.grad_wanted([image], self) or any(
-            m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        return autograd_ops.grad_wanted([image], self) or autograd_ops.any_batchnorm_training(self)
 
     def forward(self, image: torch.Tensor) -> List[torch.Tensor]:
         if self._train_path(image):

@@ -312,8 +312,7 @@ class ResnetMatchingEncoder(nn.Module):
         """Training / differentiable path: autograd is recording and something wants a gradient, or a BatchNorm layer is
         in training mode (batch statistics cannot be folded into the conv weights)."""
         from . import autograd_ops
-        return autograd_ops.grad_wanted(list(tensors), self) or any(
-            m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        return autograd_ops.grad_wanted(list(tensors), self) or autograd_ops.any_batchnorm_training(self)
 
     def _forward_train(self, image):
         """The reference's nn.Sequential (networks.py:176-201) operator by operator on the differentiable HIP operators

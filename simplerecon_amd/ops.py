@@ -26,7 +26,7 @@ _PACK_EVENTS = {}
 
 
 def _packed_here(mod, tag, device):
-    if device.type != "cuda" or not torch.cuda.is_available():
+    if device.type != "cuda" or not _lib.cuda_available():
         return
     st = torch.cuda.current_stream(device)
     if _lib.capturing():
@@ -113,10 +113,20 @@ def _strides(t):
 
 
 def _state_key(conv, bn):
-    ts = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
-    if bn is not None:
-        ts += [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
-    return tuple((t._version, t.data_ptr()) for t in ts)
+    # (version, address) of every tensor the packed weight is derived from; read through the modules' own dictionaries
+    # (nn.Module.__getattr__ is a slow path and this runs once per launch)
+    p = conv._parameters
+    w, b = p["weight"], p.get("bias")
+    if bn is None:
+        if b is None:
+            return (w._version, w.data_ptr())
+        return (w._version, w.data_ptr(), b._version, b.data_ptr())
+    ts = [w] if b is None else [w, b]
+    bufs, bp = bn._buffers, bn._parameters
+    ts += [bufs["running_mean"], bufs["running_var"]]
+    if bn.affine:
+        ts += [bp["weight"], bp["bias"]]
+    return tuple((t._version, t.data_ptr()) if t is not None else None for t in ts)
 
 
 def bn_affine(bn):
@@ -154,18 +164,18 @@ def _check_conv(conv):
 
 def packed_weight(conv: nn.Conv2d, bn=None):
     """(packed weight, bias) for the direct kernel; cached until a parameter changes."""
-    _lib.require_device_f32("conv weight", conv.weight)
-    _check_conv(conv)
     key = _state_key(conv, bn)
     hit = _PACKED.get(conv)
     if hit is not None and hit[0] == key:
-        _await_packed(conv, "direct", conv.weight.device)
+        _await_packed(conv, "direct", hit[1].device)
         return hit[1], hit[2]
+    _lib.require_device_f32("conv weight", conv.weight)
+    _check_conv(conv)
     lib = _lib.lib()
     w, bias = _effective_weight(conv, bn)
     co, ci, k, _ = w.shape
     packed = torch.empty(lib.sr_conv_packed_weight_floats(co, ci, k), dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _lib.on_device(w.device):
         rc = lib.sr_conv_pack_weights(_lib.ptr(w), co, ci, k, _lib.ptr(packed), _lib.stream_ptr(w.device))
     _lib.check(rc, "sr_conv_pack_weights")
     _packed_here(conv, "direct", w.device)
@@ -219,13 +229,13 @@ def linear(x, lin: nn.Linear, leaky=None):
         _await_packed(lin, "linear", w.device)
     else:
         wp = torch.empty(lib.sr_conv_packed_weight_floats(cout, cin, 1), dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
+        with _lib.on_device(w.device):
             _lib.check(lib.sr_conv_pack_weights(_lib.ptr(w.detach().contiguous()), cout, cin, 1, _lib.ptr(wp),
                                                 _lib.stream_ptr(w.device)), "sr_conv_pack_weights")
         _packed_here(lin, "linear", w.device)
         _PACKED_LIN[lin] = (w._version, w.data_ptr(), wp)
     bias = lin.bias.detach() if lin.bias is not None else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x2), m * cin, cin, _lib.ptr(wp), _lib.ptr(bias), None, 0, 0,
                                     _lib.ptr(out), m * cout, cout, 1, 1, m, cin, cout, 1, 1,
                                     C.c_float(-1.0 if leaky is None else float(leaky)), _lib.stream_ptr(x.device))
@@ -238,22 +248,34 @@ _PACKED_WINO = weakref.WeakKeyDictionary()  # nn.Conv2d -> (weight version, data
 
 def packed_wino_weight(conv: nn.Conv2d, bn=None):
     """(Winograd-packed weight U = G g G^T, bias); cached until a parameter changes."""
-    _check_conv(conv)
     key = _state_key(conv, bn)
     hit = _PACKED_WINO.get(conv)
     if hit is not None and hit[0] == key:
-        _await_packed(conv, "wino", conv.weight.device)
+        _await_packed(conv, "wino", hit[1].device)
         return hit[1], hit[2]
+    _check_conv(conv)
     lib = _lib.lib()
     w, bias = _effective_weight(conv, bn)
     co, ci = w.shape[:2]
     packed = torch.empty(lib.sr_wino_packed_weight_floats(co, ci), dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _lib.on_device(w.device):
         rc = lib.sr_wino_pack_weights(_lib.ptr(w), co, ci, _lib.ptr(packed), _lib.stream_ptr(w.device))
     _lib.check(rc, "sr_wino_pack_weights")
     _packed_here(conv, "wino", w.device)
     _PACKED_WINO[conv] = (key, packed, bias)
     return packed, bias
+
+
+# Pure functions of the layer shape inside the C library (launch-plan choices): asked once per shape, not once per launch.
+_SHAPE_QUERIES = {}
+
+
+def _shape_query(lib, name, *shape):
+    key = (name, shape)
+    v = _SHAPE_QUERIES.get(key)
+    if v is None:
+        v = _SHAPE_QUERIES[key] = getattr(lib, name)(*shape)
+    return v
 
 
 def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act=None, tf_same=False, library_gemm=False):
@@ -285,7 +307,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
     padded = pads != (k // 2,) * 4
     if padded and replicate:
         raise _lib.HipLibraryError("explicit padding is implemented for zero padding only")
-    use_wino = (not replicate) and (not padded) and bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, s))
+    use_wino = (not replicate) and (not padded) and bool(_shape_query(lib, "sr_conv_prefers_wino", b, h, w, ci, co, k, s))
     if residual is not None:
         residual = as_nhwc(residual, "residual")
         if tuple(residual.shape) != (b, co, ho, wo):
@@ -316,7 +338,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
         if gact >= 0 and dense:
             w2d, gbias = gemm_weight(conv, bn)
             ws = _workspace(x.device, "gemm1x1", lib.sr_gemm1x1_workspace_bytes())
-            with torch.cuda.device(x.device):
+            with _lib.on_device(x.device):
                 if prof is not None:
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ev0.record()
@@ -333,7 +355,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 _lib.check(rc, "sr_gemm1x1_nhwc_fwd")
     wp, bias = packed_wino_weight(conv, bn) if use_wino else packed_weight(conv, bn)
     slope = C.c_float(_act_code(leaky, act))
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -342,7 +364,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                                                rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, *pads, slope,
                                                _lib.stream_ptr(x.device))
         elif use_wino:
-            nbytes = lib.sr_wino_splitk_workspace_bytes(b, h, w, ci, co)   # 0 unless the launch plan splits K
+            nbytes = _shape_query(lib, "sr_wino_splitk_workspace_bytes", b, h, w, ci, co)   # 0 unless the plan splits K
             ws = _workspace(x.device, "wino_splitk", nbytes) if nbytes else None
             rc = lib.sr_conv3x3_wino_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
                                                      _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
@@ -352,7 +374,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                                                   _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
                                                   co, k, s, slope, _lib.stream_ptr(x.device))
         else:
-            nbytes = lib.sr_conv_splitk_workspace_bytes(b, h, w, ci, co, k, s)   # 0 unless the launch plan may split K
+            nbytes = _shape_query(lib, "sr_conv_splitk_workspace_bytes", b, h, w, ci, co, k, s)   # 0 unless it may split K
             ws = _workspace(x.device, "conv_splitk", nbytes) if nbytes else None
             rc = lib.sr_conv2d_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
                                                rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope,
@@ -402,7 +424,7 @@ def upsample2x(x, out=None):
         return out
     isb, isp = _strides(x)
     osb, osp = _strides(out)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.lib().sr_upsample2x_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(out), osb, osp, b, h, w, c,
                                                _lib.stream_ptr(x.device))
     _lib.check(rc, "sr_upsample2x_nhwc_fwd")
@@ -415,7 +437,7 @@ def exp(x):
     if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
         x = x.contiguous()
     out = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.lib().sr_exp_fwd(_lib.ptr(x), _lib.ptr(out), x.numel(), _lib.stream_ptr(x.device))
     _lib.check(rc, "sr_exp_fwd")
     return out
@@ -440,7 +462,7 @@ def _workspace(device, tag, nbytes):
         # a HIP graph bakes the pointer in: give it memory from its own pool, never a cached buffer that a later eager
         # call may grow and drop
         return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-    key = (device, tag, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, tag, _lib.stream_id(device))
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
@@ -466,7 +488,7 @@ def stem7x7(image, conv: nn.Conv2d, bn=None, leaky=0.0, out=None):
     hit = _PACKED_STEM.get(conv)
     if hit is None or hit[0] != key:
         wp = torch.empty(lib.sr_stem_packed_weight_floats(64), dtype=torch.float32, device=conv.weight.device)
-        with torch.cuda.device(conv.weight.device):
+        with _lib.on_device(conv.weight.device):
             _lib.check(lib.sr_stem_pack_weights(_lib.ptr(conv.weight.detach().contiguous()), 64, _lib.ptr(wp),
                                                 _lib.stream_ptr(conv.weight.device)), "sr_stem_pack_weights")
         scale = shift = None
@@ -493,7 +515,7 @@ def stem7x7(image, conv: nn.Conv2d, bn=None, leaky=0.0, out=None):
     sb, sc, sy, sx = image.stride()
     osb, osp = _strides(out)
     prof = PROFILE
-    with torch.cuda.device(image.device):
+    with _lib.on_device(image.device):
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -520,7 +542,7 @@ def maxblurpool(x):
         return out
     isb, isp = _strides(x)
     osb, osp = _strides(out)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.lib().sr_maxblurpool_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(out), osb, osp, b, h, w, c,
                                                 _lib.stream_ptr(x.device))
     _lib.check(rc, "sr_maxblurpool_nhwc_fwd")
@@ -539,7 +561,7 @@ def instance_norm(x, eps=1e-5, leaky=None, inplace=False):
     ws = _workspace(x.device, "inorm", nbytes)
     isb, isp = _strides(x)
     osb, osp = _strides(out)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.sr_instance_norm_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(out), osb, osp, b, h, w, c,
                                            C.c_float(eps), C.c_float(-1.0 if leaky is None else float(leaky)),
                                            _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr(x.device))
@@ -560,7 +582,7 @@ def instance_norm_stats(x, eps=1e-5):
     lib = _lib.lib()
     ws = _workspace(x.device, "inorm", lib.sr_instance_norm_workspace_bytes(b, h, w, c))
     isb, isp = _strides(x)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.sr_instance_norm_stats_nhwc(_lib.ptr(x), isb, isp, b, h, w, c, C.c_float(eps), _lib.ptr(stats),
                                              _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr(x.device))
     _lib.check(rc, "sr_instance_norm_stats_nhwc")
@@ -588,7 +610,7 @@ def conv1x1_stats(x, conv: nn.Conv2d, eps=1e-5):
     isb, isp = _strides(x)
     osb, osp = _strides(out)
     prof = PROFILE
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -619,7 +641,7 @@ def conv3x3_c16(x, conv: nn.Conv2d, in_stats=None, in_leaky=None, leaky=None):
     hit = _PACKED_C16.get(conv)
     if hit is None or hit[0] != key:
         wp = torch.empty(lib.sr_conv3x3_c16_packed_weight_floats(co, ci), dtype=torch.float32, device=conv.weight.device)
-        with torch.cuda.device(conv.weight.device):
+        with _lib.on_device(conv.weight.device):
             _lib.check(lib.sr_conv3x3_c16_pack_weights(_lib.ptr(conv.weight.detach().contiguous()), co, ci, _lib.ptr(wp),
                                                        _lib.stream_ptr(conv.weight.device)), "sr_conv3x3_c16_pack_weights")
         hit = (key, wp, conv.bias.detach() if conv.bias is not None else None)
@@ -636,7 +658,7 @@ def conv3x3_c16(x, conv: nn.Conv2d, in_stats=None, in_leaky=None, leaky=None):
     isb, isp = _strides(x)
     osb, osp = _strides(out)
     prof = PROFILE
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -700,7 +722,7 @@ def dwconv3x3(x, conv: nn.Conv2d, bn=None, leaky=None, act=None, tf_same=False, 
     if b > 0:
         isb, isp = _strides(x)
         osb, osp = _strides(out)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = lib.sr_dwconv3x3_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(w9c), _lib.ptr(bias), _lib.ptr(out), osb,
                                            osp, _lib.ptr(pool), b, h, w, c, s, *pads,
                                            C.c_float(_act_code(leaky, act)), _lib.stream_ptr(x.device))
@@ -726,7 +748,7 @@ def se_gate(pool_partial, pixels, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2d
     b2 = conv_expand.bias.detach() if conv_expand.bias is not None else None
     for t in (w1, w2):
         _lib.require_device_f32("squeeze-excite weight", t)
-    with torch.cuda.device(gate.device):
+    with _lib.on_device(gate.device):
         rc = _lib.lib().sr_se_gate_fwd(_lib.ptr(pool_partial.contiguous()), bands, pixels, _lib.ptr(w1.contiguous()),
                                        _lib.ptr(b1), _lib.ptr(w2.contiguous()), _lib.ptr(b2), _lib.ptr(gate), b, c, rd,
                                        _lib.stream_ptr(gate.device))
@@ -756,7 +778,7 @@ def se_scale_(x, pool_partial, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2d, w
     b1 = conv_reduce.bias.detach() if conv_reduce.bias is not None else None
     b2 = conv_expand.bias.detach() if conv_expand.bias is not None else None
     sb, sp = _strides(x)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.lib().sr_se_scale_nhwc_fwd(_lib.ptr(pool_partial), pool_partial.shape[1], _lib.ptr(w1), _lib.ptr(b1),
                                              _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(hidden), _lib.ptr(x), sb, sp,
                                              _lib.ptr(x), sb, sp, _lib.ptr(gate), b, h, w, c, rd,
@@ -777,7 +799,7 @@ def scale_channels_(x, gate):
     if b == 0:
         return x
     sb, sp = _strides(x)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.lib().sr_scale_channels_nhwc_fwd(_lib.ptr(x), sb, sp, _lib.ptr(gate), _lib.ptr(x), sb, sp, b, h, w, c,
                                                    _lib.stream_ptr(x.device))
     _lib.check(rc, "sr_scale_channels_nhwc_fwd")
@@ -796,7 +818,7 @@ def add_(y, x):
         return y
     ysb, ysp = _strides(y)
     xsb, xsp = _strides(x)
-    with torch.cuda.device(y.device):
+    with _lib.on_device(y.device):
         rc = _lib.lib().sr_add_nhwc_fwd(_lib.ptr(y), ysb, ysp, _lib.ptr(x), xsb, xsp, _lib.ptr(y), ysb, ysp, b, h, w, c,
                                         _lib.stream_ptr(y.device))
     _lib.check(rc, "sr_add_nhwc_fwd")

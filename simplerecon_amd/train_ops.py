@@ -28,7 +28,7 @@ def _dense(t, name="tensor"):
 def _add_flat_(a, b):
     """a += b for two dense fp32 tensors of the same size (numel % 4 == 0), on the HIP add kernel."""
     n = a.numel()
-    with torch.cuda.device(a.device):
+    with _lib.on_device(a.device):
         rc = _lib.lib().sr_add_nhwc_fwd(_lib.ptr(a), n, 4, _lib.ptr(b), n, 4, _lib.ptr(a), n, 4, 1, 1, n // 4, 4,
                                         _lib.stream_ptr(a.device))
     _lib.check(rc, "sr_add_nhwc_fwd")
@@ -61,7 +61,7 @@ class _NormAct(torch.autograd.Function):
             nws = lib.sr_norm_workspace_bytes(b, h * w, c, int(per_image))
             ws = _workspace(dev, "norm", nws)
             st = _lib.stream_ptr(dev)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 if train_stats:
                     _lib.check(lib.sr_norm_stats_nhwc(_lib.ptr(x), xsb, xsp, b, h * w, c, int(per_image), _lib.ptr(mean),
                                                       _lib.ptr(var), _lib.ptr(ws), nws, st), "sr_norm_stats_nhwc")
@@ -99,7 +99,7 @@ class _NormAct(torch.autograd.Function):
         ws = _workspace(dev, "norm", nws)
         gd = gamma.detach().contiguous() if gamma is not None else None
         bd = beta.detach().contiguous() if beta is not None else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.sr_norm_act_bwd_nhwc(_lib.ptr(g), gsb, gsp, _lib.ptr(x), xsb, xsp, _lib.ptr(mean), _lib.ptr(var),
                                           C.c_float(eps), _lib.ptr(gd), _lib.ptr(bd), C.c_float(act), int(per_image),
                                           int(train_stats), _lib.ptr(dx), dsb, dsp, _lib.ptr(d_gamma), _lib.ptr(d_beta), b,
@@ -156,7 +156,7 @@ class _MaxBlurPool(torch.autograd.Function):
             return dx
         nws = lib.sr_maxblurpool_bwd_workspace_bytes(b, h, w, c)
         ws = _workspace(x.device, "maxblurpool_bwd", nws)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = lib.sr_maxblurpool_bwd_nhwc(_lib.ptr(g), *_strides(g), _lib.ptr(x), *_strides(x), _lib.ptr(dx),
                                              *_strides(dx), b, h, w, c, _lib.ptr(ws), nws, _lib.stream_ptr(x.device))
         _lib.check(rc, "sr_maxblurpool_bwd_nhwc")
@@ -175,7 +175,7 @@ class _ReplicatePad(torch.autograd.Function):
         b, c, h, w = x.shape
         y = empty_nhwc(b, c, h + 2 * pad, w + 2 * pad, x.device)
         if b > 0:
-            with torch.cuda.device(x.device):
+            with _lib.on_device(x.device):
                 rc = _lib.lib().sr_replicate_pad_nhwc_fwd(_lib.ptr(x), *_strides(x), _lib.ptr(y), b, h, w, c, pad,
                                                           _lib.stream_ptr(x.device))
             _lib.check(rc, "sr_replicate_pad_nhwc_fwd")
@@ -189,7 +189,7 @@ class _ReplicatePad(torch.autograd.Function):
         g = _dense(g)
         dx = empty_nhwc(b, c, h, w, g.device)
         if b > 0:
-            with torch.cuda.device(g.device):
+            with _lib.on_device(g.device):
                 rc = _lib.lib().sr_replicate_pad_nhwc_bwd(_lib.ptr(g), _lib.ptr(dx), b, h, w, c, ctx.pad,
                                                           _lib.stream_ptr(g.device))
             _lib.check(rc, "sr_replicate_pad_nhwc_bwd")
@@ -229,7 +229,7 @@ class _Stem7x7(torch.autograd.Function):
         # unfold a few images at a time: [n, Ho, Wo, 160] floats (49 MB per 640x480 image)
         per = max(1, min(b, (1 << 32) // max(ho * wo * kp * 4, 1)))
         acc = None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             for i0 in range(0, b, per):
                 n = min(per, b - i0)
                 col = torch.empty((n, ho, wo, kp), dtype=torch.float32, device=dev)
@@ -302,7 +302,7 @@ class _DwConv3x3(torch.autograd.Function):
         nws = lib.sr_dwconv3x3_bwd_workspace_bytes(b, ho, wo, c)
         ws = _workspace(dev, "dw_bwd", nws)
         wd = weight.detach().reshape(c, 9).contiguous()
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.sr_dwconv3x3_bwd_nhwc(_lib.ptr(g), *_strides(g), _lib.ptr(x), *_strides(x), _lib.ptr(wd), _lib.ptr(dx),
                                            _lib.ptr(dw), b, h, w, c, s, pads[0], pads[1], ho, wo, _lib.ptr(ws), nws,
                                            _lib.stream_ptr(dev))
@@ -337,7 +337,7 @@ class _SqueezeExcite(torch.autograd.Function):
             nws = lib.sr_norm_workspace_bytes(b, h * w, c, 1)
             ws = _workspace(dev, "norm", nws)
             st = _lib.stream_ptr(dev)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 _lib.check(lib.sr_rowsum_nhwc(_lib.ptr(x), *_strides(x), None, 0, 0, b, h * w, c, C.c_float(1.0 / (h * w)),
                                               _lib.ptr(pooled), _lib.ptr(ws), nws, st), "sr_rowsum_nhwc")
                 _lib.check(lib.sr_small_linear_fwd(_lib.ptr(pooled), _lib.ptr(w1d), _lib.ptr(b1.detach().contiguous()),
@@ -372,7 +372,7 @@ class _SqueezeExcite(torch.autograd.Function):
         nws = lib.sr_norm_workspace_bytes(b, h * w, c, 1)
         ws = _workspace(dev, "norm", nws)
         st = _lib.stream_ptr(dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.sr_rowsum_nhwc(_lib.ptr(x), *_strides(x), _lib.ptr(g), *_strides(g), b, h * w, c, C.c_float(1.0),
                                           _lib.ptr(dgate), _lib.ptr(ws), nws, st), "sr_rowsum_nhwc")
             _lib.check(lib.sr_small_linear_bwd(_lib.ptr(dgate), _lib.ptr(pre2), _lib.ptr(hid), _lib.ptr(w2d), _lib.ptr(dhid),
@@ -406,7 +406,7 @@ class _AddAct(torch.autograd.Function):
         out = torch.empty_like(a)
         pre = torch.empty_like(a) if act != ACT_NONE else None
         if a.numel() > 0:
-            with torch.cuda.device(a.device):
+            with _lib.on_device(a.device):
                 rc = _lib.lib().sr_add_act_fwd(_lib.ptr(a), _lib.ptr(b), _lib.ptr(pre), _lib.ptr(out), a.numel(), C.c_float(act),
                                                _lib.stream_ptr(a.device))
             _lib.check(rc, "sr_add_act_fwd")
@@ -424,7 +424,7 @@ class _AddAct(torch.autograd.Function):
         g = _dense(g)
         gz = torch.empty_like(pre)
         if pre.numel() > 0:
-            with torch.cuda.device(pre.device):
+            with _lib.on_device(pre.device):
                 rc = _lib.lib().sr_act_in_bwd(_lib.ptr(g), _lib.ptr(pre), _lib.ptr(gz), pre.numel(), C.c_float(ctx.act),
                                               _lib.stream_ptr(pre.device))
             _lib.check(rc, "sr_act_in_bwd")

@@ -48,6 +48,8 @@ def stub(monkeypatch):
         def __getattr__(self, name):
             return Fn(name)
 
+    from simplerecon_amd import ops
+    monkeypatch.setattr(ops, "_SHAPE_QUERIES", {})   # per-shape answers of the (stubbed) library are cached per process
     monkeypatch.setattr(_lib, "lib", lambda: Lib())
     monkeypatch.setattr(_lib, "require_device_f32", lambda *a, **k: None)
     monkeypatch.setattr(_lib, "stream_ptr", lambda dev=None: ctypes.c_void_p(0))
