@@ -164,3 +164,42 @@ def test_autocast_region_upcasts_half_features(stub):
     vol.sum().backward()
     assert cur.grad.dtype == torch.bfloat16 and src.grad.dtype == torch.bfloat16
     assert stub[-1] == "sr_dot_volume_bwd"
+
+
+def test_packed_weight_cache_key_follows_the_parameters():
+    """ops._state_key decides whether a cached packed weight is still valid: it must change when a parameter is updated in
+    place (optimizer step, load_state_dict), replaced by a new tensor (module.to(...), re-assignment), or when the folded
+    BatchNorm's statistics move -- and must not change otherwise."""
+    from torch import nn
+
+    from simplerecon_amd import ops
+    conv, bn = nn.Conv2d(8, 16, 3, padding=1), nn.BatchNorm2d(16)
+    k0, k0_bn = ops._state_key(conv, None), ops._state_key(conv, bn)
+    assert ops._state_key(conv, None) == k0 and ops._state_key(conv, bn) == k0_bn and k0 != k0_bn
+    with torch.no_grad():
+        conv.weight.mul_(2.0)                                   # in-place update: version bump
+    k1 = ops._state_key(conv, None)
+    assert k1 != k0
+    conv.load_state_dict({k: v.clone() for k, v in conv.state_dict().items()})   # copy_ into the same storage
+    k2 = ops._state_key(conv, None)
+    assert k2 != k1
+    conv.weight = nn.Parameter(conv.weight.detach().clone())    # a new tensor object
+    k3 = ops._state_key(conv, None)
+    assert k3 != k2
+    conv.bias = None
+    assert ops._state_key(conv, None) != k3 and len(ops._state_key(conv, None)) == 2
+    kb = ops._state_key(conv, bn)
+    bn.running_var.add_(1.0)
+    assert ops._state_key(conv, bn) != kb
+    plain = nn.BatchNorm2d(16, affine=False)
+    assert len(ops._state_key(conv, plain)) == 3               # weight + the two running statistics
+
+
+def test_per_shape_library_answers_are_asked_once(stub):
+    from simplerecon_amd import ops
+    lib = _lib.lib()
+    assert ops._shape_query(lib, "sr_conv_prefers_wino", 1, 8, 16, 16, 32, 3, 1) == 0
+    n = len(stub)
+    stub.prefer_wino = True     # the library's answer is a pure function of the shape: the cached one is returned
+    assert ops._shape_query(lib, "sr_conv_prefers_wino", 1, 8, 16, 16, 32, 3, 1) == 0 and len(stub) == n
+    assert ops._shape_query(lib, "sr_conv_prefers_wino", 2, 8, 16, 16, 32, 3, 1) == 1 and len(stub) == n + 1
