@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 GPU suite: smoke + full GPU tests + bench lines + rocprofv3 kernel stats + PMC passes.
-# usage: scripts/gpu_suite_r02.sh [tests|bench|prof|pmc ...]   (default: everything)
+# usage: scripts/gpu_suite_r03.sh [tests|bench|prof|pmc ...]   (default: everything)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; export TMPDIR=/tmp; O=$R/gpurun_out; mkdir -p $O
 WHAT=${@:-tests bench prof pmc}
