@@ -50,6 +50,65 @@ def _shared_gpu():
     return os.environ.get("SR_BENCH_SHARED_GPU", "0") == "1"
 
 
+def _cpu_list(spec):
+    """'0-15,128-143' -> [0..15, 128..143]"""
+    out = []
+    for part in spec.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def _gpu_numa_cpus(local_dev):
+    """The host cores of the NUMA node GPU `local_dev` hangs off: PCI bus id (torch) -> /sys/bus/pci/devices/<id>/
+    numa_node -> /sys/devices/system/node/node<N>/cpulist.  None when sysfs does not say (containers, one-node hosts)."""
+    try:
+        bus = torch.cuda.get_device_properties(local_dev).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(local_dev), "pci_domain_id", 0)
+        devid = getattr(torch.cuda.get_device_properties(local_dev), "pci_device_id", 0)
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{devid:02x}.0/numa_node"
+        with open(path) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            return _cpu_list(f.read())
+    except Exception:
+        return None
+
+
+def pin_rank(local_rank, local_world, local_dev, threads=None):
+    """One eager Python rank per GPU issues ~800 launches per step: keep each rank's launch thread on its GPU's NUMA
+    node and away from the other ranks' cores.  The rank takes the `local_rank`-th of `local_world` equal slices of the
+    cores it may use (its GPU's NUMA node when sysfs knows it and shares cores with the allowed set, else everything
+    the process is allowed); torch's intra-op pool is cut to the slice too (SR_BENCH_PIN=0 turns all of it off).
+    Returns what it did, for the bench line."""
+    if os.environ.get("SR_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return {"pinned": False}
+    allowed = sorted(os.sched_getaffinity(0))
+    numa = _gpu_numa_cpus(local_dev)
+    pool = sorted(set(allowed) & set(numa)) if numa else []
+    by_numa = bool(pool)
+    if by_numa:
+        # ranks on the same NUMA node split that node's cores
+        peers = [r for r in range(local_world) if (_gpu_numa_cpus(r) or []) == numa] if local_world > 1 else [local_rank]
+        idx, n = (peers.index(local_rank), len(peers)) if local_rank in peers else (0, 1)
+    else:
+        pool, idx, n = allowed, local_rank, max(local_world, 1)
+    per = max(1, len(pool) // n)
+    mine = pool[idx * per:(idx + 1) * per] or pool
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return {"pinned": False}
+    nthreads = threads or min(len(mine), 16)
+    torch.set_num_threads(max(1, nthreads))
+    return {"pinned": True, "cores": len(mine), "first_core": mine[0], "by_numa_node": by_numa,
+            "torch_threads": torch.get_num_threads()}
+
+
 def _require_gpus(n):
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if have == 0:
@@ -68,6 +127,9 @@ def main():
     ap.add_argument("--workload", default=None, help="default: the BASELINE.json metric configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the process group and run the result gather / all-reduce / barrier collectives even "
+                         "with one rank (exercises the RCCL path on a 1-GPU box)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -88,19 +150,25 @@ def main():
     local_dev = local_rank % have if shared else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if shared:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    pin = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), local_dev) if collective else {"pinned": False}
 
     import bench_workloads
     name = args.workload or bench_workloads.DEFAULT
     wl = bench_workloads.WORKLOADS[name](dev, rank)
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,7 +179,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             wl.step(i)
-        wl.finish(world)  # result gather to rank 0 (RCCL) -- part of the job
+        wl.finish(world, force_collective=args.force_collective)  # result gather to rank 0 (RCCL) -- part of the job
         barrier()
         elapsed = time.perf_counter() - t0
     dump = os.environ.get("SR_BENCH_DUMP")   # tests: the gathered result of the job, as rank 0 holds it
@@ -119,7 +187,7 @@ def main():
         import numpy as np
         np.save(dump, wl.gathered.cpu().numpy())
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else dev)
-    if world > 1:
+    if collective:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -139,6 +207,9 @@ def main():
         "data": "synthetic",
         "config": wl.config(world),
     }
+    if collective:
+        out["config"]["backend"] = dist.get_backend()
+        out["config"]["rank_pinning"] = pin
     if shared:
         out["config"]["parallelism"] += " -- SR_BENCH_SHARED_GPU test mode: ranks share a device over gloo, not a measurement"
     if rank == 0:
@@ -157,7 +228,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

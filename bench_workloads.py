@@ -136,9 +136,9 @@ class DotCfg2:
     def step(self, i=0):
         self.last = self.mgr(**self.inp)
 
-    def finish(self, world):
+    def finish(self, world, force_collective=False):
         # the job's only exchange: this step's results to rank 0 (keyframe i lives on rank i mod world)
-        sharding.gather_results(self.last[1], world * self.last[1].shape[0], dst=0)
+        sharding.gather_results(self.last[1], world * self.last[1].shape[0], dst=0, force_collective=force_collective)
 
     def config(self, world):
         return {"workload": f"{self.name}: CostVolumeManager (dot-product plane sweep), batch {self.B}/GPU, "
@@ -301,11 +301,11 @@ class HeroCfg3:
         else:
             self.last = self._eager(*args)
 
-    def finish(self, world):
+    def finish(self, world, force_collective=False):
         # the job's only exchange: the depth maps of the last batch to rank 0 (keyframe i lives on rank i mod world);
         # hero_cfg4_stream gathers EVERY depth map of the run instead
         depth = self.last["depth_pred_s0_b1hw"]
-        sharding.gather_results(depth, world * depth.shape[0], dst=0)
+        sharding.gather_results(depth, world * depth.shape[0], dst=0, force_collective=force_collective)
 
     def config(self, world):
         kind = "FeatureVolumeManager (metadata-MLP matching)" if self.feature_volume_type == "mlp_feature_volume" \
@@ -604,9 +604,9 @@ class HeroCfg4Stream(HeroCfg3):
         self.last = out
         self.results.append(out["depth_pred_s0_b1hw"])
 
-    def finish(self, world):
+    def finish(self, world, force_collective=False):
         local = torch.cat(self.results, 0)
-        self.gathered = sharding.gather_results(local, world * local.shape[0], dst=0)
+        self.gathered = sharding.gather_results(local, world * local.shape[0], dst=0, force_collective=force_collective)
 
     def config(self, world):
         c = super().config(world)
@@ -643,9 +643,9 @@ class HeroVolumeOnly:
     def step(self, i=0):
         self.last = self.mgr(return_mask=True, **self.inp)
 
-    def finish(self, world):
+    def finish(self, world, force_collective=False):
         # the job's only exchange: this step's results to rank 0 (keyframe i lives on rank i mod world)
-        sharding.gather_results(self.last[1], world * self.last[1].shape[0], dst=0)
+        sharding.gather_results(self.last[1], world * self.last[1].shape[0], dst=0, force_collective=force_collective)
 
     def config(self, world):
         return {"workload": f"{self.name}: FeatureVolumeManager (metadata-MLP sweep) only, batch {self.B}/GPU, {self.K} "
@@ -704,7 +704,7 @@ class TsdfFuse:
         self.step_i += 1
         self.fuser.tsdf_fuser_pred.integrate_depth(self.depth, self._poses(self.step_i), self.K)
 
-    def finish(self, world):
+    def finish(self, world, force_collective=False):
         pass  # each rank fuses its own scene (scenes are independent; a volume is never split across GPUs)
 
     def config(self, world):

@@ -58,11 +58,13 @@ def _stash(ctx, *tensors):
         narrow = half and isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.dim() == 4 and \
             not isinstance(t, nn.Parameter) and t.numel() >= 4096
         if narrow:
-            h = getattr(t, "_sr_narrow", None)
-            if h is None or h.dtype != dt:
-                h = t.detach().to(dt)
-                t._sr_narrow = h
-            keep.append(h)
+            # the 16-bit copy is shared between the operators that save this tensor; it is valid only for the very
+            # contents it was made from (an input refreshed in place with copy_ must be narrowed again)
+            rec = getattr(t, "_sr_narrow", None)
+            if rec is None or rec[0] != t._version or rec[1] != t.data_ptr() or rec[2].dtype != dt:
+                rec = (t._version, t.data_ptr(), t.detach().to(dt))
+                t._sr_narrow = rec
+            keep.append(rec[2])
         else:
             keep.append(t)
         flags.append(narrow)
@@ -97,11 +99,15 @@ def any_batchnorm_training(module):
     """True if a BatchNorm2d layer of `module` is in training mode (batch statistics cannot be folded into the conv
     weights).  The layer list is gathered once per module object -- walking `modules()` costs ~1 ms per forward on the
     EfficientNetV2-S pyramid."""
-    bns = module.__dict__.get("_sr_bn_layers")
-    if bns is None:
-        bns = [m for m in module.modules() if isinstance(m, nn.BatchNorm2d)]
-        module.__dict__["_sr_bn_layers"] = bns
-    for m in bns:
+    rec = module.__dict__.get("_sr_bn_layers")
+    # the cached list is valid for one module tree and one train / eval state: a flip of module.training (model.train() /
+    # .eval() walk the CURRENT tree) or a different number of registered submodules rebuilds it, so layers swapped in
+    # later (SyncBatchNorm conversion, BatchNorm fusion) are seen
+    key = (module.training, len(module._modules))
+    if rec is None or rec[0] != key:
+        rec = (key, [m for m in module.modules() if isinstance(m, nn.BatchNorm2d)])
+        module.__dict__["_sr_bn_layers"] = rec
+    for m in rec[1]:
         if m.training:
             return True
     return False
@@ -110,8 +116,11 @@ def any_batchnorm_training(module):
 def _dense_nhwc(t):
     """Channels-last, dense (pixel stride = C): what the elementwise backward kernels and the wgrad staging expect."""
     t = as_nhwc(t, "gradient")
-    if t.stride(1) != 1 or t.stride(3) != t.shape[1] or t.stride(2) != t.shape[3] * t.shape[1]:
+    c, h, w = t.shape[1], t.shape[2], t.shape[3]
+    if t.stride(1) != 1 or t.stride(3) != c or t.stride(2) != w * c or (t.shape[0] > 1 and t.stride(0) != h * w * c):
         t = t.contiguous(memory_format=torch.channels_last)
+        if t.shape[0] > 1 and t.stride(0) != h * w * c:   # (contiguous() keeps a batch-strided view whose images are dense)
+            t = t.clone(memory_format=torch.channels_last)
     return t
 
 

@@ -21,11 +21,18 @@ def batches(indices: List[int], batch_size: int) -> List[List[int]]:
     return [indices[i:i + batch_size] for i in range(0, len(indices), batch_size)]
 
 
-def gather_results(local: torch.Tensor, n_items: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+def gather_results(local: torch.Tensor, n_items: int, dst: int = 0, group=None,
+                   force_collective: bool = False) -> Optional[torch.Tensor]:
     """`local[j]` is the result of keyframe shard_indices(n_items, rank, world)[j].  Returns, on
     rank `dst`, the [n_items, ...] tensor in keyframe order; None elsewhere.  One collective:
-    shards are padded to the longest shard so a plain gather works with ragged counts."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    shards are padded to the longest shard so a plain gather works with ragged counts.
+    `force_collective`: run the gather even in a world of one (the early return otherwise hides the RCCL
+    device-buffer path from every 1-GPU test box)."""
+    if not dist.is_initialized():
+        if force_collective:
+            raise RuntimeError("gather_results(force_collective=True) needs an initialised process group")
+        return local
+    if dist.get_world_size(group) == 1 and not force_collective:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = (n_items + world - 1) // world

@@ -222,17 +222,20 @@ class _Stem7x7(torch.autograd.Function):
         g = _dense(g)
         ho, wo = g.shape[2], g.shape[3]
         kp = 160   # 147 taps padded to a multiple of 32
-        d_w = torch.zeros((64, 3, 7, 7), dtype=torch.float32, device=dev)
-        if b == 0 or not ctx.needs_input_grad[1]:
-            return None, d_w if ctx.needs_input_grad[1] else None, None
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        if b == 0:
+            return None, torch.zeros((64, 3, 7, 7), dtype=torch.float32, device=dev), None
         st = _lib.stream_ptr(dev)
-        # unfold a few images at a time: [n, Ho, Wo, 160] floats (49 MB per 640x480 image)
-        per = max(1, min(b, (1 << 32) // max(ho * wo * kp * 4, 1)))
+        # unfold a few images at a time into ONE reused buffer of <= 256 MB: [n, Ho, Wo, 160] floats (49 MB per 640x480
+        # image); the weight-gradient partials of the chunks are added in chunk order
+        per = max(1, min(b, (1 << 28) // max(ho * wo * kp * 4, 1)))
         acc = None
+        col_buf = torch.empty((per, ho, wo, kp), dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             for i0 in range(0, b, per):
                 n = min(per, b - i0)
-                col = torch.empty((n, ho, wo, kp), dtype=torch.float32, device=dev)
+                col = col_buf[:n]
                 img = image[i0:i0 + n]
                 sb, sc, sy, sx = img.stride()
                 _lib.check(lib.sr_im2col7x7s2_nhwc(_lib.ptr(img), sb, sc, sy, sx, _lib.ptr(col), n, h, w, kp, st),
@@ -252,6 +255,10 @@ class _Stem7x7(torch.autograd.Function):
 def stem7x7(image, conv: nn.Conv2d):
     if conv.bias is not None:
         raise _lib.HipLibraryError("the HIP stem trains the bias-free ResNet conv1 only")
+    if torch.is_grad_enabled() and image.requires_grad:
+        # like geometry._data: a gradient this path does not compute must not come back silently as None
+        raise _lib.HipLibraryError("the HIP matching-encoder stem has no gradient w.r.t. the image (the reference trains "
+                                   "on images as data); detach() the image or use the torch module")
     return _Stem7x7.apply(image, conv.weight, conv)
 
 

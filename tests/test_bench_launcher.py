@@ -46,3 +46,29 @@ def test_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_rank_pinning_gives_local_ranks_disjoint_core_slices():
+    """bench.pin_rank: the local ranks of a node take disjoint, equal slices of the allowed cores (no NUMA information
+    without a GPU: the slice is cut from everything the process may use) and torch's intra-op pool shrinks with it."""
+    sys.path.insert(0, ROOT)
+    code = ("import sys, os, json; sys.path.insert(0, %r); import bench; "
+            "r = bench.pin_rank(int(sys.argv[1]), 4, 0); r['set'] = sorted(os.sched_getaffinity(0)); print(json.dumps(r))" % ROOT)
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        import pytest
+        pytest.skip("needs >= 4 cores")
+    sets = []
+    for rank in range(4):
+        r = subprocess.run([sys.executable, "-c", code, str(rank)], env=_clean_env(), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["pinned"] and d["cores"] == len(allowed) // 4 == len(d["set"]) and 1 <= d["torch_threads"] <= 16
+        sets.append(set(d["set"]))
+    assert all(sets[i].isdisjoint(sets[j]) for i in range(4) for j in range(i))
+    assert bench_cpu_list() == [0, 1, 2, 3, 8, 10, 11]
+
+
+def bench_cpu_list():
+    import bench
+    return bench._cpu_list("0-3,8,10-11")
