@@ -24,6 +24,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SR_WINO_PIPE 1   // 1: next slab stored mid-slab, barrier after step 5, its first transform half under steps 6-7
 #endif
 
+#ifndef SR_WINO_PRIME
+#define SR_WINO_PRIME 0   // 1: the next region's first weight fragments + first transform are issued in the epilogue's second half
+#endif
+
 #define WN_TR 4
 #define WN_TC 8
 #define WN_PH (2 * WN_TR + 2)  // 10 patch rows

@@ -57,6 +57,31 @@ __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// ---- buffer addressing (r04) ----------------------------------------------------------------------------------------
+// Every VALU instruction the kernel issues outside its MFMA stream costs ~13 clocks while the co-resident workgroup
+// keeps the matrix pipe busy, and r03's epilogue + prologue issued ~680 of them per region (64-bit
+// address arithmetic, eight predicated residual-load / store branches, a 3 x division-by-18 re-aim of the staging
+// loads).  The vector instantiations now address global memory through buffer descriptors: a wave-uniform descriptor
+// (image base, byte range) + a 32-bit lane offset + a scalar offset operand.  A lane is switched off by its OFFSET
+// (WN_OOB: the load returns 0, the store is dropped) instead of a branch, the per-(tile, pixel) deltas ride in the
+// scalar offset operand (SALU work), and an interior region -- every one at 240x320 / 120x160 -- needs no per-lane
+// predicate at all.
+typedef unsigned int wn_u4 __attribute__((ext_vector_type(4)));
+typedef float wn_f4 __attribute__((ext_vector_type(4)));
+#define WN_RSRC_FLAGS 0x00020000      // raw buffer descriptor word 3 on gfx9-family parts
+#define WN_OOB 0x7fffffffu            // a lane offset beyond any num_records
+__device__ __forceinline__ float4 wn_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const wn_f4 v = __builtin_bit_cast(wn_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void wn_buf_store(const float4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const wn_f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, t), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, WN_RSRC_FLAGS);
+}
+
 template <int NT, bool VEC4, bool VOUT>
 __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -80,6 +105,12 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
   const int t_ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1), t_rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
   const float t_sign = wave == 1 ? 1.0f : -1.0f;
   const int rv_base = ((2 * (i >> 3)) * WN_PW + 2 * (i & 7)) * WN_ROW + 4 * kk;   // patch offset of tile i, quad kk
+  // the two patch rows this wave's transform reads, as ONE register each: every other term of an rv_ld address is an
+  // immediate (left to itself the compiler hoists the 16 distinct addresses out of the work loop and spills them)
+  int rv_a = rv_base + t_ra * WN_PW * WN_ROW, rv_b = rv_base + t_rb * WN_PW * WN_ROW;
+  // (`SR_WN_PIN`: an empty asm that makes the value opaque at this point, so that addresses derived from it are formed
+  // HERE as register + immediate instead of being hoisted out of the loops, one register -- then one spill -- each)
+#define SR_WN_PIN(...) asm volatile("" : __VA_ARGS__)
 
 #ifdef SR_WINO_TRACE
   int tr_region = -1;
@@ -111,30 +142,74 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
     r.oy0 = ry * (2 * WN_TR); r.ox0 = rx * (2 * WN_TC); r.co0 = cb * (32 * NT);
     return r;
   };
+  // ---- staging: global -> registers -> LDS ----
+  // Vector path (VEC4): lane offsets in BYTES relative to the image base, through the buffer descriptor `rs_in`.  For an
+  // interior region (the whole 10x18 patch inside the image) they are the per-thread constants `rel` plus the scalar
+  // patch origin `s_org`; a border region computes them with the image test (outside -> WN_OOB -> 0).  Scalar path:
+  // element offsets from the image pointer, -1 = outside (r03 code, unaligned inputs only).
   int offs[WN_STAGE_PER_THREAD];
+  unsigned s_org = 0;
   const float* in_b = p.in;
+  __amdgpu_buffer_rsrc_t rs_in = wn_rsrc(p.in, 0);
+  const int64_t in_img_bytes = ((int64_t)(p.H * p.W - 1) * p.in_sp + p.Cin) * 4;
+  const int c_quad = 4 * (tid & 3);      // (tid + 256 it) & 3 == tid & 3: a thread stages the same channel quad of a slab
   auto aim = [&](const Region& r) {  // point the staging loads at region r
     in_b = p.in + (int64_t)r.b * p.in_sb;
+    if (VEC4) {
+      rs_in = wn_rsrc(in_b, in_img_bytes);
+      const bool interior = (r.oy0 >= 1) & (r.oy0 + 2 * WN_TR + 1 <= p.H) & (r.ox0 >= 1) & (r.ox0 + 2 * WN_TC + 1 <= p.W);
+      if (interior) {   // no image test: offsets relative to the patch origin, which rides in the scalar operand
+        s_org = (unsigned)(((r.oy0 - 1) * p.W + (r.ox0 - 1)) * p.in_sp * 4);
 #pragma unroll
-    for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
-      const int e = tid + it * 256;
-      const int px = e >> 2, q = e & 3;
-      const int py = px / WN_PW, pxx = px - py * WN_PW;
-      const int iy = r.oy0 - 1 + py, ix = r.ox0 - 1 + pxx;
-      const bool ok = (e < WN_STAGE_ELEMS) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-      offs[it] = ok ? (iy * p.W + ix) * p.in_sp + 4 * q : -1;
+        for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
+          const int e = tid + it * 256;
+          const int px = e >> 2;
+          const int py = px / WN_PW, pxx = px - py * WN_PW;
+          offs[it] = (it < WN_STAGE_PER_THREAD - 1 || e < WN_STAGE_ELEMS) ? ((py * p.W + pxx) * p.in_sp + c_quad) * 4
+                                                                          : (int)WN_OOB;
+        }
+      } else {
+        s_org = 0;
+#pragma unroll
+        for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
+          const int e = tid + it * 256;
+          const int px = e >> 2;
+          const int py = px / WN_PW, pxx = px - py * WN_PW;
+          const int iy = r.oy0 - 1 + py, ix = r.ox0 - 1 + pxx;
+          const bool ok = (e < WN_STAGE_ELEMS) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+          offs[it] = ok ? ((iy * p.W + ix) * p.in_sp + c_quad) * 4 : (int)WN_OOB;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
+        const int e = tid + it * 256;
+        const int px = e >> 2, q = e & 3;
+        const int py = px / WN_PW, pxx = px - py * WN_PW;
+        const int iy = r.oy0 - 1 + py, ix = r.ox0 - 1 + pxx;
+        const bool ok = (e < WN_STAGE_ELEMS) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+        offs[it] = ok ? (iy * p.W + ix) * p.in_sp + 4 * q : -1;
+      }
     }
   };
+  const bool c_tail = (p.Cin & 15) != 0;   // the last slab is cut by Cin: channel quads at or beyond it read 0
   auto stage_load = [&](int c0, float4 (&stg)[WN_STAGE_PER_THREAD]) {
+    if (VEC4) {
+      const unsigned so = s_org + (unsigned)c0 * 4u;
+      if (c_tail && c0 + c_quad >= p.Cin) {   // (lane-divergent only in the last slab of a ragged channel count)
 #pragma unroll
-    for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
-      const int c = c0 + 4 * ((tid + it * 256) & 3);
-      const bool ok = (offs[it] >= 0) & (c < p.Cin) & !SR_WN_DBG(4);
-      const float* src = in_b + (ok ? offs[it] + c0 : 0);
-      if (VEC4) {
-        const float4 v = *reinterpret_cast<const float4*>(src);
-        stg[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) stg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
+#pragma unroll
+        for (int it = 0; it < WN_STAGE_PER_THREAD; ++it)
+          stg[it] = SR_WN_DBG(4) ? make_float4(0.f, 0.f, 0.f, 0.f) : wn_buf_load(rs_in, (unsigned)offs[it], so);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
+        const int c = c0 + 4 * ((tid + it * 256) & 3);
+        const bool ok = (offs[it] >= 0) & (c < p.Cin) & !SR_WN_DBG(4);
+        const float* src = in_b + (ok ? offs[it] + c0 : 0);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
           v.x = src[0];
@@ -146,19 +221,26 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
       }
     }
   };
+  // LDS side of the staging: element e -> pixel e >> 2, quad e & 3.  The 48 thread slots beyond the 720 elements of a
+  // patch write their (zero) registers into the pad quad of a pixel row instead of being branched around.
+  static_assert(WN_STAGE_PER_THREAD == 3 && 2 * 256 < WN_STAGE_ELEMS, "only the third slot of a thread can be a spare");
+  int st_lds0 = (tid >> 2) * WN_ROW + 4 * (tid & 3);   // slots 0 / 1: + it * 64 pixels
+  int st_lds2 = tid + 512 < WN_STAGE_ELEMS ? st_lds0 + 128 * WN_ROW : (tid + 512 - WN_STAGE_ELEMS) * WN_ROW + 16;
   auto stage_store = [&](const float4 (&stg)[WN_STAGE_PER_THREAD], float* raw) {
-#pragma unroll
-    for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
-      const int e = tid + it * 256;
-      if (e < WN_STAGE_ELEMS) *reinterpret_cast<float4*>(&raw[(e >> 2) * WN_ROW + 4 * (e & 3)]) = stg[it];
-    }
+    *reinterpret_cast<float4*>(&raw[st_lds0]) = stg[0];
+    *reinterpret_cast<float4*>(&raw[st_lds0 + 64 * WN_ROW]) = stg[1];
+    *reinterpret_cast<float4*>(&raw[st_lds2]) = stg[2];
   };
-  const float4* wu4 = nullptr;
+  (void)rv_base;
+  // weight fragments: scalar record base (SGPR pair) + a 32-bit lane index -- the saddr form of global_load, no 64-bit
+  // vector address arithmetic in the MFMA stream
+  unsigned wu_lane = 0;   // BYTE offset of this lane's fragment inside a record (a 32-bit offset: what the saddr form takes)
   auto load_b = [&](int ch, int s, float4 (&dst)[NT]) {   // step s = (g, uc): all four frequencies of group 0, then group 1
     const int xi = 4 * wave + (s & 3), g = s >> 2;
-    const float4* wrec = wu4 + (SR_WN_DBG(32) ? (int64_t)0 : (int64_t)(xi * p.G + 2 * ch + g) * rec);
+    const char* wrec = reinterpret_cast<const char*>(reinterpret_cast<const float4*>(p.wu) +
+                                                     (SR_WN_DBG(32) ? (int64_t)0 : (int64_t)(xi * p.G + 2 * ch + g) * rec));
 #pragma unroll
-    for (int n = 0; n < NT; ++n) dst[n] = wrec[32 * n];
+    for (int n = 0; n < NT; ++n) dst[n] = *reinterpret_cast<const float4*>(wrec + (wu_lane + 512u * n));
   };
   // rv_col(raw, g, c): row `ur = wave` of B^T d at patch column c, channel quad 2g + kk; rv_row: the four frequencies
   // uc = 0..3 of that row from its four columns = the A operands of steps (g, uc).
@@ -169,8 +251,8 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
     return make_float4(lo.x, lo.y, hi.x, hi.y);
   };
   auto rv_ld = [&](const float* raw, int g, int c, float4& da, float4& db) {
-    da = *reinterpret_cast<const float4*>(&raw[rv_base + 8 * g + (t_ra * WN_PW + c) * WN_ROW]);
-    db = *reinterpret_cast<const float4*>(&raw[rv_base + 8 * g + (t_rb * WN_PW + c) * WN_ROW]);
+    da = *reinterpret_cast<const float4*>(&raw[rv_a + 8 * g + c * WN_ROW]);
+    db = *reinterpret_cast<const float4*>(&raw[rv_b + 8 * g + c * WN_ROW]);
   };
   auto rv_col = [&](const float* raw, int g, int c) {
     float4 da, db;
@@ -187,20 +269,28 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
   // after step 5, and steps 6 / 7 carry the transform of slab c+1's first channel group -- so a slab boundary costs no
   // serial LDS latency chain.  Otherwise: stored at the end of slab c, barrier, transform at the top of slab c+1.
   // With an even slab count the NEXT region's slab 0 follows the same way during the last slab -- it lands in B,
-  // which the epilogue leaves alone, and is issued in front of the epilogue's stores (VMEM returns in order).
+  // which the epilogue leaves alone, and is issued in front of the epilogue's stores (VMEM returns in order).  r04: the
+  // rest of the next region's prologue -- its first weight fragments and the transform of its first channel group --
+  // is then issued in the SECOND half of the epilogue (behind the O exchange, where the accumulators are dead), under
+  // the output stores, instead of in front of the next region's first MFMA.
   float4 stg[WN_STAGE_PER_THREAD];
   const bool chain = !(chunks & 1);
-  bool staged = false;
+  bool staged = false;      // the next region's slab 0 sits in raw B
+  bool primed_w = false, primed_t = false;   // ... and its first weight fragments / first A operands are already in registers
+  float4 b_f[NB][NT];
+  float4 av[2][4];   // A operands of the current slab: [g][uc]
+  float4 wq[4];
+  Region reg = decode(blockIdx.x < (unsigned)p.total ? (int)blockIdx.x : 0), nxt = reg;
   for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
-    const Region reg = decode(work);
     const int b = reg.b, oy0 = reg.oy0, ox0 = reg.ox0, co0 = reg.co0, sl0 = reg.ks * chunks;
-    wu4 = reinterpret_cast<const float4*>(p.wu) + (kk * p.Co_pad + co0 + i);
+    wu_lane = (unsigned)(kk * p.Co_pad + co0 + i) * 16u;
     const bool has_next = chain && (work + (int)gridDim.x < p.total);
 #ifdef SR_WINO_TRACE
     ++tr_region;
 #endif
     SR_TR(0);
     if (!staged) {
+      SR_WN_PIN("+v"(st_lds0), "+v"(st_lds2));
       aim(reg);
       stage_load(sl0 * 16, stg);
       stage_store(stg, rawB);
@@ -212,32 +302,37 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
     // cost 128 VALU instructions per region, each ~13 clocks while the co-resident workgroup keeps the matrix pipe busy)
     f32x16 acc[4][NT];
 
-    float4 b_f[NB][NT];
+    if (!primed_w) {
 #pragma unroll
-    for (int s = 0; s < PD; ++s) load_b(sl0, s, b_f[s]);
+      for (int s = 0; s < PD; ++s) load_b(sl0, s, b_f[s]);
+    }
     SR_TR(1);
 
-    float4 av[2][4];   // A operands of the current slab: [g][uc]
-    float4 wq[4];
 #if SR_WINO_PIPE
     float4 pa[2], pb[2];   // patch rows on their way from LDS to the next slab's transform
-    {  // first slab of the region: its group 0 has no MFMAs to hide under
+    if (!primed_t) {  // first slab of the region: its group 0 has no MFMAs to hide under
+      SR_WN_PIN("+v"(rv_a), "+v"(rv_b));
 #pragma unroll
       for (int c = 0; c < 4; ++c) wq[c] = rv_col(rawB, 0, c);
       rv_row(wq, av[0]);
     }
 #endif
+    primed_w = primed_t = false;
     auto slab = [&](auto first_tag, const int ch) {
       constexpr bool FIRST = decltype(first_tag)::value;   // first slab of the region: accumulators start from 0
       const bool more = ch + 1 < chunks;
       if (more) stage_load((sl0 + ch + 1) * 16, stg);
       else if (has_next) {
-        const Region nxt = decode(work + gridDim.x);
+        nxt = decode(work + gridDim.x);
         aim(nxt);
         stage_load(nxt.ks * chunks * 16, stg);
+      } else {   // nothing follows: the unconditional store below then writes zeros (keeps `stg` from living across regions)
+#pragma unroll
+        for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) stg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       const float* raw = (ch & 1) ? rawA : rawB;
       float* raw_next = (ch & 1) ? rawB : rawA;
+      SR_WN_PIN("+v"(rv_a), "+v"(rv_b), "+v"(st_lds0), "+v"(st_lds2), "+v"(wu_lane));
 #if !SR_WINO_PIPE
       if (!SR_WN_DBG(2)) {
 #pragma unroll
@@ -307,7 +402,7 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
       }
       if (ch < 5) SR_TR(3 + 2 * ch);   // this wave's MFMAs issued
 #if SR_WINO_PIPE
-      rv_row(wq, av[0]);
+      if (more) rv_row(wq, av[0]);     // (after the last slab of a region: the next region's, done under the epilogue)
 #else
       if (more || has_next) stage_store(stg, raw_next);
       __syncthreads();
@@ -328,80 +423,149 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
     // Y = A^T M A is separable: wave w holds the whole frequency ROW ur = w (its 4 accumulators are the columns
     // uc = 0..3), so the column half (M A) is done in registers and only 2 of 4 values per (tile, channel) go
     // through LDS: O[ur][b][tile][co] (64 KB for both N-tiles -> one pass, two barriers).
+    // The next region's prologue pieces that ride in the epilogue's second half (PIPE builds with a staged next region):
+    auto prime_next = [&]() {
+#if SR_WINO_PIPE && SR_WINO_PRIME
+      if (has_next) {
+        SR_WN_PIN("+v"(rv_a), "+v"(rv_b));
+        if (SR_WINO_PRIME & 1) {
+          wu_lane = (unsigned)(kk * p.Co_pad + nxt.co0 + i) * 16u;
+          const int nsl0 = nxt.ks * chunks;
+#pragma unroll
+          for (int s = 0; s < PD; ++s) load_b(nsl0, s, b_f[s]);
+          primed_w = true;
+        }
+        if (SR_WINO_PRIME & 2) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) wq[c] = rv_col(rawB, 0, c);
+          rv_row(wq, av[0]);
+          primed_t = true;
+        }
+      }
+#endif
+    };
     if (!SR_WN_DBG(16)) {
       constexpr int CO = 32 * NT;           // channels per workgroup
       if (VOUT) {
         // Vector epilogue (Cout % 4 == 0, 16-byte aligned output / residual rows): a thread owns (tile, 4 consecutive
-        // channels) units -- float4 residual loads, ds_read_b128 of the exchanged slab, float4 stores.
+        // channels) units -- float4 residual loads, ds_read_b128 of the exchanged slab, float4 stores.  All of them
+        // through buffer descriptors: ONE lane offset per tensor (the unit's first pixel, channel quad), the other
+        // seven (unit, pixel) positions are scalar deltas; border regions / channel tails switch lanes off by offset.
         constexpr int CG = CO / 4;            // channel groups per workgroup
         constexpr int UNITS = 32 * CG / 256;  // = NT
+        constexpr int TILE_ROWS_PER_UNIT = (256 / CG) / 8;   // tile rows between a thread's consecutive units
         const int cg = tid % CG;
-        const int cog = co0 + 4 * cg;
-        const bool okc = cog < p.Cout;
-        float4 rv[UNITS][4];
-        bool ok[UNITS][4];
-        unsigned opix[UNITS][4];
+        const int tile0 = tid / CG;
+        const int tr0 = tile0 >> 3, tc0 = tile0 & 7;
+        const __amdgpu_buffer_rsrc_t rs_out = wn_rsrc(outp, ((int64_t)(p.H * p.W - 1) * out_sp + p.Cout) * 4);
+        const __amdgpu_buffer_rsrc_t rs_res =
+            wn_rsrc(resp ? (const void*)resp : (const void*)p.wu,
+                    resp ? ((int64_t)(p.H * p.W - 1) * p.res_sp + p.Cout) * 4 : (int64_t)0);
+        const __amdgpu_buffer_rsrc_t rs_bias = wn_rsrc(bias_p ? (const void*)bias_p : (const void*)p.wu,
+                                                       bias_p ? (int64_t)p.Cout * 4 : (int64_t)0);
+        const bool okc = co0 + 4 * cg < p.Cout;
+        const bool full = (oy0 + 2 * WN_TR <= p.H) & (ox0 + 2 * WN_TC <= p.W) & (co0 + CO <= p.Cout);   // uniform
+        const unsigned pix0 = (unsigned)((2 * tr0) * p.W + 2 * tc0);
+        const unsigned v_out = (pix0 * out_sp + 4u * cg) * 4u, v_res = (pix0 * (unsigned)p.res_sp + 4u * cg) * 4u;
+        const unsigned s_out0 = ((unsigned)(oy0 * p.W + ox0) * out_sp + (unsigned)co0) * 4u;
+        const unsigned s_res0 = ((unsigned)(oy0 * p.W + ox0) * (unsigned)p.res_sp + (unsigned)co0) * 4u;
+        auto d_pix = [&](int it, int q) {   // scalar: pixel delta of (unit, pixel) from the unit-0 / pixel-0 position
+          return (unsigned)((2 * TILE_ROWS_PER_UNIT * it + (q >> 1)) * p.W + (q & 1));
+        };
+        // FULL = the region lies inside the image and the channel block inside Cout (every region of the 240x320 and
+        // 120x160 levels): one lane offset per tensor serves all eight (unit, pixel) positions.  Otherwise a per-position
+        // offset, WN_OOB outside the image / past Cout.
+        // LDS offsets of the O exchange as ONE register each + immediates (laundered per region: hoisted out of the work
+        // loop, the compiler kept 16 precomputed addresses in scratch and reloaded them in front of every ds_write)
+        int o_wr = (wave * 2 * 32 + 4 * kk) * CO + i, o_rd = tile0 * CO + 4 * cg;
+        asm volatile("" : "+v"(o_wr), "+v"(o_rd));
+        // a - b as fma(-1, b, a) with a -1 the compiler cannot see: v_pk_fma_f32 (the same single rounding as the
+        // subtraction).  Written as a - b, the compiler scalarises the 32 packed subtractions of the column transform
+        // into 64 v_sub_f32.
+        float neg1s = -1.0f;
+        asm volatile("" : "+s"(neg1s));
+        const wn_f2 neg1 = {neg1s, neg1s};
+        unsigned rsp4 = (unsigned)p.res_sp * 4u, osp4 = out_sp * 4u;   // (pinned: the eight scalar deltas are recomputed per
+        SR_WN_PIN("+s"(rsp4), "+s"(osp4));                             //  region on the SALU, not parked in VGPR lanes)
+        const bool fast_leaky = slope >= 0.0f && slope <= 1.0f;        // LeakyReLU as max(v, slope v): v_pk_mul + 2 v_max per pair
+        const wn_f2 slope2 = {slope, slope};
+        auto epilogue = [&](auto full_tag, auto res_tag) {
+          constexpr bool FULL = decltype(full_tag)::value, RES = decltype(res_tag)::value;
+          unsigned okm = 0;   // bit 4 it + q: position inside the image and channel quad below Cout
+          if (!FULL) {
 #pragma unroll
-        for (int it = 0; it < UNITS; ++it) {
-          const int tile = tid / CG + (256 / CG) * it;
-          const int tr = tile >> 3, tc = tile & 7;
+            for (int it = 0; it < UNITS; ++it)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int oy = oy0 + 2 * tr + (q >> 1), ox = ox0 + 2 * tc + (q & 1);
-            ok[it][q] = okc & (oy < p.H) & (ox < p.W);
-            opix[it][q] = (unsigned)(oy * p.W + ox);
-            const bool ld = ok[it][q] & (resp != nullptr);
-            const float4 v = *reinterpret_cast<const float4*>((resp ? resp : p.in) +
-                                                               (ld ? opix[it][q] * (unsigned)p.res_sp + cog : 0u));
-            rv[it][q] = ld ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+              for (int q = 0; q < 4; ++q) {
+                const int oy = oy0 + 2 * (tr0 + TILE_ROWS_PER_UNIT * it) + (q >> 1), ox = ox0 + 2 * tc0 + (q & 1);
+                okm |= (unsigned)(okc & (oy < p.H) & (ox < p.W)) << (4 * it + q);
+              }
           }
-        }
-        SR_TR(10);
+          auto lane_off = [&](unsigned v, int it, int q) { return (FULL || ((okm >> (4 * it + q)) & 1u)) ? v : WN_OOB; };
+          float4 rv[UNITS][4];
+          if (RES) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          // whole-vector arithmetic: packed fp32 adds, half the VALU instructions of the element-wise form (every VALU
-          // instruction here costs matrix-pipe time of the co-resident workgroup)
+            for (int it = 0; it < UNITS; ++it)
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {   // register PAIRS spelled out: v_pk_add_f32 (the f32x16 form compiled to scalar adds)
-            const wn_f2 m0 = {acc[0][n][r], acc[0][n][r + 1]}, m1 = {acc[1][n][r], acc[1][n][r + 1]};
-            const wn_f2 m2 = {acc[2][n][r], acc[2][n][r + 1]}, m3 = {acc[3][n][r], acc[3][n][r + 1]};
-            const wn_f2 c0 = (m0 + m1) + m2, c1 = (m1 - m2) - m3;
-            float* o0 = &O[((wave * 2 + 0) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CO + 32 * n + i];
-            float* o1 = &O[((wave * 2 + 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * CO + 32 * n + i];
-            o0[0] = c0.x; o0[CO] = c0.y;
-            o1[0] = c1.x; o1[CO] = c1.y;
+              for (int q = 0; q < 4; ++q)
+                rv[it][q] = wn_buf_load(rs_res, lane_off(v_res, it, q), s_res0 + d_pix(it, q) * rsp4);
           }
-        }
-        SR_TR(11);
-        __syncthreads();
-        SR_TR(13);
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias_p && okc) bv = *reinterpret_cast<const float4*>(bias_p + cog);
+          const float4 bv = wn_buf_load(rs_bias, (FULL || okc) ? 16u * cg : WN_OOB, (unsigned)co0 * 4u);
+          SR_TR(10);
 #pragma unroll
-        for (int it = 0; it < UNITS; ++it) {
-          const int tile = tid / CG + (256 / CG) * it;
-          float4 t[4][2];
+          for (int n = 0; n < NT; ++n) {
+            // whole-vector arithmetic: packed fp32 adds, half the VALU instructions of the element-wise form (every VALU
+            // instruction here costs matrix-pipe time of the co-resident workgroup)
 #pragma unroll
-          for (int ur = 0; ur < 4; ++ur)
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
-              t[ur][bb] = *reinterpret_cast<const float4*>(&O[((ur * 2 + bb) * 32 + tile) * CO + 4 * cg]);
-          const float4 y[4] = {f4add(f4add(t[0][0], t[1][0]), t[2][0]), f4add(f4add(t[0][1], t[1][1]), t[2][1]),
-                               f4sub(f4sub(t[1][0], t[2][0]), t[3][0]), f4sub(f4sub(t[1][1], t[2][1]), t[3][1])};
-          float o16[16];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 v = f4add(f4add(y[q], bv), rv[it][q]);
-            o16[4 * q + 0] = v.x; o16[4 * q + 1] = v.y; o16[4 * q + 2] = v.z; o16[4 * q + 3] = v.w;
+            for (int r = 0; r < 16; r += 2) {   // register PAIRS spelled out: v_pk_add_f32 (the f32x16 form compiled to scalar adds)
+              const wn_f2 m0 = {acc[0][n][r], acc[0][n][r + 1]}, m1 = {acc[1][n][r], acc[1][n][r + 1]};
+              const wn_f2 m2 = {acc[2][n][r], acc[2][n][r + 1]}, m3 = {acc[3][n][r], acc[3][n][r + 1]};
+              const wn_f2 c0 = (m0 + m1) + m2;
+              const wn_f2 c1 = __builtin_elementwise_fma(neg1, m3, __builtin_elementwise_fma(neg1, m2, m1));   // (m1 - m2) - m3
+              float* o0 = &O[o_wr + ((r & 3) + 8 * (r >> 2)) * CO + 32 * n];
+              float* o1 = o0 + 32 * CO;
+              o0[0] = c0.x; o0[CO] = c0.y;
+              o1[0] = c1.x; o1[CO] = c1.y;
+            }
           }
-          sr_activate_group(o16, slope);
+          SR_TR(11);
+          __syncthreads();
+          SR_TR(13);
+          __builtin_amdgcn_sched_barrier(0);   // (keeps the prologue pieces out of the column transform: registers)
+          prime_next();   // the accumulators are dead: next region's first weights + first transform, under the stores
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (ok[it][q] && (!SR_WN_DBG(1) || o16[4 * q] == 1.2345e33f))
-              *reinterpret_cast<float4*>(outp + (opix[it][q] * out_sp + cog)) =
-                  make_float4(o16[4 * q], o16[4 * q + 1], o16[4 * q + 2], o16[4 * q + 3]);
+          for (int it = 0; it < UNITS; ++it) {
+            float4 t[4][2];
+#pragma unroll
+            for (int ur = 0; ur < 4; ++ur)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb)
+                t[ur][bb] = *reinterpret_cast<const float4*>(&O[o_rd + ((ur * 2 + bb) * 32 + (256 / CG) * it) * CO]);
+            const float4 y[4] = {f4add(f4add(t[0][0], t[1][0]), t[2][0]), f4add(f4add(t[0][1], t[1][1]), t[2][1]),
+                                 f4sub(f4sub(t[1][0], t[2][0]), t[3][0]), f4sub(f4sub(t[1][1], t[2][1]), t[3][1])};
+            float o16[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float4 v = f4add(y[q], bv);
+              if (RES) v = f4add(v, rv[it][q]);
+              if (fast_leaky) {   // (same values as sr_activate_group's max(v, slope v), with the products packed)
+                const wn_f2 lo = wn_f2{v.x, v.y} * slope2, hi = wn_f2{v.z, v.w} * slope2;
+                v = make_float4(sr_vmax(v.x, lo.x), sr_vmax(v.y, lo.y), sr_vmax(v.z, hi.x), sr_vmax(v.w, hi.y));
+              }
+              o16[4 * q + 0] = v.x; o16[4 * q + 1] = v.y; o16[4 * q + 2] = v.z; o16[4 * q + 3] = v.w;
+            }
+            if (!fast_leaky) sr_activate_group(o16, slope);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (!SR_WN_DBG(1) || o16[4 * q] == 1.2345e33f)
+                wn_buf_store(make_float4(o16[4 * q], o16[4 * q + 1], o16[4 * q + 2], o16[4 * q + 3]), rs_out,
+                             lane_off(v_out, it, q), s_out0 + d_pix(it, q) * osp4);
+            }
           }
-        }
+        };
+        if (full) { if (resp) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::true_type{}, std::false_type{}); }
+        else { if (resp) epilogue(std::false_type{}, std::true_type{}); else epilogue(std::false_type{}, std::false_type{}); }
 #ifdef SR_WINO_TRACE
         if (tr_region > 0) SR_TR(15);
 #endif
@@ -441,6 +605,7 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
             O[((wave * 2 + 1) * 32 + tile) * CO + 32 * n + i] = (m1 - m2) - m3;
           }
         __syncthreads();
+        prime_next();
         // (3) row transform, + bias + residual, LeakyReLU, store
         const float bv = (bias_p && okc) ? bias_p[cog] : 0.0f;
 #pragma unroll
@@ -464,6 +629,7 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
         __syncthreads();
       }
     }
+    reg = has_next ? nxt : decode(work + (int)gridDim.x < p.total ? work + (int)gridDim.x : work);
   }
 }
 
