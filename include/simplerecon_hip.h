@@ -83,6 +83,23 @@ int sr_gemm1x1_nhwc_fwd(const float* in, int in_pix_stride, const float* weight,
                         int res_pix_stride, float* out, int out_pix_stride, int M, int Cin, int Cout, int act,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Pointwise (1x1, stride 1) convolution as a hand-written fp32-MFMA GEMM (csrc/sr_pw.hip), deterministic:
+ *   out[b,p,co] = act( sum_ci gate[b,ci] * in[b,p,ci] * W[co,ci] + bias[co] + residual[b,p,co] ),  p = 0 .. HW-1
+ * on channels-last views (batch stride, pixel stride in floats; channel slices of wider buffers are fine).  `packed_w` comes
+ * from sr_conv_pack_weights(ksize = 1) (eval-mode BatchNorm folded by the caller); `gate` ([B][Cin], may be null) is the
+ * squeeze-excite gate of an MBConv block, applied to the A operand while it is loaded; `residual` may be null; `act_code`
+ * as `leaky_slope` of sr_conv2d_nhwc_fwd.  Replaces BasicBlock's 1x1 skip convolution (reference modules/layers.py:20-22,
+ * 57-62) and nn.Conv2d(k=1) + BatchNorm (+ SiLU) (+ squeeze-excite scaling of the input) of the image-prior encoder's
+ * MBConv blocks (reference experiment_modules/depth_model.py:110-116).  Needs Cin % 4 == 0 and 16-byte aligned input rows
+ * (sr_pw_conv_supported; SR_ERR_UNSUPPORTED otherwise -> sr_conv2d_nhwc_fwd).  sr_pw_conv_plan reports the launch plan
+ * (32-channel tiles per wave, K split across the waves of a workgroup) chosen for a shape. */
+int sr_pw_conv_supported(int Cin, int Cout);
+int sr_pw_conv_plan(int B, int HW, int Cin, int Cout, int* nt, int* ks);
+int sr_pw_conv_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_w,
+                        const float* bias, const float* gate, const float* residual, int64_t res_batch_stride,
+                        int res_pix_stride, float* out, int64_t out_batch_stride, int out_pix_stride, int B, int HW,
+                        int Cin, int Cout, float act_code, void* stream);
+
 /* Standalone forms of the reference's small geometry helpers (utils/geometry_utils.py) for callers outside the fused
  * sweeps; same operation order as the sweeps' internal arithmetic (FP contraction off).
  *  sr_backproject_fwd   BackprojectDepth.forward (:51-59): depth [B,h*w], invK [B,16] -> points [B,4,h*w]
@@ -464,6 +481,13 @@ int sr_dwconv3x3_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_s
  * with mean[b, c] = (sum over bands of pool_partial[b, band, c]) / pixels.  w_reduce: [rd][C]; w_expand: [C][rd]. */
 int sr_se_gate_fwd(const float* pool_partial, int bands, int pixels, const float* w_reduce, const float* b_reduce,
                    const float* w_expand, const float* b_expand, float* gate, int B, int C, int rd, void* stream);
+
+/* The squeeze-excite gates alone, gate[b][c] = sigmoid(W2 silu(W1 mean_b + b1) + b2)[c], from sr_dwconv3x3_nhwc_fwd's partial
+ * sums (timm SqueezeExcite of the MBConv blocks, reference depth_model.py:110-116) for a consumer that applies them itself:
+ * sr_pw_conv_nhwc_fwd(gate = ...) scales the projection's input while loading it.  `hidden`: scratch [B][rd]. */
+int sr_se_gate2_fwd(const float* pool_partial, int bands, int pixels, const float* w_reduce, const float* b_reduce,
+                    const float* w_expand, const float* b_expand, float* hidden, float* gate, int B, int C, int rd,
+                    void* stream);
 
 /* The whole squeeze-excite step of an MBConv block in two short launches: hidden[b, j] = silu(w_reduce[j] . mean[b]
  * + b_reduce[j]) (workspace `hidden`: B * rd floats), then out[b, y, x, c] = in[b, y, x, c] * gate[b, c] with the gate

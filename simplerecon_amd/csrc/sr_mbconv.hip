@@ -360,6 +360,25 @@ extern "C" int sr_add_nhwc_fwd(const float* a, int64_t a_batch_stride, int a_pix
   return sr_hip_rc(hipGetLastError());
 }
 
+// Squeeze-excite gates only ([B][C]), for consumers that apply them themselves (sr_pw_conv_nhwc_fwd scales the projection's
+// input while it loads it): the two short launches of sr_se_scale_nhwc_fwd without the scaling pass over the map.
+extern "C" int sr_se_gate2_fwd(const float* pool_partial, int bands, int pixels, const float* w_reduce,
+                               const float* b_reduce, const float* w_expand, const float* b_expand, float* hidden,
+                               float* gate, int B, int C, int rd, void* stream_) {
+  if (B < 0 || C <= 0 || rd <= 0 || bands <= 0 || pixels <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!pool_partial || !w_reduce || !w_expand || !hidden || !gate) return SR_ERR_INVALID_ARGUMENT;
+  if (rd > 256 || C > 16384) return SR_ERR_UNSUPPORTED;
+  SrSeParams p;
+  p.pool = pool_partial; p.bands = bands; p.inv_count = 1.0f / (float)pixels;
+  p.w1 = w_reduce; p.b1 = b_reduce; p.w2 = w_expand; p.b2 = b_expand; p.gate = gate; p.C = C; p.rd = rd;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(sr_se_hidden_kernel, dim3((rd + 3) / 4, B), dim3(256), (size_t)C * sizeof(float), stream, p, hidden);
+  hipLaunchKernelGGL(sr_se_scale_kernel, dim3((C + DW_CH - 1) / DW_CH, B), dim3(256), 0, stream, p, (const float*)hidden,
+                     (const float*)nullptr, (int64_t)0, 0, (float*)nullptr, (int64_t)0, 0, 0);
+  return sr_hip_rc(hipGetLastError());
+}
+
 extern "C" int sr_se_scale_nhwc_fwd(const float* pool_partial, int bands, const float* w_reduce, const float* b_reduce,
                                     const float* w_expand, const float* b_expand, float* hidden, const float* in,
                                     int64_t in_batch_stride, int in_pix_stride, float* out, int64_t out_batch_stride,

@@ -74,9 +74,16 @@ __device__ __forceinline__ float4 wn_buf_load(__amdgpu_buffer_rsrc_t r, unsigned
   const wn_f4 v = __builtin_bit_cast(wn_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+// Stores take their scalar delta through the LANE offset (one v_add), not through the scalar-offset operand: a 16-byte
+// buffer store reads its data registers some cycles after it issues, and a VALU write to them in that window corrupts the
+// store ("VMEM store of more than 8 bytes" hazard, 2 wait states on gfx940+).  The compiler inserts those wait states only
+// when the scalar-offset operand is NOT a register -- with an SGPR offset it assumes there is no hazard, and on gfx950
+// there is: the border-region epilogue, which recomputes a lane offset between two stores, wrote the OFFSET into the
+// first channel of the previous store (found by tests/test_gpu_image_encoder.py at 480x640, r04).
 __device__ __forceinline__ void wn_buf_store(const float4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   const wn_f4 t = {v.x, v.y, v.z, v.w};
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, t), r, (int)voff, (int)soff, 0);
+  // (WN_OOB + soff stays below 2^32 and above every num_records: a switched-off lane stays switched off)
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, t), r, (int)(voff + soff), 0, 0);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void* base, int64_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, WN_RSRC_FLAGS);
@@ -229,6 +236,9 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
   auto stage_store = [&](const float4 (&stg)[WN_STAGE_PER_THREAD], float* raw) {
     *reinterpret_cast<float4*>(&raw[st_lds0]) = stg[0];
     *reinterpret_cast<float4*>(&raw[st_lds0 + 64 * WN_ROW]) = stg[1];
+#ifdef SR_WINO_DBG_NOPAD
+    if (tid + 512 < WN_STAGE_ELEMS)
+#endif
     *reinterpret_cast<float4*>(&raw[st_lds2]) = stg[2];
   };
   (void)rv_base;
@@ -464,7 +474,11 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
         const __amdgpu_buffer_rsrc_t rs_bias = wn_rsrc(bias_p ? (const void*)bias_p : (const void*)p.wu,
                                                        bias_p ? (int64_t)p.Cout * 4 : (int64_t)0);
         const bool okc = co0 + 4 * cg < p.Cout;
+#ifdef SR_WINO_FORCE_BORDER   // (test builds: every region through the per-position epilogue)
+        const bool full = false;
+#else
         const bool full = (oy0 + 2 * WN_TR <= p.H) & (ox0 + 2 * WN_TC <= p.W) & (co0 + CO <= p.Cout);   // uniform
+#endif
         const unsigned pix0 = (unsigned)((2 * tr0) * p.W + 2 * tc0);
         const unsigned v_out = (pix0 * out_sp + 4u * cg) * 4u, v_res = (pix0 * (unsigned)p.res_sp + 4u * cg) * 4u;
         const unsigned s_out0 = ((unsigned)(oy0 * p.W + ox0) * out_sp + (unsigned)co0) * 4u;

@@ -18,6 +18,7 @@ The modules only hold parameters.  Every forward runs HIP kernels (inference: op
 BatchNorm and SiLU epilogue, ops.dwconv3x3, ops.se_scale_, ops.add_; training -- a gradient is wanted or a BatchNorm
 layer is in training mode: the differentiable operators of train_ops, forward and backward on HIP kernels); there is no
 torch fallback."""
+import os
 from typing import List
 
 import torch
@@ -33,6 +34,7 @@ def _tf_pads(x, conv):
     return None if pads == (1, 1, 1, 1) else pads
 
 BN_EPS = 1e-3          # tf_* models
+FUSE_SE_GATE = os.environ.get("SR_SE_GATE_FUSED", "1") != "0"   # 0: separate in-place scaling pass (r03)
 STEM_CHANNELS = 24
 # (block type, repeats, stride, expansion, output channels, squeeze-excite ratio w.r.t. the block input)
 STAGES = (("cn", 2, 1, 1, 24, 0.0), ("er", 4, 2, 4, 48, 0.0), ("er", 4, 2, 4, 64, 0.0),
@@ -108,6 +110,10 @@ class InvertedResidual(nn.Module):
     def forward(self, x):
         t = ops.conv2d(x, self.conv_pw, bn=self.bn1, act="silu", library_gemm=True)
         d, pool = ops.dwconv3x3(t, self.conv_dw, bn=self.bn2, act="silu", tf_same=True, want_pool=True)
+        if ops.USE_PW_1X1 and FUSE_SE_GATE:
+            # the squeeze-excite gate rides in the projection's A operand: the gated map is never written
+            gate = ops.se_gates(pool, d.shape[2] * d.shape[3], self.se.conv_reduce, self.se.conv_expand)
+            return ops.conv2d(d, self.conv_pwl, bn=self.bn3, residual=x if self.has_skip else None, gate=gate)
         ops.se_scale_(d, pool, self.se.conv_reduce, self.se.conv_expand)
         return ops.conv2d(d, self.conv_pwl, bn=self.bn3, residual=x if self.has_skip else None, library_gemm=True)
 

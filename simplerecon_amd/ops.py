@@ -184,7 +184,12 @@ def packed_weight(conv: nn.Conv2d, bn=None):
 
 
 _GEMM_W = weakref.WeakKeyDictionary()  # nn.Conv2d (1x1) -> (state key, [Cout, Cin] weight with BN folded, bias)
-USE_GEMM_1X1 = os.environ.get("SR_CONV1X1_GEMM", "1") != "0"   # 0: every 1x1 conv on the implicit-GEMM HIP kernel
+# 1x1 / stride-1 convolutions: "pw" (default) = the hand-written pointwise MFMA GEMM of csrc/sr_pw.hip (deterministic, r04);
+# "lib" = hipBLASLt where the caller allows it (library_gemm=True; r02 / r03 behaviour: the algorithm is picked by timing,
+# per process); "0" = the implicit-GEMM conv kernel for everything.
+_MODE_1X1 = os.environ.get("SR_CONV1X1_GEMM", "pw")
+USE_PW_1X1 = _MODE_1X1 not in ("0", "lib", "1")
+USE_GEMM_1X1 = _MODE_1X1 in ("lib", "1")
 GEMM_1X1_MIN_PIXELS = 1024
 SHORTCUT_GEMM = os.environ.get("SR_SHORTCUT_GEMM", "1") != "0"   # BasicBlock's 1x1 skip conv as a library GEMM
 
@@ -278,13 +283,15 @@ def _shape_query(lib, name, *shape):
     return v
 
 
-def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act=None, tf_same=False, library_gemm=False):
+def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act=None, tf_same=False, library_gemm=False,
+           gate=None):
     """act(bn(conv(x) + bias) [+ residual]) with nn.Conv2d semantics (zero or replicate padding); `bn` is an
     eval-mode BatchNorm2d folded into weight and bias.  `leaky` = LeakyReLU slope, or act="silu".  tf_same=True
     replaces the module's symmetric padding by TensorFlow-"SAME" padding (tf_same_pads).  library_gemm=True lets a 1x1
     conv over a dense map run as a hipBLASLt GEMM (faster on the MBConv shapes; its algorithm choice depends on the number
     of pixels, so results are no longer bitwise independent of the batch size -- callers that promise that keep the
-    default).  Returns a channels-last view."""
+    default; only with SR_CONV1X1_GEMM=lib since r04).  `gate` ([B, Cin], 1x1 / stride-1 convs only): the input is scaled
+    per image and input channel while it is loaded (the squeeze-excite gate of an MBConv block).  Returns a channels-last view."""
     _lib.refuse_autograd(x, conv.weight)
     x = as_nhwc(x, "conv input")
     b, ci, h, w = x.shape
@@ -317,6 +324,34 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
     isb, isp = _strides(x)
     osb, osp = _strides(out)
     rsb, rsp = _strides(residual) if residual is not None else (0, 0)
+    prof = PROFILE
+    if gate is not None:
+        _lib.require_device_f32("gate", gate)
+        if k != 1 or s != 1 or tuple(gate.shape) != (b, ci) or not gate.is_contiguous():
+            raise ValueError(f"`gate` needs a 1x1 / stride-1 conv and a contiguous [{b}, {ci}] tensor")
+    if k == 1 and s == 1 and not padded and not replicate and (USE_PW_1X1 or gate is not None) and ci % 4 == 0 \
+            and x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0:
+        wp, bias = packed_weight(conv, bn)
+        with _lib.on_device(x.device):
+            if prof is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            rc = lib.sr_pw_conv_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(gate),
+                                         _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h * w, ci, co,
+                                         C.c_float(_act_code(leaky, act)), _lib.stream_ptr(x.device))
+            if prof is not None:
+                ev1.record()
+                nt, ks = C.c_int(0), C.c_int(0)
+                lib.sr_pw_conv_plan(b, h * w, ci, co, C.byref(nt), C.byref(ks))
+                mt = b * ((h * w + 31) // 32)
+                executed = 2.0 * mt * 32 * ((co + 32 * nt.value - 1) // (32 * nt.value) * 32 * nt.value) * ((ci + 7) // 8 * 8)
+                prof.append((f"sr_pw_kernel<{nt.value}, {ks.value}, {'true' if gate is not None else 'false'}>",
+                             2.0 * b * h * w * co * ci, ev0, ev1, (b, ci, h, w, co, k, s, ho, wo, residual is not None),
+                             executed))
+        _lib.check(rc, "sr_pw_conv_nhwc_fwd")
+        return out
+    if gate is not None:
+        raise _lib.HipLibraryError("a gated 1x1 convolution needs Cin % 4 == 0 and 16-byte aligned input rows")
     if k == 1 and s == 1 and (w % 32 != 0 or h % 4 != 0) and (isp, isb) == (ci, h * w * ci) \
             and (osp, osb) == (co, h * w * co) and (residual is None or (rsp, rsb) == (co, h * w * co)):
         # a 1x1 conv over dense channels-last maps is a [B*H*W, Cin] x [Cin, Cout] product: hand the kernel the
@@ -327,7 +362,6 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
         if fw:
             b, h, w, ho, wo = 1, m // fw, fw, m // fw, fw
             isb, osb, rsb = m * ci, m * co, (m * co if residual is not None else 0)
-    prof = PROFILE
     # 1x1 convs over dense maps are plain GEMMs: hipBLASLt (north star: "rocBLAS/MFMA only where it is a dense im2col
     # GEMM") is 1.25-1.75x faster than the implicit-GEMM kernel on the MBConv shapes (scripts/gemm_probe.py)
     if library_gemm and k == 1 and s == 1 and not padded and not replicate and USE_GEMM_1X1 and \
@@ -753,6 +787,33 @@ def se_gate(pool_partial, pixels, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2d
                                        _lib.ptr(b1), _lib.ptr(w2.contiguous()), _lib.ptr(b2), _lib.ptr(gate), b, c, rd,
                                        _lib.stream_ptr(gate.device))
     _lib.check(rc, "sr_se_gate_fwd")
+    return gate
+
+
+def se_gates(pool_partial, pixels, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2d):
+    """[B, C] squeeze-excite gates from dwconv3x3's partial sums (two short launches); the consumer -- conv2d(..., gate=) --
+    applies them to its input while loading it, so the gated map is never written."""
+    _lib.require_device_f32("pool partial sums", pool_partial)
+    b, bands, c = pool_partial.shape
+    rd = conv_reduce.out_channels
+    if conv_reduce.kernel_size != (1, 1) or conv_expand.kernel_size != (1, 1) or conv_reduce.in_channels != c \
+            or conv_expand.in_channels != rd or conv_expand.out_channels != c or not pool_partial.is_contiguous():
+        raise _lib.HipLibraryError("squeeze-excite expects 1x1 convs C -> rd -> C and contiguous [B, bands, C] partial sums")
+    _lib.refuse_autograd(pool_partial, conv_reduce.weight, conv_expand.weight)
+    gate = torch.empty((b, c), dtype=torch.float32, device=pool_partial.device)
+    if b == 0:
+        return gate
+    hidden = torch.empty((b, rd), dtype=torch.float32, device=pool_partial.device)
+    w1, w2 = conv_reduce.weight.detach(), conv_expand.weight.detach()
+    if not (w1.is_contiguous() and w2.is_contiguous()):
+        w1, w2 = w1.contiguous(), w2.contiguous()
+    b1 = conv_reduce.bias.detach() if conv_reduce.bias is not None else None
+    b2 = conv_expand.bias.detach() if conv_expand.bias is not None else None
+    with _lib.on_device(gate.device):
+        rc = _lib.lib().sr_se_gate2_fwd(_lib.ptr(pool_partial), bands, pixels, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
+                                        _lib.ptr(b2), _lib.ptr(hidden), _lib.ptr(gate), b, c, rd,
+                                        _lib.stream_ptr(gate.device))
+    _lib.check(rc, "sr_se_gate2_fwd")
     return gate
 
 

@@ -206,6 +206,7 @@ def test_conv1x1_library_gemm_path(shape, monkeypatch):
         ref = ref + res
     ref = torch.nn.functional.silu(ref) if act == "silu" else torch.relu(ref) if act == "relu" else ref
     outs = {}
+    monkeypatch.setattr(ops, "USE_PW_1X1", False)   # (r04 default: the hand-written pointwise GEMM, tested below)
     for use in (True, False):
         monkeypatch.setattr(ops, "USE_GEMM_1X1", use)
         with torch.inference_mode():
@@ -219,3 +220,100 @@ def test_conv1x1_library_gemm_path(shape, monkeypatch):
         outs[use] = buf[:, 4:4 + co].clone()
         assert rel_err(outs[use], ref.detach()) < 1e-5, use
     assert rel_err(outs[True], outs[False]) < 1e-5
+
+
+PW_SHAPES = [  # (B, Cin, Cout, h, w, act, residual, gate)
+    (8, 256, 1536, 15, 20, "silu", False, False),    # encoder stage 5 expand
+    (8, 1536, 256, 15, 20, None, True, True),        # ... project: squeeze-excite gate + skip; K split across waves
+    (8, 960, 160, 30, 40, None, True, True),         # stage 4 project (five 32-channel tiles)
+    (2, 192, 64, 120, 160, None, False, False),      # BasicBlock skip
+    (1, 112, 64, 48, 64, None, False, False),
+    (3, 24, 48, 33, 47, "relu", True, False),        # ragged pixel tiles, Cout not a multiple of 32
+    (2, 20, 1, 9, 11, None, False, False),           # Cin % 8 == 4, one output channel
+    (1, 640, 384, 15, 20, 0.2, False, False),
+    (2, 64, 100, 7, 5, "silu", True, True),          # 35 pixels per image: two tiles, the second ragged
+]
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES)
+@pytest.mark.parametrize("plan", [None, (1, 1), (2, 2), (2, 4), (4, 1)])
+def test_pointwise_gemm_kernel(shape, plan, monkeypatch):
+    """sr_pw_conv_nhwc_fwd (csrc/sr_pw.hip): the 1x1 convolution as a hand-written fp32-MFMA GEMM -- bias, BatchNorm fold,
+    residual before the activation, SiLU / ReLU / LeakyReLU, the squeeze-excite gate on the input, channel-slice inputs
+    and outputs, every launch plan (channel tiles per wave, K split 1 / 2 / 4) -- against ATen in float64; deterministic."""
+    B, ci, co, h, w, act, with_res, with_gate = shape
+    if plan is not None:
+        monkeypatch.setenv("SR_PW_NT", str(plan[0]))
+        monkeypatch.setenv("SR_PW_KS", str(plan[1]))
+        if plan[1] > 1 and (ci + 7) // 8 // plan[1] < 8:
+            pytest.skip("K too short for this split")
+    g = torch.Generator().manual_seed(ci * 5 + co)
+    conv = torch.nn.Conv2d(ci, co, 1).to(DEV)
+    bn = synthetic.seeded_fill_(torch.nn.BatchNorm2d(co).eval(), seed=2).to(DEV)
+    wide = torch.randn((B, ci + 8, h, w), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    x = wide[:, 4:4 + ci]                                     # a channel slice of a wider buffer (16-byte aligned rows)
+    res = torch.randn((B, co, h, w), generator=g).to(DEV) if with_res else None
+    gate = torch.rand((B, ci), generator=g).to(DEV) if with_gate else None
+    kw = dict(act="silu") if act == "silu" else dict(leaky=0.0) if act == "relu" else dict(leaky=act) if act else {}
+    xr = x.double() * (gate.double()[:, :, None, None] if with_gate else 1.0)
+    bnd = torch.nn.BatchNorm2d(co).eval().double().to(DEV)
+    bnd.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    ref = bnd(torch.nn.functional.conv2d(xr, conv.weight.double(), conv.bias.double()))
+    if res is not None:
+        ref = ref + res.double()
+    ref = torch.nn.functional.silu(ref) if act == "silu" else torch.relu(ref) if act == "relu" else \
+        torch.nn.functional.leaky_relu(ref, act) if act else ref
+    with torch.inference_mode():
+        ops.PROFILE = []
+        co_buf = (co + 3) // 4 * 4 + 8
+        buf = ops.empty_nhwc(B, co_buf, h, w, DEV).fill_(3.0)
+        ops.conv2d(x, conv, bn=bn, residual=res, out=buf[:, 4:4 + co], gate=gate, **kw)
+        names = [r[0] for r in ops.PROFILE]
+        ops.PROFILE = None
+        again = ops.conv2d(x, conv, bn=bn, residual=res, gate=gate, **kw)
+    assert names[0].startswith("sr_pw_kernel"), names
+    if plan is not None and not (plan[0] == 4 and plan[1] == 1 and False):
+        assert names[0].startswith(f"sr_pw_kernel<{plan[0]}, {plan[1]}"), names
+    assert bool((buf[:, :4] == 3).all()) and bool((buf[:, 4 + co:] == 3).all())
+    got = buf[:, 4:4 + co]
+    assert rel_err(got, ref.float().detach()) < 1e-5
+    assert torch.equal(got, again)      # fixed reduction order: bit-identical across calls and output layouts
+
+
+def test_pointwise_gemm_is_batch_independent_and_matches_the_conv_kernel(monkeypatch):
+    """An image's result does not depend on what else is in the batch (pixel tiles never straddle images), and the GEMM agrees
+    with the implicit-GEMM kernel it replaces."""
+    g = torch.Generator().manual_seed(11)
+    conv = torch.nn.Conv2d(128, 96, 1).to(DEV)
+    x = torch.randn((5, 128, 17, 23), generator=g).to(DEV)
+    with torch.inference_mode():
+        all5 = ops.conv2d(x, conv, leaky=0.2)
+        one = ops.conv2d(x[3:4].contiguous(memory_format=torch.channels_last), conv, leaky=0.2)
+        monkeypatch.setattr(ops, "USE_PW_1X1", False)
+        old = ops.conv2d(x, conv, leaky=0.2)
+    assert torch.equal(all5[3:4], one)
+    assert rel_err(all5, old) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 240, 320, 24, "silu"), (2, 32, 240, 320, 24, None), (1, 16, 240, 320, 24, 0.2),
+                                   (1, 24, 120, 168, 40, None)])
+def test_winograd_many_regions_per_workgroup_with_a_channel_tail(shape):
+    """Output channel counts that are not a multiple of 32 send EVERY region through the per-position ("border") epilogue of
+    sr_wino_kernel; with more regions than workgroups each workgroup runs it many times in a row.  r04 regression: a 16-byte
+    buffer store with an SGPR offset followed by a VALU write to its data registers stored the next store's OFFSET into
+    channel 4 cg of a few pixels (the compiler does not know that hazard for register offsets) -- sparse, timing dependent,
+    only visible at full resolution (EfficientNetV2-S stage 0 at 480x640)."""
+    B, ci, H, W, co, act = shape
+    g = torch.Generator().manual_seed(co)
+    conv = torch.nn.Conv2d(ci, co, 3, padding=1).to(DEV)
+    x = torch.randn((B, ci, H, W), generator=g).to(DEV)
+    res = torch.randn((B, co, H, W), generator=g).to(DEV)
+    kw = dict(act="silu") if act == "silu" else dict(leaky=act) if act is not None else {}
+    ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double()
+    ref = torch.nn.functional.silu(ref) if act == "silu" else torch.nn.functional.leaky_relu(ref, act) if act is not None else ref
+    with torch.inference_mode():
+        for _ in range(3):
+            out = ops.empty_nhwc(B, co, H, W, DEV).fill_(777.0)
+            ops.conv2d(x, conv, residual=res, out=out, **kw)
+            assert int((out == 777.0).sum()) == 0
+            assert rel_err(out, ref.float()) < 1e-5
