@@ -8,8 +8,10 @@ Reference path: experiment_modules/depth_model.py:358-405 (what bench.py times a
 
 Batch 1 is checked in full; of a batch of 8 (the timed batch size: other tile plans, no split-K) frames 0 and 7.
 Checked per frame: the cost volume, `lowest_cost`, `overall_mask`, every CVEncoder level, all four
-`log_depth_pred_s*` / `depth_pred_s*` at 1e-4 range-relative, and element-wise p99 < 1e-4 on `depth_pred_s0`.
+`log_depth_pred_s*` / `depth_pred_s*` at 1e-4 range-relative, and element-wise p99 < 1.5e-5 / max < 3e-5 on `depth_pred_s0`
+(2x what is measured; every measured error is written to gpurun_out/parity_e2e.json -> profiles/r04_parity.json).
 """
+import json
 import os
 
 import numpy as np
@@ -101,26 +103,53 @@ class _Case:
         return r
 
     def check(self, out, i, b, what):
-        """frame i of the HIP outputs against oracle frame b."""
+        """frame i of the HIP outputs against oracle frame b.  Every measured error goes into the parity record
+        (`RECORD`, written to gpurun_out/parity_e2e.json at module teardown; profiles/r04_parity.json is a copy)."""
         r = self.oracle_frame(b)
-        assert_close(out["cost_volume"][i:i + 1], r["vol"], what=f"{what}: cost volume")
-        assert mismatch_fraction(out["overall_mask_bhw"][i:i + 1], r["mask"]) == 0.0, f"{what}: overall_mask"
-        assert_lowest_cost(out["lowest_cost_bhw"][i:i + 1], out["cost_volume"][i:i + 1], r["planes"], r["low"],
-                           what=what)
+        rec = RECORD.setdefault(what, {})
+
+        def stage(name, got, ref):
+            e = assert_close(got, ref, what=f"{what}: {name}")
+            rec[name] = {"range_rel": e, **{"elementwise_" + k: v for k, v in
+                                            elementwise_rel_percentiles(got, ref, floor=1e-3 * float(np.abs(ref).max())).items()}}
+        stage("cost_volume", out["cost_volume"][i:i + 1], r["vol"])
+        mm = mismatch_fraction(out["overall_mask_bhw"][i:i + 1], r["mask"])
+        rec["overall_mask_mismatch_fraction"] = mm
+        assert mm == 0.0, f"{what}: overall_mask"
+        rec["lowest_cost_argmax_flip_fraction"] = assert_lowest_cost(
+            out["lowest_cost_bhw"][i:i + 1], out["cost_volume"][i:i + 1], r["planes"], r["low"], what=what)
         for lv, (got, ref) in enumerate(zip(out["levels"], r["levels"])):
-            assert_close(got[i:i + 1], ref, what=f"{what}: CVEncoder level {lv}")
+            stage(f"cv_encoder_level_{lv}", got[i:i + 1], ref)
         for s in range(4):
             k = f"log_depth_pred_s{s}_b1hw"
             assert out[k].shape[1:] == (1, (H // 2) >> s, (W // 2) >> s)
-            assert_close(out[k][i:i + 1], r["ref"][k], what=f"{what}: {k}")
-            assert_close(out[k.replace("log_", "")][i:i + 1], np.exp(r["ref"][k]), what=f"{what}: depth {k}")
+            stage(k, out[k][i:i + 1], r["ref"][k])
+            stage(k.replace("log_", ""), out[k.replace("log_", "")][i:i + 1], np.exp(r["ref"][k]))
         pct = elementwise_rel_percentiles(out["depth_pred_s0_b1hw"][i:i + 1], np.exp(r["ref"]["log_depth_pred_s0_b1hw"]))
-        assert pct["p99"] < 1e-4 and pct["max"] < 1e-3, (what, pct)
+        rec["depth_pred_s0_elementwise"] = pct
+        # measured (r04, batch 1 and frames 0 / 7 of a batch of 8): p99 7.5e-6, max 1.4e-5 -- the bounds are 2x that
+        assert pct["p99"] < ELEMENTWISE_P99 and pct["max"] < ELEMENTWISE_MAX, (what, pct)
+
+
+RECORD = {}
+ELEMENTWISE_P99, ELEMENTWISE_MAX = 1.5e-5, 3e-5   # element-wise bounds on depth_pred_s0: 2x the measured values (r03: 1e-4 / 1e-3)
 
 
 @pytest.fixture(scope="module")
 def case():
-    return _Case()
+    yield _Case()
+    if RECORD:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.environ.get("SR_PARITY_JSON") or os.path.join(root, "gpurun_out", "parity_e2e.json")
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump({"what": "DepthModel.forward_tensors (HIP, production dispatch) vs the CPU oracle chain at 640x480, "
+                                   "7 source views, 64 planes (tests/test_gpu_e2e_full_size.py); range_rel = max|a-b| / max|b|, "
+                                   "elementwise_* = |a-b| / max(|b|, 1e-3 max|b|) percentiles (depth_pred_s0_elementwise: floor 1e-6)",
+                           "frames": RECORD}, f, indent=1, sort_keys=True)
+        except OSError:
+            pass
 
 
 def test_batch_1_at_benchmarked_shape_matches_oracle_chain(case):
