@@ -607,6 +607,25 @@ def _bn_act(x, sd, prefix, act, precision):
     return silu(y) if act else y
 
 
+def effnet_mbconv_block(x, sd, pre, stride, precision="f32"):
+    """One MBConv block WITHOUT its identity skip: bn(conv1x1(se(silu(bn(dw3x3(silu(bn(conv1x1(x))))))))), TF-"SAME" padding
+    on the depthwise conv, squeeze-excite = x * sigmoid(W2 silu(W1 mean(x) + b1) + b2), parameters under timm's names
+    `pre + {conv_pw, bn1, conv_dw, bn2, se.conv_reduce, se.conv_expand, conv_pwl, bn3}`.  The one independent anchor on
+    this box: transformers' EfficientNetBlock (the V1 block: same expand -> depthwise(SAME) -> SE -> project semantics)
+    computes the same function (tests/test_oracle_effnet.py)."""
+    dt, _ = _dt(precision)
+    y = _bn_act(conv2d(x, sd[pre + "conv_pw.weight"], None, precision=precision), sd, pre + "bn1.", True, precision)
+    y = _bn_act(dwconv3x3_same(y, sd[pre + "conv_dw.weight"], stride), sd, pre + "bn2.", True, precision)
+    m = y.mean(axis=(2, 3), keepdims=True, dtype=y.dtype)
+    w1, b1 = np.asarray(sd[pre + "se.conv_reduce.weight"], dt), np.asarray(sd[pre + "se.conv_reduce.bias"], dt)
+    w2, b2 = np.asarray(sd[pre + "se.conv_expand.weight"], dt), np.asarray(sd[pre + "se.conv_expand.bias"], dt)
+    h = silu(np.einsum("oc,bc->bo", w1[:, :, 0, 0], m[:, :, 0, 0]) + b1)
+    g = np.einsum("oc,bc->bo", w2[:, :, 0, 0], h) + b2
+    with np.errstate(over="ignore"):
+        y = y * (dt(1) / (dt(1) + np.exp(-g)))[:, :, None, None]
+    return _bn_act(conv2d(y, sd[pre + "conv_pwl.weight"], None, precision=precision), sd, pre + "bn3.", False, precision)
+
+
 def efficientnetv2_s_features(img, sd, precision="f32", taps=None):
     """[f2, f4, f8, f16, f32] of the tf_efficientnetv2_s feature extractor for an image batch [B,3,H,W]."""
     dt, _ = _dt(precision)
@@ -625,18 +644,7 @@ def efficientnetv2_s_features(img, sd, precision="f32", taps=None):
                 y = _bn_act(conv2d(y, sd[pre + "conv_pwl.weight"], None, precision=precision), sd, pre + "bn2.",
                             False, precision)
             else:                 # MBConv: expand 1x1, depthwise 3x3, squeeze-excite, project 1x1
-                y = _bn_act(conv2d(x, sd[pre + "conv_pw.weight"], None, precision=precision), sd, pre + "bn1.", True,
-                            precision)
-                y = _bn_act(dwconv3x3_same(y, sd[pre + "conv_dw.weight"], s), sd, pre + "bn2.", True, precision)
-                m = y.mean(axis=(2, 3), keepdims=True, dtype=y.dtype)
-                w1, b1 = np.asarray(sd[pre + "se.conv_reduce.weight"], dt), np.asarray(sd[pre + "se.conv_reduce.bias"], dt)
-                w2, b2 = np.asarray(sd[pre + "se.conv_expand.weight"], dt), np.asarray(sd[pre + "se.conv_expand.bias"], dt)
-                h = silu(np.einsum("oc,bc->bo", w1[:, :, 0, 0], m[:, :, 0, 0]) + b1)
-                g = np.einsum("oc,bc->bo", w2[:, :, 0, 0], h) + b2
-                with np.errstate(over="ignore"):
-                    y = y * (dt(1) / (dt(1) + np.exp(-g)))[:, :, None, None]
-                y = _bn_act(conv2d(y, sd[pre + "conv_pwl.weight"], None, precision=precision), sd, pre + "bn3.",
-                            False, precision)
+                y = effnet_mbconv_block(x, sd, pre, s, precision)
             x = y + skip if skip is not None else y
             cin = cout
             if taps is not None:

@@ -51,3 +51,52 @@ def test_structure_anchors(encoder):
         assert tuple(sd[key].shape) == shape, key
     assert [len(s) for s in encoder.blocks] == [2, 4, 4, 6, 9, 15]
     assert all(m.eps == 1e-3 for m in encoder.modules() if isinstance(m, torch.nn.BatchNorm2d))
+
+
+@pytest.mark.parametrize("case", [dict(cin=64, cout=64, stride=1, expand=4, hw=(12, 16), skip=True),
+                                  dict(cin=48, cout=96, stride=2, expand=6, hw=(14, 18), skip=False),
+                                  dict(cin=32, cout=32, stride=1, expand=6, hw=(9, 11), skip=True)])
+def test_mbconv_block_matches_transformers_efficientnet_block(case):
+    """The only INDEPENDENT statement of an MBConv + squeeze-excite block on this box: `transformers.models.efficientnet.
+    modeling_efficientnet.EfficientNetBlock` (EfficientNet V1's block: expand 1x1 -> BN -> swish -> depthwise 3x3 with
+    TF-"SAME" padding -> BN -> swish -> SE (reduce to 0.25 x block input, swish, expand, sigmoid) -> project 1x1 -> BN ->
+    + input).  oracle.effnet_mbconv_block -- the function every stage-3..5 block of the image-prior encoder restatement
+    goes through -- computes the same numbers from the same weights.  (Parity with timm's tf_efficientnetv2_s itself
+    stays UNPINNED: timm is not installed here; this pins the block semantics, not the network definition.)"""
+    M = pytest.importorskip("transformers.models.efficientnet.modeling_efficientnet")
+    from transformers import EfficientNetConfig
+    cfg = EfficientNetConfig(hidden_act="swish", batch_norm_eps=1e-3, squeeze_expansion_ratio=0.25)
+    H, W = case["hw"]
+    if case["stride"] == 2:
+        assert H % 2 == 0 and W % 2 == 0   # transformers pads (0, 1, 0, 1) = TF-"SAME" only on even maps (adjust_padding)
+    blk = M.EfficientNetBlock(cfg, in_dim=case["cin"], out_dim=case["cout"], stride=case["stride"],
+                              expand_ratio=case["expand"], kernel_size=3, drop_rate=0.0, id_skip=not case["skip"],
+                              adjust_padding=case["stride"] == 2).eval()
+    g = torch.Generator().manual_seed(case["cin"] + case["cout"])
+    with torch.no_grad():
+        for name, p in blk.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.1) + (1.0 if name.endswith("norm.weight") or
+                                                                                         name.endswith("bn.weight") else 0.0))
+        for name, b in blk.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif name.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+    x = torch.randn((2, case["cin"], H, W), generator=g)
+    with torch.inference_mode():
+        ref = blk(x).numpy()
+    t = {k: v.detach().numpy() for k, v in blk.state_dict().items()}
+    pre = "b."
+    sd = {pre + "conv_pw.weight": t["expansion.expand_conv.weight"], pre + "conv_dw.weight": t["depthwise_conv.depthwise_conv.weight"],
+          pre + "se.conv_reduce.weight": t["squeeze_excite.reduce.weight"], pre + "se.conv_reduce.bias": t["squeeze_excite.reduce.bias"],
+          pre + "se.conv_expand.weight": t["squeeze_excite.expand.weight"], pre + "se.conv_expand.bias": t["squeeze_excite.expand.bias"],
+          pre + "conv_pwl.weight": t["projection.project_conv.weight"]}
+    for ours, theirs in (("bn1", "expansion.expand_bn"), ("bn2", "depthwise_conv.depthwise_norm"), ("bn3", "projection.project_bn")):
+        for f in ("weight", "bias", "running_mean", "running_var"):
+            sd[f"{pre}{ours}.{f}"] = t[f"{theirs}.{f}"]
+    for precision, tol in (("f64", 1e-6), ("f32", 2e-5)):
+        y = oracle.effnet_mbconv_block(x.numpy(), sd, pre, case["stride"], precision=precision)
+        if case["skip"]:
+            y = y + x.numpy()
+        assert y.shape == ref.shape == (2, case["cout"], -(-H // case["stride"]), -(-W // case["stride"]))
+        assert np.abs(y - ref).max() <= tol * np.abs(ref).max(), (precision, np.abs(y - ref).max() / np.abs(ref).max())
