@@ -734,6 +734,27 @@ class TsdfFuse:
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "not run for this workload"}
 
 
+class HeroCfg5(HeroCfg3):
+    """BASELINE.json configs[4] end to end: hero_model.yaml stress configuration -- 15 source views, 96 planes, batch 4 -- at
+    960x736 (the reference's UNet++ cannot run at 960x720: 23 -> 46 != 45 rows, modules/networks.py:83-89; 736 = 23 * 32 is
+    SURVEY.md §7's padded variant).  Whole DepthModel.forward from the images; parity at this shape:
+    tests/test_gpu_e2e_stress_size.py."""
+    name = "hero_cfg5"
+    B, K, Cc, D, h, w = 4, 15, 16, 96, 184, 240
+
+    def config(self, world):
+        c = super().config(world)
+        c["workload"] = (f"{self.name}: whole DepthModel.forward (EfficientNetV2-S image-prior encoder + ResnetMatchingEncoder on "
+                         f"{self.B}x{self.K + 1} images -> 410-input metadata-MLP sweep -> CVEncoder -> DepthDecoderPP -> exp), batch "
+                         f"{self.B}/GPU, {self.K} source views, {self.D} planes, 960x736 image ({self.h}x{self.w} matching "
+                         f"features), fp32, random-init weights (BASELINE.json configs[4] padded from 960x720, where the "
+                         f"reference's decoder cannot run)")
+        return c
+
+    def cpu_baseline(self):
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "not run for this workload"}
+
+
 class DotFull(HeroCfg3):
     """dot_product_model.yaml through the full hot path (cost volume + conv stack), batch 8."""
     name = "dot_full"
@@ -756,6 +777,7 @@ WORKLOADS = {
     "dot_full": lambda dev, rank: DotFull(dev, rank),
     "hero_cfg4_stream": lambda dev, rank: HeroCfg4Stream(dev, rank),
     "hero_cfg5_volume": lambda dev, rank: HeroVolumeOnly(dev, rank),
+    "hero_cfg5": lambda dev, rank: HeroCfg5(dev, rank),
     "hero_cfg3_volume": lambda dev, rank: HeroVolumeOnly(dev, rank, B=8, K=7, D=64, h=120, w=160),
     "tsdf_fuse": lambda dev, rank: TsdfFuse(dev, rank),
     "dot_cfg2": lambda dev, rank: DotCfg2(dev, rank),

@@ -815,7 +815,11 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   p.part_stride = (int64_t)B * H * W * Cout;
   p.co_blocks = p.Co_pad / (32 * nt);
   p.total = p.regions_x * p.regions_y * p.co_blocks * B * p.ksplit;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_WINO_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
+#ifdef SR_WINO_ABLATION   // (ablation builds: read per call, so that one process can sweep the switches)
+  { const char* e = getenv("SR_WINO_DEBUG"); p.debug = e ? atoi(e) : 0; }
+#else
+  p.debug = 0;
+#endif
   { const char* e = getenv("SR_WINO_XCD"); p.xcd_order = e ? atoi(e) : 1; }
   hipStream_t stream = (hipStream_t)stream_;
   int blocks = sr_wino_num_cus() * (nt == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES);
