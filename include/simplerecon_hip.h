@@ -93,6 +93,19 @@ int sr_gemm1x1_nhwc_fwd(const float* in, int in_pix_stride, const float* weight,
  * MBConv blocks (reference experiment_modules/depth_model.py:110-116).  Needs Cin % 4 == 0 and 16-byte aligned input rows
  * (sr_pw_conv_supported; SR_ERR_UNSUPPORTED otherwise -> sr_conv2d_nhwc_fwd).  sr_pw_conv_plan reports the launch plan
  * (32-channel tiles per wave, K split across the waves of a workgroup) chosen for a shape. */
+/* LDS-tiled form of the same operator for BATCH-DENSE views (batch stride = HW * pixel stride, so the M = B * HW pixel rows
+ * are one strided matrix): a workgroup stages (64 | 128) x 32 input and 32 x (64 | 128 | 160) weight tiles through LDS,
+ * double-buffered -- each operand byte crosses the CU's vector-memory path once per workgroup instead of once per wave,
+ * which is what the MBConv expand / project GEMMs of the image-prior encoder (M = 2 400 ... 9 600) need.  Small problems
+ * split K across workgroups: raw partial tiles go to `workspace` (sr_pw_conv_tiled_workspace_bytes; may be null: no
+ * split) and are added in index order (deterministic).  Same arguments otherwise; sr_pw_conv_tiled_plan reports the tile
+ * configuration (0: 64x128, 1: 128x160, 2: 128x64, 3: 64x64) and the K split chosen for a shape. */
+size_t sr_pw_conv_tiled_workspace_bytes(int M, int Cin, int Cout);
+int sr_pw_conv_tiled_plan(int M, int Cin, int Cout, int can_split, int* cfg, int* ks);
+int sr_pw_conv_tiled_nhwc_fwd(const float* in, int in_pix_stride, const float* packed_w, const float* bias,
+                              const float* gate, const float* residual, int res_pix_stride, float* out,
+                              int out_pix_stride, int M, int HW, int Cin, int Cout, float act_code, void* workspace,
+                              size_t workspace_bytes, void* stream);
 int sr_pw_conv_supported(int Cin, int Cout);
 int sr_pw_conv_plan(int B, int HW, int Cin, int Cout, int* nt, int* ks);
 int sr_pw_conv_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_w,

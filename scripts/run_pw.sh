@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_conv.py -q -x -k "pointwise or library" 2>&1 | tail -5
-timeout 900 python -m pytest tests/test_gpu_image_encoder.py tests/test_gpu_depth_model.py -q -x 2>&1 | tail -3
-for m in lib pw lib pw; do SR_CONV1X1_GEMM=$m timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m', round(d['value'],1), round(d['ms_per_step'],2))"; done
-for m in lib pw; do echo "== $m"; SR_CONV1X1_GEMM=$m timeout 300 python scripts/effnet_micro.py 2>&1 | grep -v amdgpu | grep "stage\|whole\|block1"; done
+(echo "== direct kernel (sr_pw_kernel), forced plans: channel tiles per wave x K split across the waves"; python scripts/pw_sweep.py 2>&1 | grep -v amdgpu
+ echo "== LDS-tiled kernel (sr_pw_tiled_kernel), forced plans: tile config (0: 64x128, 1: 128x160, 2: 128x64, 3: 64x64) x K split across workgroups"; SR_SWEEP_TILED=1 python scripts/pw_sweep.py 2>&1 | grep -v amdgpu) > gpurun_out/pw_plan_sweep.txt
+for m in 0 auto 0 auto; do SR_PW_TILED=$m timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tiled=$m', round(d['value'],1), round(d['ms_per_step'],2))"; done

@@ -51,8 +51,12 @@ struct SrPwParams {
   float slope;
 };
 
-constexpr int PW_U = 4;    // rotating operand register sets (the K loop is unrolled by U)
-constexpr int PW_PD = 3;   // loads run PD groups ahead of their MFMAs
+#ifndef SR_PW_U
+#define SR_PW_U 4
+#define SR_PW_PD 3
+#endif
+constexpr int PW_U = SR_PW_U;    // rotating operand register sets (the K loop is unrolled by U)
+constexpr int PW_PD = SR_PW_PD;  // loads run PD groups ahead of their MFMAs
 
 template <int NT, int KS, bool GATE>
 __global__ __launch_bounds__(256, 2) void sr_pw_kernel(SrPwParams p) {

@@ -189,6 +189,12 @@ _GEMM_W = weakref.WeakKeyDictionary()  # nn.Conv2d (1x1) -> (state key, [Cout, C
 # per process); "0" = the implicit-GEMM conv kernel for everything.
 _MODE_1X1 = os.environ.get("SR_CONV1X1_GEMM", "pw")
 USE_PW_1X1 = _MODE_1X1 not in ("0", "lib", "1")
+# which of the two pointwise kernels: "auto" = the LDS-tiled one for batch-dense maps of at least PW_TILED_MIN_ROWS pixels
+# (the HBM-bound full-resolution skips: 168 vs 182 us for 192 -> 64 @ 8x240x320), the direct one below that -- on the small-M
+# encoder GEMMs the tiled kernel's one or two workgroups per CU cannot hide their load latency and it measured no faster
+# (38 vs 36 us for 1536 -> 256 @ 8x15x20, profiles/r04_pw_plan_sweep.txt); "1" / "0" force one of them
+PW_TILED = os.environ.get("SR_PW_TILED", "auto")
+PW_TILED_MIN_ROWS = 100000
 USE_GEMM_1X1 = _MODE_1X1 in ("lib", "1")
 GEMM_1X1_MIN_PIXELS = 1024
 SHORTCUT_GEMM = os.environ.get("SR_SHORTCUT_GEMM", "1") != "0"   # BasicBlock's 1x1 skip conv as a library GEMM
@@ -332,23 +338,42 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
     if k == 1 and s == 1 and not padded and not replicate and (USE_PW_1X1 or gate is not None) and ci % 4 == 0 \
             and x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0:
         wp, bias = packed_weight(conv, bn)
+        m = b * h * w
+        dense = (b == 1 or (isb == h * w * isp and osb == h * w * osp and (residual is None or rsb == h * w * rsp)))
+        tiled = dense and (PW_TILED == "1" or (PW_TILED == "auto" and m >= PW_TILED_MIN_ROWS))
+        gflag = 'true' if gate is not None else 'false'
         with _lib.on_device(x.device):
+            if tiled:
+                nbytes = _shape_query(lib, "sr_pw_conv_tiled_workspace_bytes", m, ci, co)
+                ws = _workspace(x.device, "pw_splitk", nbytes) if nbytes else None
             if prof is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            rc = lib.sr_pw_conv_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(gate),
-                                         _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h * w, ci, co,
-                                         C.c_float(_act_code(leaky, act)), _lib.stream_ptr(x.device))
+            if tiled:
+                rc = lib.sr_pw_conv_tiled_nhwc_fwd(_lib.ptr(x), isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(gate),
+                                                   _lib.ptr(residual), rsp, _lib.ptr(out), osp, m, h * w, ci, co,
+                                                   C.c_float(_act_code(leaky, act)), _lib.ptr(ws), nbytes,
+                                                   _lib.stream_ptr(x.device))
+            else:
+                rc = lib.sr_pw_conv_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(gate),
+                                             _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h * w, ci, co,
+                                             C.c_float(_act_code(leaky, act)), _lib.stream_ptr(x.device))
             if prof is not None:
                 ev1.record()
-                nt, ks = C.c_int(0), C.c_int(0)
-                lib.sr_pw_conv_plan(b, h * w, ci, co, C.byref(nt), C.byref(ks))
-                mt = b * ((h * w + 31) // 32)
-                executed = 2.0 * mt * 32 * ((co + 32 * nt.value - 1) // (32 * nt.value) * 32 * nt.value) * ((ci + 7) // 8 * 8)
-                prof.append((f"sr_pw_kernel<{nt.value}, {ks.value}, {'true' if gate is not None else 'false'}>",
-                             2.0 * b * h * w * co * ci, ev0, ev1, (b, ci, h, w, co, k, s, ho, wo, residual is not None),
+                a_, b_ = C.c_int(0), C.c_int(0)
+                if tiled:
+                    lib.sr_pw_conv_tiled_plan(m, ci, co, int(ws is not None), C.byref(a_), C.byref(b_))
+                    bm, bn = ((64, 128), (128, 160), (128, 64), (64, 64))[a_.value]
+                    executed = 2.0 * (-(-m // bm) * bm) * (-(-co // bn) * bn) * (-(-ci // 32) * 32)
+                    name = f"sr_pw_tiled_kernel<{bm}x{bn}, ks {b_.value}, {gflag}>"
+                else:
+                    lib.sr_pw_conv_plan(b, h * w, ci, co, C.byref(a_), C.byref(b_))
+                    mt = b * ((h * w + 31) // 32)
+                    executed = 2.0 * mt * 32 * ((co + 32 * a_.value - 1) // (32 * a_.value) * 32 * a_.value) * ((ci + 7) // 8 * 8)
+                    name = f"sr_pw_kernel<{a_.value}, {b_.value}, {gflag}>"
+                prof.append((name, 2.0 * b * h * w * co * ci, ev0, ev1, (b, ci, h, w, co, k, s, ho, wo, residual is not None),
                              executed))
-        _lib.check(rc, "sr_pw_conv_nhwc_fwd")
+        _lib.check(rc, "sr_pw_conv_tiled_nhwc_fwd" if tiled else "sr_pw_conv_nhwc_fwd")
         return out
     if gate is not None:
         raise _lib.HipLibraryError("a gated 1x1 convolution needs Cin % 4 == 0 and 16-byte aligned input rows")

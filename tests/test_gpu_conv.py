@@ -236,12 +236,61 @@ PW_SHAPES = [  # (B, Cin, Cout, h, w, act, residual, gate)
 
 
 @pytest.mark.parametrize("shape", PW_SHAPES)
+@pytest.mark.parametrize("plan", [None, (0, 1), (0, 4), (1, 1), (1, 2), (2, 1), (3, 2), (3, 8)])
+def test_pointwise_gemm_tiled_kernel(shape, plan, monkeypatch):
+    """sr_pw_conv_tiled_nhwc_fwd (csrc/sr_pw_tiled.hip): the LDS-tiled form of the same operator on batch-dense maps --
+    every tile configuration (64x128, 128x160, 128x64, 64x64) and K split (partials added in index order), gate per image
+    with pixel tiles that straddle images, ragged M / N / K tails, channel-slice operands -- against ATen in float64."""
+    B, ci, co, h, w, act, with_res, with_gate = shape
+    monkeypatch.setattr(ops, "PW_TILED", "1")
+    if plan is not None:
+        monkeypatch.setenv("SR_PT_CFG", str(plan[0]))
+        monkeypatch.setenv("SR_PT_KS", str(plan[1]))
+        if plan[1] > 1 and ((ci + 31) // 32 // plan[1] < 4 or co % 4):
+            pytest.skip("K too short (or Cout not in float4 quads) for this split")
+    ops._SHAPE_QUERIES.clear()
+    g = torch.Generator().manual_seed(ci * 5 + co)
+    conv = torch.nn.Conv2d(ci, co, 1).to(DEV)
+    bn = synthetic.seeded_fill_(torch.nn.BatchNorm2d(co).eval(), seed=2).to(DEV)
+    wide = torch.randn((B, ci + 8, h, w), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    x = wide[:, 4:4 + ci]
+    res = torch.randn((B, co, h, w), generator=g).to(DEV) if with_res else None
+    gate = torch.rand((B, ci), generator=g).to(DEV) if with_gate else None
+    kw = dict(act="silu") if act == "silu" else dict(leaky=0.0) if act == "relu" else dict(leaky=act) if act else {}
+    xr = x.double() * (gate.double()[:, :, None, None] if with_gate else 1.0)
+    bnd = torch.nn.BatchNorm2d(co).eval().double().to(DEV)
+    bnd.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    ref = bnd(torch.nn.functional.conv2d(xr, conv.weight.double(), conv.bias.double()))
+    if res is not None:
+        ref = ref + res.double()
+    ref = torch.nn.functional.silu(ref) if act == "silu" else torch.relu(ref) if act == "relu" else \
+        torch.nn.functional.leaky_relu(ref, act) if act else ref
+    with torch.inference_mode():
+        ops.PROFILE = []
+        co_buf = (co + 3) // 4 * 4 + 8
+        buf = ops.empty_nhwc(B, co_buf, h, w, DEV).fill_(3.0)
+        ops.conv2d(x, conv, bn=bn, residual=res, out=buf[:, 4:4 + co], gate=gate, **kw)
+        names = [r[0] for r in ops.PROFILE]
+        ops.PROFILE = None
+        again = ops.conv2d(x, conv, bn=bn, residual=res, gate=gate, **kw)
+    ops._SHAPE_QUERIES.clear()
+    assert names[0].startswith("sr_pw_tiled_kernel"), names
+    if plan is not None:
+        assert f"ks {plan[1]}," in names[0] and ("64x128", "128x160", "128x64", "64x64")[plan[0]] in names[0], names
+    assert bool((buf[:, :4] == 3).all()) and bool((buf[:, 4 + co:] == 3).all())
+    got = buf[:, 4:4 + co]
+    assert rel_err(got, ref.float().detach()) < 1e-5
+    assert torch.equal(got, again)      # fixed reduction order: bit-identical across calls and output layouts
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES)
 @pytest.mark.parametrize("plan", [None, (1, 1), (2, 2), (2, 4), (4, 1)])
 def test_pointwise_gemm_kernel(shape, plan, monkeypatch):
     """sr_pw_conv_nhwc_fwd (csrc/sr_pw.hip): the 1x1 convolution as a hand-written fp32-MFMA GEMM -- bias, BatchNorm fold,
     residual before the activation, SiLU / ReLU / LeakyReLU, the squeeze-excite gate on the input, channel-slice inputs
     and outputs, every launch plan (channel tiles per wave, K split 1 / 2 / 4) -- against ATen in float64; deterministic."""
     B, ci, co, h, w, act, with_res, with_gate = shape
+    monkeypatch.setattr(ops, "PW_TILED", "0")
     if plan is not None:
         monkeypatch.setenv("SR_PW_NT", str(plan[0]))
         monkeypatch.setenv("SR_PW_KS", str(plan[1]))
@@ -287,12 +336,16 @@ def test_pointwise_gemm_is_batch_independent_and_matches_the_conv_kernel(monkeyp
     conv = torch.nn.Conv2d(128, 96, 1).to(DEV)
     x = torch.randn((5, 128, 17, 23), generator=g).to(DEV)
     with torch.inference_mode():
-        all5 = ops.conv2d(x, conv, leaky=0.2)
-        one = ops.conv2d(x[3:4].contiguous(memory_format=torch.channels_last), conv, leaky=0.2)
+        outs = {}
+        for tiled in ("0", "1"):
+            monkeypatch.setattr(ops, "PW_TILED", tiled)
+            all5 = ops.conv2d(x, conv, leaky=0.2)
+            one = ops.conv2d(x[3:4].contiguous(memory_format=torch.channels_last), conv, leaky=0.2)
+            assert torch.equal(all5[3:4], one), tiled    # (fp32 accumulation in k order per output: tiling does not matter)
+            outs[tiled] = all5
         monkeypatch.setattr(ops, "USE_PW_1X1", False)
         old = ops.conv2d(x, conv, leaky=0.2)
-    assert torch.equal(all5[3:4], one)
-    assert rel_err(all5, old) < 1e-5
+    assert rel_err(outs["0"], old) < 1e-5 and rel_err(outs["1"], old) < 1e-5
 
 
 @pytest.mark.parametrize("shape", [(1, 24, 240, 320, 24, "silu"), (2, 32, 240, 320, 24, None), (1, 16, 240, 320, 24, 0.2),

@@ -144,7 +144,7 @@ def test_whole_model_control_flow(stub, prefer_wino, fvt):
     seen = set(stub)
     sweep = "sr_mlp_volume_fwd" if fvt == "mlp_feature_volume" else "sr_dot_volume_fwd"
     for name in (sweep, "sr_stem7x7_fwd", "sr_maxblurpool_nhwc_fwd", "sr_conv1x1_stats_nhwc_fwd", "sr_conv3x3_c16_nhwc_fwd",
-                 "sr_conv2d_padded_nhwc_fwd", "sr_dwconv3x3_nhwc_fwd", "sr_se_scale_nhwc_fwd", "sr_add_nhwc_fwd",
+                 "sr_conv2d_padded_nhwc_fwd", "sr_dwconv3x3_nhwc_fwd", "sr_se_gate2_fwd", "sr_pw_conv_nhwc_fwd", "sr_add_nhwc_fwd",
                  "sr_upsample2x_nhwc_fwd", "sr_exp_fwd",
                  "sr_conv3x3_wino_splitk_nhwc_fwd" if prefer_wino else "sr_conv2d_splitk_nhwc_fwd"):
         assert name in seen, name
