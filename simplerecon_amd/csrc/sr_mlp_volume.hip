@@ -404,13 +404,9 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
 
       // layer 2: the layer-1 accumulators, passed through LeakyReLU(slope) = max(v, slope*v) (networks.py:139,
       // 0 < slope < 1) on the fly, are the B operands; W2 streams from L2 three steps ahead
+      // (not zeroed: the first k-step takes the constant 0 as its C operand -- 128 v_mov per plane and wave otherwise)
       f32x16 acc2[2][4];
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc2[g][m][r] = 0.0f;
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const float4* w2 = (W2_LDS ? reinterpret_cast<const float4*>(lds + SR_LDS_W3_FLOATS) : gW2) + lane;
       if (!W2_LDS) asm volatile("" : "+v"(w2));  // keep hipcc from hoisting 65 loop-invariant 64-bit addresses (spills)
       float4 wn0 = w2[0], wn1 = w2[64], wn2 = w2[128];
@@ -422,14 +418,14 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
         if (!SR_MLP_DBG(1)) wn2 = w2[(size_t)min(t + 3, 64) * 64];
         const float aP = acc[0][t >> 4][t & 15], aQ = acc[1][t >> 4][t & 15];
         const float bP = sr_vmax_mfma(aP, p.slope * aP), bQ = sr_vmax_mfma(aQ, p.slope * aQ);
-        acc2[0][0] = SR_MFMA(wA.x, bP, acc2[0][0]);
-        acc2[1][0] = SR_MFMA(wA.x, bQ, acc2[1][0]);
-        acc2[0][1] = SR_MFMA(wA.y, bP, acc2[0][1]);
-        acc2[1][1] = SR_MFMA(wA.y, bQ, acc2[1][1]);
-        acc2[0][2] = SR_MFMA(wA.z, bP, acc2[0][2]);
-        acc2[1][2] = SR_MFMA(wA.z, bQ, acc2[1][2]);
-        acc2[0][3] = SR_MFMA(wA.w, bP, acc2[0][3]);
-        acc2[1][3] = SR_MFMA(wA.w, bQ, acc2[1][3]);
+        acc2[0][0] = SR_MFMA(wA.x, bP, t == 0 ? zero16 : acc2[0][0]);
+        acc2[1][0] = SR_MFMA(wA.x, bQ, t == 0 ? zero16 : acc2[1][0]);
+        acc2[0][1] = SR_MFMA(wA.y, bP, t == 0 ? zero16 : acc2[0][1]);
+        acc2[1][1] = SR_MFMA(wA.y, bQ, t == 0 ? zero16 : acc2[1][1]);
+        acc2[0][2] = SR_MFMA(wA.z, bP, t == 0 ? zero16 : acc2[0][2]);
+        acc2[1][2] = SR_MFMA(wA.z, bQ, t == 0 ? zero16 : acc2[1][2]);
+        acc2[0][3] = SR_MFMA(wA.w, bP, t == 0 ? zero16 : acc2[0][3]);
+        acc2[1][3] = SR_MFMA(wA.w, bQ, t == 0 ? zero16 : acc2[1][3]);
       }
       {
         const float4 wA = wn0;  // bias step (t = 64)
