@@ -118,6 +118,7 @@ struct SrMlpParams {
   int chunk, chunks;      // planes per work unit, ceil(D / chunk)
   float inv_w, inv_h, slope;
   int debug;              // ablation bits (env SR_MLP_DEBUG), 0 in production
+  int xcd_order;          // 1: each XCD (workgroup index mod 8) sweeps its own contiguous eighth of the work units
   int vec_store;          // channels-last volume (plane stride 1): a lane keeps the costs of its unit's planes and
                           // stores them as 16-byte pieces at the end of the unit (instead of one 4-byte store per plane
                           // into 64 different 256-byte rows: r02 PMC counted 6.7x the volume's bytes in WRITE_SIZE)
@@ -167,6 +168,9 @@ __device__ __forceinline__ void sr_l1_step_init(f32x16 (&acc)[2][4], const f32x1
 #define SR_MLP_DBG(bit) 0
 #endif
 
+#ifndef SR_MLP_NT_TAPS
+#define SR_MLP_NT_TAPS 0
+#endif
 #define SR_LDS_W3_FLOATS 256  // w3tab (128) + b3 + pad, in front of W1 in LDS
 
 template <bool W1_LDS, bool W2_LDS>
@@ -198,11 +202,24 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
 
   const int N = p.h * p.w;
   const long nunits = (long)p.B * p.tiles * p.chunks;
-  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  // XCD-aware work order (r04): workgroup b runs on XCD b % 8 and each XCD has its own 4 MB L2.  With units dealt round-robin
+  // every XCD touches every region of every source image (41 MB per keyframe at 15 views) and the tap reads miss its L2
+  // again and again (r03 PMC, cfg5: 1.2 GB of fabric traffic per launch for 244 MB of compulsory bytes).  Units are
+  // ordered (image, pixel tile, plane chunk): give XCD x the contiguous eighth [x U8, (x + 1) U8) -- a band of pixel tiles
+  // whose tap footprints overlap -- and let its waves stride through that band.
+  long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  long unit_end = nunits;
+  if (p.xcd_order && (gridDim.x & 7) == 0) {
+    const long u8 = (nunits + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    nwaves = (long)(gridDim.x >> 3) * (blockDim.x >> 6);
+    wave0 = xcd * u8 + (long)(blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    unit_end = min(nunits, (xcd + 1) * u8);
+  }
   const int half = lane >> 5;
 
-  for (long unit = wave0; unit < nunits; unit += nwaves) {
+  for (long unit = wave0; unit < unit_end; unit += nwaves) {
     const int chunk = (int)(unit % p.chunks);
     const long tb = unit / p.chunks;
     const int tile = (int)(tb % p.tiles);
@@ -282,7 +299,16 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
       if (!SR_MLP_DBG(2)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#if SR_MLP_NT_TAPS   // streaming policy for the taps: they should not push the W1 / W2 blocks of a streaming variant out of L2
+          typedef float nt_f4 __attribute__((ext_vector_type(4)));
+          auto ntl = [](const float4* q) {
+            const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(q));
+            return make_float4(v.x, v.y, v.z, v.w);
+          };
+          taps[i] = ntl(&t_nw[i]); taps[4 + i] = ntl(&t_ne[i]); taps[8 + i] = ntl(&t_sw[i]); taps[12 + i] = ntl(&t_se[i]);
+#else
           taps[i] = t_nw[i]; taps[4 + i] = t_ne[i]; taps[8 + i] = t_sw[i]; taps[12 + i] = t_se[i];
+#endif
         }
       }
     };
@@ -581,6 +607,7 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
   p.vec_store = (cv_sd == 1) && (p.chunk % 4 == 0) && (cv_sp % 4 == 0) && (cv_sb % 4 == 0) &&
                 (((uintptr_t)out_cv & 15) == 0);
   { const char* e = getenv("SR_MLP_VEC_STORE"); if (e && atoi(e) == 0) p.vec_store = 0; }   // ablation
+  { const char* e = getenv("SR_MLP_XCD"); p.xcd_order = e ? atoi(e) : 1; }
   const long nunits = (long)B * p.tiles * p.chunks;
   const int blocks = (int)((nunits + 3) / 4 < cus ? (nunits + 3) / 4 : cus);
   const size_t w3_bytes = SR_LDS_W3_FLOATS * sizeof(float);
