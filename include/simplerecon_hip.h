@@ -495,6 +495,15 @@ int sr_dwconv3x3_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_s
 int sr_se_gate_fwd(const float* pool_partial, int bands, int pixels, const float* w_reduce, const float* b_reduce,
                    const float* w_expand, const float* b_expand, float* gate, int B, int C, int rd, void* stream);
 
+/* EfficientNetV2's RGB stem (conv_stem of timm's tf_efficientnetv2_s, reference depth_model.py:110-116): act(conv3x3 /
+ * stride 2 (3 -> 24) + bias) with explicit top / left zero padding (TF-"SAME": 0 / 0 on even images, the odd pixel goes
+ * below / right), image read through its strides (NCHW or channels-last), output channels-last.  `weight27c` =
+ * [ky][kx][ci][24] with the eval-mode BatchNorm scale folded in.  Byte work (29 MB in, 59 MB out per 8 images): a VALU
+ * kernel, not the padded-K implicit GEMM.  Cout = 24 only (SR_ERR_UNSUPPORTED otherwise -> sr_conv2d_padded_nhwc_fwd). */
+int sr_rgb_stem3x3s2_fwd(const float* image, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* weight27c,
+                         const float* bias, float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W,
+                         int Cout, int pad_top, int pad_left, int Ho, int Wo, float act_code, void* stream);
+
 /* The squeeze-excite gates alone, gate[b][c] = sigmoid(W2 silu(W1 mean_b + b1) + b2)[c], from sr_dwconv3x3_nhwc_fwd's partial
  * sums (timm SqueezeExcite of the MBConv blocks, reference depth_model.py:110-116) for a consumer that applies them itself:
  * sr_pw_conv_nhwc_fwd(gate = ...) scales the projection's input while loading it.  `hidden`: scratch [B][rd]. */

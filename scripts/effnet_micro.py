@@ -23,8 +23,8 @@ def timed(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 with torch.inference_mode():
-    x = ops.conv2d(img, enc.conv_stem, bn=enc.bn1, act="silu", tf_same=True)
-    print(f"stem   {timed(lambda: ops.conv2d(img, enc.conv_stem, bn=enc.bn1, act='silu', tf_same=True)):8.3f} ms")
+    x = ops.rgb_stem3x3s2(img, enc.conv_stem, bn=enc.bn1, act="silu", tf_same=True)
+    print(f"stem   {timed(lambda: ops.rgb_stem3x3s2(img, enc.conv_stem, bn=enc.bn1, act='silu', tf_same=True)):8.3f} ms")
     tot = 0.0
     for i, stage in enumerate(enc.blocks):
         xin = x

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(f)):
         n[r["Kernel_Name"]] += 1
 rows = []
 for k, c in agg.items():
-    if c["SQ_VALU_MFMA_BUSY_CYCLES"] <= 0 or not k.startswith(("void sr_", "sr_")):
+    if c["SQ_VALU_MFMA_BUSY_CYCLES"] <= 0 or "sr_" not in k[:40]:
         continue
     cycles = c["GRBM_GUI_ACTIVE"] / 8.0
     rows.append((c["GRBM_GUI_ACTIVE"], k, n[k], c["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / n[k] / 1e9,

@@ -265,6 +265,50 @@ __global__ __launch_bounds__(256) void sr_add_kernel(const float* __restrict__ a
   }
 }
 
+// ---- RGB stem: conv 3x3 / stride 2 on a 3-channel image (any strides) -> COUT channels, channels-last ----
+// EfficientNetV2's conv_stem (3 -> 24, TF-"SAME": one row / column of zeros below / right on even images).  As an
+// implicit GEMM on the matrix cores its K = 27 pads to 9 x 16 channels and its input rows cannot be read as float4
+// (sr_conv_kernel<3,2,1,1,32,false>: 169 us per 8 images, 3 % of the MFMA peak).  It is 0.4 GFLOP on 29 MB in / 59 MB
+// out: byte work.  One lane = one output pixel x all COUT channels; the 27 x COUT weights are wave-uniform (scalar
+// loads, SGPR operands of the FMAs); lanes of a wave are consecutive pixels of a row, so the 27 input loads are
+// contiguous (stride 2) and the 6 float4 stores of a wave cover 6 KB without gaps.
+template <int COUT>
+__global__ __launch_bounds__(256) void sr_rgb_stem3x3s2_kernel(const float* __restrict__ img, int64_t sb, int64_t sc, int64_t sy,
+                                                               int64_t sx, const float* __restrict__ w /*[27][COUT]*/,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int64_t out_sb, int out_sp, int H, int W, int Ho, int Wo,
+                                                               int pad_y, int pad_x, float slope) {
+  const int b = blockIdx.y;
+  const int64_t npix = (int64_t)Ho * Wo;
+  for (int64_t pix = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+    const int oy = (int)(pix / Wo), ox = (int)(pix - (int64_t)oy * Wo);
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = bias ? bias[c] : 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - pad_y + ky;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - pad_x + kx;
+        const bool ok = (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+        const float* q = img + b * sb + (ok ? iy * sy + ix * sx : 0);
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          const float v = ok ? q[ci * sc] : 0.0f;
+          const float* wr = w + ((ky * 3 + kx) * 3 + ci) * COUT;
+#pragma unroll
+          for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+        }
+      }
+    }
+    sr_activate_group(acc, sr_uniform(slope));
+    float* o = out + b * out_sb + pix * out_sp;
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4) *reinterpret_cast<float4*>(o + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+  }
+}
+
 inline bool aligned16(const void* ptr) { return (((uintptr_t)ptr) & 15) == 0; }
 
 }  // namespace
@@ -357,6 +401,23 @@ extern "C" int sr_add_nhwc_fwd(const float* a, int64_t a_batch_stride, int a_pix
   dim3 grid(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks), B);
   hipLaunchKernelGGL(sr_add_kernel, grid, dim3(256), 0, (hipStream_t)stream_, a, a_batch_stride, a_pix_stride, b,
                      b_batch_stride, b_pix_stride, out, out_batch_stride, out_pix_stride, H * W, C / 4);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// act(conv3x3 / stride 2 (3 -> Cout) + bias) of an RGB image with explicit top / left zero padding (bottom / right: whatever
+// the output size needs); `weight27c` = [ky][kx][ci][Cout] with the eval-mode BatchNorm scale folded in.  Cout = 24 only.
+extern "C" int sr_rgb_stem3x3s2_fwd(const float* image, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* weight27c,
+                                    const float* bias, float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H,
+                                    int W, int Cout, int pad_top, int pad_left, int Ho, int Wo, float act_code, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || pad_top < 0 || pad_left < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!image || !weight27c || !out) return SR_ERR_INVALID_ARGUMENT;
+  if (Cout != 24 || out_pix_stride % 4 != 0 || out_batch_stride % 4 != 0 || !aligned16(out)) return SR_ERR_UNSUPPORTED;
+  if (2 * (Ho - 1) - pad_top >= H || 2 * (Wo - 1) - pad_left >= W) return SR_ERR_INVALID_ARGUMENT;   // a window with no pixel
+  const int64_t npix = (int64_t)Ho * Wo;
+  const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+  hipLaunchKernelGGL((sr_rgb_stem3x3s2_kernel<24>), dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, image, sb, sc, sy, sx,
+                     weight27c, bias, out, out_batch_stride, out_pix_stride, H, W, Ho, Wo, pad_top, pad_left, act_code);
   return sr_hip_rc(hipGetLastError());
 }
 

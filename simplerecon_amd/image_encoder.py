@@ -179,7 +179,7 @@ class EfficientNetV2SFeatures(nn.Module):
                 if i in FEATURE_STAGES:
                     feats.append(x)
             return feats
-        x = ops.conv2d(image, self.conv_stem, bn=self.bn1, act="silu", tf_same=True)
+        x = ops.rgb_stem3x3s2(image, self.conv_stem, bn=self.bn1, act="silu", tf_same=True)
         feats = []
         for i, stage in enumerate(self.blocks):
             x = stage(x)

@@ -815,6 +815,44 @@ def se_gate(pool_partial, pixels, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2d
     return gate
 
 
+_PACKED_RGB = weakref.WeakKeyDictionary()  # stem nn.Conv2d -> (state key, [27, Cout] weight with BN folded, bias)
+
+
+def rgb_stem3x3s2(image, conv: nn.Conv2d, bn=None, act=None, leaky=None, tf_same=True):
+    """act(bn(conv3x3_s2(image))) for a 3-channel image (EfficientNetV2's conv_stem): a VALU kernel that reads the image
+    through its strides; returns a channels-last [B, Cout, Ho, Wo] tensor.  Falls back to conv2d for other layers."""
+    _lib.require_device_f32("image", image)
+    _lib.refuse_autograd(image, conv.weight)
+    if conv.kernel_size != (3, 3) or conv.stride != (2, 2) or conv.in_channels != 3 or conv.groups != 1 or \
+            conv.out_channels != 24 or image.dim() != 4 or image.shape[1] != 3:
+        return conv2d(image, conv, bn=bn, act=act, leaky=leaky, tf_same=tf_same)
+    b, _, h, w = image.shape
+    pads = tf_same_pads(h, w, 3, 2) if tf_same else (1, 1, 1, 1)
+    ho, wo = (h + pads[0] + pads[2] - 3) // 2 + 1, (w + pads[1] + pads[3] - 3) // 2 + 1
+    key = _state_key(conv, bn)
+    hit = _PACKED_RGB.get(conv)
+    if hit is None or hit[0] != key:
+        wt, bias = _effective_weight(conv, bn)                          # [Cout, 3, 3, 3]
+        w27 = wt.permute(2, 3, 1, 0).reshape(27, conv.out_channels).contiguous()   # [ky][kx][ci][Cout]
+        hit = (key, w27, bias.contiguous() if bias is not None else None)
+        _packed_here(conv, "rgb", conv.weight.device)
+        _PACKED_RGB[conv] = hit
+    else:
+        _await_packed(conv, "rgb", conv.weight.device)
+    _, w27, bias = hit
+    out = empty_nhwc(b, conv.out_channels, ho, wo, image.device)
+    if b == 0:
+        return out
+    sb, sc, sy, sx = image.stride()
+    osb, osp = _strides(out)
+    with _lib.on_device(image.device):
+        rc = _lib.lib().sr_rgb_stem3x3s2_fwd(_lib.ptr(image), sb, sc, sy, sx, _lib.ptr(w27), _lib.ptr(bias), _lib.ptr(out), osb,
+                                             osp, b, h, w, conv.out_channels, pads[0], pads[1], ho, wo,
+                                             C.c_float(_act_code(leaky, act)), _lib.stream_ptr(image.device))
+    _lib.check(rc, "sr_rgb_stem3x3s2_fwd")
+    return out
+
+
 def se_gates(pool_partial, pixels, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2d):
     """[B, C] squeeze-excite gates from dwconv3x3's partial sums (two short launches); the consumer -- conv2d(..., gate=) --
     applies them to its input while loading it, so the gated map is never written."""

@@ -174,3 +174,29 @@ def test_refuses_training_mode_and_cpu():
     enc.train()
     feats = enc(torch.randn(2, 3, 64, 64, device=DEV))
     assert all(f.requires_grad for f in feats) and [f.shape[1] for f in feats] == [24, 48, 64, 160, 256]
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 73, 89), (3, 480, 640), (1, 2, 2)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_rgb_stem_kernel(shape, channels_last):
+    """sr_rgb_stem3x3s2_fwd (conv_stem 3 -> 24, stride 2, TF-"SAME", folded BatchNorm, SiLU as a VALU kernel) against ATen in
+    float64 and against the implicit-GEMM path it replaces; NCHW and channels-last images, even and odd sizes."""
+    import torch.nn.functional as F
+    from simplerecon_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * 3 + W)
+    conv = torch.nn.Conv2d(3, 24, 3, stride=2, padding=1, bias=False).to(DEV)
+    bn = synthetic.seeded_fill_(torch.nn.BatchNorm2d(24, eps=1e-3).eval(), seed=5).to(DEV)
+    img = torch.randn((B, 3, H, W), generator=g).to(DEV)
+    if channels_last:
+        img = img.contiguous(memory_format=torch.channels_last)
+    pt, pl, pb, pr = ops.tf_same_pads(H, W, 3, 2)
+    scale, shift = ops.bn_affine(bn)
+    ref = F.conv2d(F.pad(img.double(), (pl, pr, pt, pb)), conv.weight.double(), None, stride=2)
+    ref = F.silu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    with torch.inference_mode():
+        got = ops.rgb_stem3x3s2(img, conv, bn=bn, act="silu", tf_same=True)
+        old = ops.conv2d(img, conv, bn=bn, act="silu", tf_same=True)
+    assert tuple(got.shape) == tuple(ref.shape) == (B, 24, -(-H // 2), -(-W // 2))
+    assert_close(got, ref.float(), tol=1e-5, what="rgb stem vs ATen")
+    assert_close(got, old, tol=1e-5, what="rgb stem vs implicit GEMM")
