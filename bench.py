@@ -20,6 +20,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The step runs on 4 HIP streams (main, image-prior encoder, two decoder branches); an RCCL process group brings its own.  With
+# ROCm's default of 4 hardware queues per process the fifth stream shares a queue with one of ours and the streams serialise
+# against each other: +0.45 ms per step (1.6 %) from nothing but `init_process_group("nccl")` (scripts/pg_probe.py, r04).
+# Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -175,13 +181,22 @@ def main():
     with torch.inference_mode():
         for _ in range(args.warmup):
             wl.step()
+        if collective and args.warmup > 0:
+            # the job's gather once, untimed: RCCL sets its point-to-point channels up at the first use of a collective
+            # (~10 ms), which is start-up cost, not part of a steady-state step; the timed region below gathers again
+            wl.finish(world, force_collective=args.force_collective)
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             wl.step(i)
+        t_loop = time.perf_counter() - t0
         wl.finish(world, force_collective=args.force_collective)  # result gather to rank 0 (RCCL) -- part of the job
+        t_fin = time.perf_counter() - t0
         barrier()
         elapsed = time.perf_counter() - t0
+        if os.environ.get("SR_BENCH_TRACE"):
+            print(f"[rank {rank}] steps issued {t_loop*1e3:.2f} ms, + gather issued {t_fin*1e3:.2f} ms, + barrier/sync {elapsed*1e3:.2f} ms",
+                  file=sys.stderr, flush=True)
     dump = os.environ.get("SR_BENCH_DUMP")   # tests: the gathered result of the job, as rank 0 holds it
     if dump and rank == 0 and getattr(wl, "gathered", None) is not None:
         import numpy as np
