@@ -93,6 +93,21 @@ int sr_gemm1x1_nhwc_fwd(const float* in, int in_pix_stride, const float* weight,
  * MBConv blocks (reference experiment_modules/depth_model.py:110-116).  Needs Cin % 4 == 0 and 16-byte aligned input rows
  * (sr_pw_conv_supported; SR_ERR_UNSUPPORTED otherwise -> sr_conv2d_nhwc_fwd).  sr_pw_conv_plan reports the launch plan
  * (32-channel tiles per wave, K split across the waves of a workgroup) chosen for a shape. */
+/* 16-bit activation I/O (training under torch.autocast; reference options.py:100-101 `precision: 16`, train.py:132): the
+ * same two operators on fp16 (io_dtype = 1) / bf16 (io_dtype = 2) input / residual / output tensors (strides in ELEMENTS;
+ * four channels = one 8-byte access, 8-byte aligned rows), widened to fp32 on load and rounded to nearest even on store;
+ * weights (packed as for the fp32 entry points), bias, transforms and the MFMA accumulation stay fp32.  The result equals the
+ * fp32 entry point's result on the widened inputs, rounded once.  io_dtype = 0 forwards to the fp32 entry point.  The
+ * Winograd form never splits K; the pointwise form takes no gate. */
+int sr_conv3x3_wino_io_nhwc_fwd(const void* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u,
+                                const float* bias, const void* residual, int64_t res_batch_stride, int res_pix_stride,
+                                void* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                                int Cout, float leaky_slope, int io_dtype, void* stream);
+int sr_pw_conv_io_nhwc_fwd(const void* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_w,
+                           const float* bias, const void* residual, int64_t res_batch_stride, int res_pix_stride, void* out,
+                           int64_t out_batch_stride, int out_pix_stride, int B, int HW, int Cin, int Cout, float act_code,
+                           int io_dtype, void* stream);
+
 /* LDS-tiled form of the same operator for BATCH-DENSE views (batch stride = HW * pixel stride, so the M = B * HW pixel rows
  * are one strided matrix): a workgroup stages (64 | 128) x 32 input and 32 x (64 | 128 | 160) weight tiles through LDS,
  * double-buffered -- each operand byte crosses the CU's vector-memory path once per workgroup instead of once per wave,

@@ -28,10 +28,15 @@ src = {"image_b3hw": torch.from_numpy(rng.standard_normal((B, K, 3, H, W)).astyp
        "K_s1_b44": inp["src_Ks"], "cam_T_world_b44": inp["src_extrinsics"], "world_T_cam_b44": inp["src_poses"]}
 
 
+AMP = os.environ.get("SR_TRAIN_AUTOCAST", "")   # "" (fp32), "fp16" or "bf16": the step inside torch.autocast
+AMP_DT = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(AMP)
+
+
 def step():
     model.zero_grad(set_to_none=True)
-    out = model("train", cur, src)
-    loss = sum(out[f"log_depth_pred_s{i}_b1hw"].abs().mean() for i in range(4))
+    with torch.autocast("cuda", dtype=AMP_DT or torch.float16, enabled=AMP_DT is not None):
+        out = model("train", cur, src)
+        loss = sum(out[f"log_depth_pred_s{i}_b1hw"].float().abs().mean() for i in range(4))
     loss.backward()
 
 

@@ -34,6 +34,8 @@ SIGNATURES = {
     "sr_gemm1x1_nhwc_fwd": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "sr_rgb_stem3x3s2_fwd": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "sr_se_gate2_fwd": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "sr_conv3x3_wino_io_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "sr_pw_conv_io_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _f, _i, _p]),
     "sr_pw_conv_tiled_workspace_bytes": (_sz, [_i, _i, _i]),
     "sr_pw_conv_tiled_plan": (_i, [_i, _i, _i, _i, _p, _p]),
     "sr_pw_conv_tiled_nhwc_fwd": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _sz, _p]),

@@ -48,6 +48,47 @@ def _amp_fwd(fwd):
 # dtype and widened again when the backward kernel needs it.  A tensor saved by several operators (a producer saves its
 # output for the activation's derivative, the consumer saves it as its input) is narrowed once and shared.
 STORE_HALF = os.environ.get("SR_AUTOCAST_HALF_STORAGE", "1") != "0"
+# 16-bit KERNEL I/O under torch.autocast (r04; SR_AUTOCAST_HALF_IO=0: fp32 kernels + 16-bit storage as in r03).  Inside an
+# autocast region the convolutions of the conv stack (BasicBlock / CVEncoder / DepthDecoderPP: _ConvBiasAct) read and write
+# their activations in the autocast dtype -- the Winograd and pointwise kernels load four fp16 / bf16 channels as one 8-byte
+# access, widen them on the way into LDS / registers, accumulate in fp32 (fp32 weights, fp32 MFMA) and round the result once
+# on the way out (sr_conv3x3_wino_io_nhwc_fwd, sr_pw_conv_io_nhwc_fwd); what flows between the layers and what autograd saves
+# is 16-bit, like the reference's `precision: 16` training (options.py:100-101, train.py:132), with fp32 instead of fp16
+# accumulation inside a layer.  The backward kernels (weight / bias gradients, activation derivative, data gradient) run on
+# fp32 copies of the saved tensors; stride-2 and explicitly padded convolutions convert at their boundary.
+HALF_IO = os.environ.get("SR_AUTOCAST_HALF_IO", "1") != "0"
+_IO_CODE = {torch.float16: 1, torch.bfloat16: 2}
+
+
+def _amp_state_fwd(fwd):
+    """Like `_amp_fwd` but WITHOUT casting the inputs: records the caller's autocast state on ctx and runs the body with
+    autocast off; the operator decides what dtype its kernels read and write."""
+    def wrapper(ctx, *args, **kwargs):
+        on = torch.is_autocast_enabled("cuda")
+        ctx._sr_autocast = on
+        ctx._sr_autocast_dtype = torch.get_autocast_dtype("cuda") if on else None
+        with torch.autocast(device_type="cuda", enabled=False):
+            return fwd(ctx, *args, **kwargs)
+    wrapper.__name__, wrapper.__doc__ = getattr(fwd, "__name__", "forward"), fwd.__doc__
+    return wrapper
+
+
+def _amp_state_bwd(bwd):
+    def wrapper(ctx, *grads):
+        with torch.autocast(device_type="cuda", enabled=False):
+            return bwd(ctx, *grads)
+    wrapper.__name__, wrapper.__doc__ = getattr(bwd, "__name__", "backward"), bwd.__doc__
+    return wrapper
+
+
+def _nhwc_any(t, name):
+    """A channels-last view of a CUDA tensor of any of the I/O dtypes (fp32 / fp16 / bf16)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        raise _lib.HipLibraryError(f"{name}: expected a CUDA fp32 / fp16 / bf16 tensor, got {getattr(t, 'dtype', type(t))} on "
+                                   f"{getattr(t, 'device', '?')}")
+    if t.dim() != 4:
+        raise ValueError(f"{name} must be [B,C,H,W], got {tuple(t.shape)}")
+    return t if _is_nhwc_view(t) else t.contiguous(memory_format=torch.channels_last)
 
 
 def _stash(ctx, *tensors):
@@ -124,9 +165,54 @@ def _dense_nhwc(t):
     return t
 
 
+def _conv_raw_io(x, weight, bias, stride, residual, slope, pads):
+    """_conv_raw on fp16 / bf16 activations: 16-bit kernel I/O where the kernel has it (3x3 / stride 1 through Winograd,
+    1x1 / stride 1 through the pointwise GEMM), boundary conversion around the fp32 kernel otherwise."""
+    lib = _lib.lib()
+    dt = x.dtype
+    x = _nhwc_any(x, "conv input")
+    b, ci, h, w = x.shape
+    co, ci_w, k, _ = weight.shape
+    if ci_w != ci:
+        raise ValueError(f"conv weight expects {ci_w} input channels, got {ci}")
+    if residual is not None:
+        residual = _nhwc_any(residual if residual.dtype == dt else residual.to(dt), "residual")
+    wino = pads is None and stride == 1 and k == 3 and b > 0 and ci % 4 == 0 and co % 4 == 0 and \
+        bool(lib.sr_conv_prefers_wino(b, h, w, ci, co, k, stride))
+    pw = pads is None and stride == 1 and k == 1 and b > 0 and ci % 4 == 0
+    aligned = x.data_ptr() % 8 == 0 and _strides(x)[1] % 4 == 0 and _strides(x)[0] % 4 == 0 and \
+        (residual is None or (residual.data_ptr() % 8 == 0 and _strides(residual)[1] % 4 == 0 and _strides(residual)[0] % 4 == 0))
+    if not ((wino or pw) and aligned):
+        y = _conv_raw(x.float(), weight, bias, stride, residual.float() if residual is not None else None, slope, pads)
+        return y.to(dt)
+    out = torch.empty((b, co, h, w), dtype=dt, device=x.device, memory_format=torch.channels_last)
+    wd = weight.detach().float().contiguous()
+    st = _lib.stream_ptr(x.device)
+    isb, isp = _strides(x)
+    osb, osp = _strides(out)
+    rsb, rsp = _strides(residual) if residual is not None else (0, 0)
+    bd = bias.detach().float().contiguous() if bias is not None else None
+    sl = C.c_float(-1.0 if slope is None else float(slope))
+    with _lib.on_device(x.device):
+        if wino:
+            wp = torch.empty(lib.sr_wino_packed_weight_floats(co, ci), dtype=torch.float32, device=x.device)
+            _lib.check(lib.sr_wino_pack_weights(_lib.ptr(wd), co, ci, _lib.ptr(wp), st), "sr_wino_pack_weights")
+            rc = lib.sr_conv3x3_wino_io_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bd), _lib.ptr(residual), rsb, rsp,
+                                                 _lib.ptr(out), osb, osp, b, h, w, ci, co, sl, _IO_CODE[dt], st)
+        else:
+            wp = torch.empty(lib.sr_conv_packed_weight_floats(co, ci, 1), dtype=torch.float32, device=x.device)
+            _lib.check(lib.sr_conv_pack_weights(_lib.ptr(wd), co, ci, 1, _lib.ptr(wp), st), "sr_conv_pack_weights")
+            rc = lib.sr_pw_conv_io_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bd), _lib.ptr(residual), rsb, rsp,
+                                            _lib.ptr(out), osb, osp, b, h * w, ci, co, sl, _IO_CODE[dt], st)
+    _lib.check(rc, "conv forward (16-bit I/O)")
+    return out
+
+
 def _conv_raw(x, weight, bias, stride, residual=None, slope=None, pads=None):
     """act(conv(x, weight) + bias [+ residual]) on the inference kernels with a weight TENSOR [Co, Ci, k, k]
     (packed on the fly; padding k // 2, or explicit (top, left, bottom, right) zero `pads`)."""
+    if x.dtype in _IO_CODE:
+        return _conv_raw_io(x, weight, bias, stride, residual, slope, pads)
     lib = _lib.lib()
     x = as_nhwc(x, "conv input")
     b, ci, h, w = x.shape
@@ -175,11 +261,25 @@ class _ConvBiasAct(torch.autograd.Function):
     the valid convolution behind the matching encoder's replicate pad)."""
 
     @staticmethod
-    @_amp_fwd
+    @_amp_state_fwd
     def forward(ctx, x, weight, bias, residual, stride, slope, pads=None):
-        for name, t in (("conv input", x), ("conv weight", weight)):
-            _lib.require_device_f32(name, t)
-        x = as_nhwc(x, "conv input")
+        # activation dtype of this layer: the autocast dtype with 16-bit kernel I/O, fp32 otherwise (inputs that arrive
+        # in another floating dtype are cast: a differentiable cast, gradients go back in the caller's dtype)
+        dt = ctx._sr_autocast_dtype if (ctx._sr_autocast and HALF_IO and ctx._sr_autocast_dtype in _IO_CODE) else torch.float32
+        if not ctx._sr_autocast:   # outside autocast the path is fp32 only, loudly (as everywhere in this package)
+            for name, t in (("conv input", x), ("conv weight", weight)) + ((("residual", residual),) if residual is not None else ()):
+                _lib.require_device_f32(name, t)
+        ctx.in_dtypes = (x.dtype, residual.dtype if residual is not None else None)
+        x = x if x.dtype == dt else x.to(dt)
+        if residual is not None and residual.dtype != dt:
+            residual = residual.to(dt)
+        weight = weight if weight.dtype == torch.float32 else weight.float()
+        if bias is not None and bias.dtype != torch.float32:
+            bias = bias.float()
+        if dt == torch.float32:
+            for name, t in (("conv input", x), ("conv weight", weight)):
+                _lib.require_device_f32(name, t)
+            x = as_nhwc(x, "conv input")
         out = _conv_raw(x, weight, bias, stride, residual, slope, pads)
         ctx.stride, ctx.slope, ctx.pads = stride, slope, pads
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
@@ -187,9 +287,12 @@ class _ConvBiasAct(torch.autograd.Function):
         return out
 
     @staticmethod
-    @_amp_bwd
+    @_amp_state_bwd
     def backward(ctx, g):
         x, weight, out = _unstash(ctx)
+        # (16-bit I/O: the backward kernels take fp32 copies of what the forward saved in 16 bits)
+        x = x if x.dtype == torch.float32 else x.float()
+        out = out if (out is None or out.dtype == torch.float32) else out.float()
         lib = _lib.lib()
         dev = x.device
         b, ci, h, w = x.shape
@@ -262,7 +365,13 @@ class _ConvBiasAct(torch.autograd.Function):
                     d_x = _conv_raw(src, wt, None, 1, pads=(k - 1 - pads[0], k - 1 - pads[1], k - 1 - pads[2], k - 1 - pads[3]))
                 else:          # the stuffed gradient lives on the input's H x W grid: output H x W needs (k-1-pt, k-1-pl, pt, pl)
                     d_x = _conv_raw(src, wt, None, 1, pads=(k - 1 - pads[0], k - 1 - pads[1], pads[0], pads[1]))
-        return d_x, d_w, d_b, (gp if (ctx.has_res and need_r) else None), None, None, None
+        d_r = gp if (ctx.has_res and need_r) else None
+        xdt, rdt = ctx.in_dtypes
+        if d_x is not None and d_x.dtype != xdt:
+            d_x = d_x.to(xdt)
+        if d_r is not None and d_r.dtype != rdt:
+            d_r = d_r.to(rdt)
+        return d_x, d_w, d_b, d_r, None, None, None
 
 
 class _Upsample2x(torch.autograd.Function):

@@ -35,6 +35,38 @@ typedef unsigned int pw_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ pw_f4 pw_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(pw_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
+// 16-bit activation I/O (IO = 1: fp16, 2: bf16; 0 = fp32): input / residual / output elements are 2 bytes in HBM, widened on
+// load and rounded to nearest even on store; gate, weights, bias and the accumulation stay fp32 (training under autocast).
+typedef unsigned int pw_u2 __attribute__((ext_vector_type(2)));
+template <int IO>
+__device__ __forceinline__ float pw_widen(unsigned short h) {
+  if (IO == 1) return (float)__builtin_bit_cast(_Float16, h);
+  return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+template <int IO>
+__device__ __forceinline__ unsigned short pw_narrow(float f) {
+  if (IO == 1) return __builtin_bit_cast(unsigned short, (_Float16)f);
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+template <int IO>
+__device__ __forceinline__ pw_f4 pw_load_a(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if (IO == 0) return __builtin_bit_cast(pw_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+  const pw_u2 v = __builtin_bit_cast(pw_u2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+  return pw_f4{pw_widen<IO>((unsigned short)(v.x & 0xffffu)), pw_widen<IO>((unsigned short)(v.x >> 16)),
+               pw_widen<IO>((unsigned short)(v.y & 0xffffu)), pw_widen<IO>((unsigned short)(v.y >> 16))};
+}
+template <int IO>
+__device__ __forceinline__ float pw_load_elem(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if (IO == 0) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+  return pw_widen<IO>(__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0));
+}
+template <int IO>
+__device__ __forceinline__ void pw_store_elem(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if (IO == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+  else __builtin_amdgcn_raw_buffer_store_b16(pw_narrow<IO>(v), r, (int)voff, (int)soff, 0);
+}
+#define PW_ES(io) ((io) == 0 ? 4u : 2u)
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pw_rsrc(const void* base, int64_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, PW_RSRC_FLAGS);
 }
@@ -58,8 +90,9 @@ struct SrPwParams {
 constexpr int PW_U = SR_PW_U;    // rotating operand register sets (the K loop is unrolled by U)
 constexpr int PW_PD = SR_PW_PD;  // loads run PD groups ahead of their MFMAs
 
-template <int NT, int KS, bool GATE>
+template <int NT, int KS, bool GATE, int IO = 0>
 __global__ __launch_bounds__(256, 2) void sr_pw_kernel(SrPwParams p) {
+  constexpr unsigned ES = PW_ES(IO);   // bytes per activation element
   extern __shared__ __attribute__((aligned(16))) float red[];   // KS > 1: [m local][KS - 1][NT][16][64]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,13 +113,14 @@ __global__ __launch_bounds__(256, 2) void sr_pw_kernel(SrPwParams p) {
   const int g1 = min(p.G8, g0 + per);
   const int steps = live && g1 > g0 ? (g1 - g0 + PW_U - 1) / PW_U * PW_U : 0;
 
-  const __amdgpu_buffer_rsrc_t rs_in = pw_rsrc(p.in + (int64_t)img * p.in_sb, ((int64_t)(p.HW - 1) * p.in_sp + p.Cin) * 4);
+  const __amdgpu_buffer_rsrc_t rs_in = pw_rsrc(reinterpret_cast<const char*>(p.in) + (int64_t)img * p.in_sb * ES,
+                                               ((int64_t)(p.HW - 1) * p.in_sp + p.Cin) * ES);
   const __amdgpu_buffer_rsrc_t rs_w = pw_rsrc(p.wp, (int64_t)p.G * 2 * p.Co_pad * 16);
   const __amdgpu_buffer_rsrc_t rs_g = pw_rsrc(GATE ? p.gate + (int64_t)img * p.Cin : p.wp, GATE ? (int64_t)p.Cin * 4 : 0);
   const int row = row0 + i;
   // lane offsets (bytes): the group index rides in the scalar offset.  A lane whose row is past the image, or whose
   // channel quad is past Cin (Cin % 8 == 4, last group), reads through an out-of-range offset: 0.
-  const unsigned a_voff = (row < p.HW) ? ((unsigned)row * (unsigned)p.in_sp + 4u * kk) * 4u : PW_OOB;
+  const unsigned a_voff = (row < p.HW) ? ((unsigned)row * (unsigned)p.in_sp + 4u * kk) * ES : PW_OOB;
   const bool k_tail = (p.Cin & 7) != 0;
   const unsigned w_voff = (unsigned)(kk * p.Co_pad + n0 + i) * 16u;
   const unsigned g_voff = 16u * kk;
@@ -103,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void sr_pw_kernel(SrPwParams p) {
     const bool in_range = g < g1;
     unsigned av = in_range ? a_voff : PW_OOB;
     if (k_tail && 8 * g + 4 * kk + 4 > p.Cin) av = PW_OOB;
-    a_f[slot] = pw_load(rs_in, av, (unsigned)g * 32u);
+    a_f[slot] = pw_load_a<IO>(rs_in, av, (unsigned)g * 8u * ES);
     if (GATE) s_f[slot] = pw_load(rs_g, g_voff + (unsigned)g * 32u, 0u);   // (lane offset: past Cin -> out of range -> 0)
     const unsigned gw = (unsigned)min(g, g_last_w);
 #pragma unroll
@@ -148,18 +182,19 @@ __global__ __launch_bounds__(256, 2) void sr_pw_kernel(SrPwParams p) {
   // ---- epilogue: + bias + residual, activation, store.  Lane (i, kk) holds column n0 + 32 n + i of rows
   // row0 + (r & 3) + 8 (r >> 2) + 4 kk: a wave's store covers 2 rows x 128 contiguous bytes.
   const float slope = sr_uniform(p.slope);
-  const float* resb = p.res ? p.res + (int64_t)img * p.res_sb : nullptr;
-  const __amdgpu_buffer_rsrc_t rs_out = pw_rsrc(p.out + (int64_t)img * p.out_sb, ((int64_t)(p.HW - 1) * p.out_sp + p.Cout) * 4);
+  const char* resb = p.res ? reinterpret_cast<const char*>(p.res) + (int64_t)img * p.res_sb * ES : nullptr;
+  const __amdgpu_buffer_rsrc_t rs_out = pw_rsrc(reinterpret_cast<char*>(p.out) + (int64_t)img * p.out_sb * ES,
+                                                ((int64_t)(p.HW - 1) * p.out_sp + p.Cout) * ES);
   const __amdgpu_buffer_rsrc_t rs_res = pw_rsrc(resb ? (const void*)resb : (const void*)p.wp,
-                                                resb ? ((int64_t)(p.HW - 1) * p.res_sp + p.Cout) * 4 : (int64_t)0);
+                                                resb ? ((int64_t)(p.HW - 1) * p.res_sp + p.Cout) * ES : (int64_t)0);
   const bool full = (row0 + 32 <= p.HW) & (n0 + 32 * NT <= p.Cout);   // uniform
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int col = n0 + 32 * n + i;
     const bool okc = col < p.Cout;
     const float bv = (p.bias && okc) ? p.bias[col] : 0.0f;
-    const unsigned o_base = ((unsigned)(row0 + 4 * kk) * (unsigned)p.out_sp + (unsigned)col) * 4u;
-    const unsigned r_base = ((unsigned)(row0 + 4 * kk) * (unsigned)p.res_sp + (unsigned)col) * 4u;
+    const unsigned o_base = ((unsigned)(row0 + 4 * kk) * (unsigned)p.out_sp + (unsigned)col) * ES;
+    const unsigned r_base = ((unsigned)(row0 + 4 * kk) * (unsigned)p.res_sp + (unsigned)col) * ES;
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[n][r] + bv;
@@ -169,8 +204,7 @@ __global__ __launch_bounds__(256, 2) void sr_pw_kernel(SrPwParams p) {
       for (int r = 0; r < 16; ++r) {
         const int dr = (r & 3) + 8 * (r >> 2);
         const bool ok = full || (okc && row0 + 4 * kk + dr < p.HW);
-        rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)(ok ? r_base : PW_OOB),
-                                                                                 (int)((unsigned)dr * (unsigned)p.res_sp * 4u), 0));
+        rv[r] = pw_load_elem<IO>(rs_res, ok ? r_base : PW_OOB, (unsigned)dr * (unsigned)p.res_sp * ES);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] += rv[r];
@@ -180,8 +214,7 @@ __global__ __launch_bounds__(256, 2) void sr_pw_kernel(SrPwParams p) {
     for (int r = 0; r < 16; ++r) {
       const int dr = (r & 3) + 8 * (r >> 2);
       const bool ok = full || (okc && row0 + 4 * kk + dr < p.HW);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rs_out, (int)(ok ? o_base : PW_OOB),
-                                            (int)((unsigned)dr * (unsigned)p.out_sp * 4u), 0);
+      pw_store_elem<IO>(v[r], rs_out, ok ? o_base : PW_OOB, (unsigned)dr * (unsigned)p.out_sp * ES);
     }
   }
 }
@@ -234,11 +267,13 @@ PwPlan pw_plan(int B, int HW, int Cin, int Cout) {
 }
 
 template <int NT, int KS>
-int pw_launch(const SrPwParams& p, hipStream_t stream) {
+int pw_launch(const SrPwParams& p, hipStream_t stream, int io) {
   const int mt_per_wg = 4 / KS;
   const long wgs = ((long)p.total_mt + mt_per_wg - 1) / mt_per_wg * p.n_blocks;
   const size_t lds = KS > 1 ? (size_t)mt_per_wg * (KS - 1) * NT * 16 * 64 * sizeof(float) : 0;
-  if (p.gate) hipLaunchKernelGGL((sr_pw_kernel<NT, KS, true>), dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  if (io == 1) hipLaunchKernelGGL((sr_pw_kernel<NT, KS, false, 1>), dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  else if (io == 2) hipLaunchKernelGGL((sr_pw_kernel<NT, KS, false, 2>), dim3((unsigned)wgs), dim3(256), lds, stream, p);
+  else if (p.gate) hipLaunchKernelGGL((sr_pw_kernel<NT, KS, true>), dim3((unsigned)wgs), dim3(256), lds, stream, p);
   else hipLaunchKernelGGL((sr_pw_kernel<NT, KS, false>), dim3((unsigned)wgs), dim3(256), lds, stream, p);
   return sr_hip_rc(hipGetLastError());
 }
@@ -257,16 +292,17 @@ extern "C" int sr_pw_conv_plan(int B, int HW, int Cin, int Cout, int* nt, int* k
   return SR_OK;
 }
 
-extern "C" int sr_pw_conv_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_w,
-                                   const float* bias, const float* gate, const float* residual, int64_t res_batch_stride,
-                                   int res_pix_stride, float* out, int64_t out_batch_stride, int out_pix_stride, int B,
-                                   int HW, int Cin, int Cout, float act_code, void* stream_) {
-  if (B < 0 || HW <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
+static int pw_run(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_w,
+                  const float* bias, const float* gate, const float* residual, int64_t res_batch_stride,
+                  int res_pix_stride, float* out, int64_t out_batch_stride, int out_pix_stride, int B,
+                  int HW, int Cin, int Cout, float act_code, void* stream_, int io) {
+  if (B < 0 || HW <= 0 || Cin <= 0 || Cout <= 0 || io < 0 || io > 2) return SR_ERR_INVALID_ARGUMENT;
   if (B == 0) return SR_OK;
   if (!in || !packed_w || !out) return SR_ERR_INVALID_ARGUMENT;
-  if (Cin % 4 != 0 || in_pix_stride % 4 != 0 || in_batch_stride % 4 != 0 || (((uintptr_t)in) & 15) != 0 ||
+  if (io && gate) return SR_ERR_UNSUPPORTED;   // (the gated projection is an inference path: fp32)
+  if (Cin % 4 != 0 || in_pix_stride % 4 != 0 || in_batch_stride % 4 != 0 || (((uintptr_t)in) & (io ? 7 : 15)) != 0 ||
       (gate && (((uintptr_t)gate) & 15) != 0))
-    return SR_ERR_UNSUPPORTED;   // 16-byte A fragments
+    return SR_ERR_UNSUPPORTED;   // 4-channel A fragments (16 bytes of fp32, 8 of fp16 / bf16)
   const int64_t lim = (int64_t)1 << 31;
   if (((int64_t)(HW - 1) * in_pix_stride + Cin) * 4 >= lim || ((int64_t)(HW - 1) * out_pix_stride + Cout) * 4 >= lim ||
       (residual && ((int64_t)(HW - 1) * res_pix_stride + Cout) * 4 >= lim))
@@ -287,14 +323,33 @@ extern "C" int sr_pw_conv_nhwc_fwd(const float* in, int64_t in_batch_stride, int
   p.n_blocks = (p.Co_pad / 32 + pl.nt - 1) / pl.nt;
   hipStream_t stream = (hipStream_t)stream_;
   switch (pl.nt * 10 + pl.ks) {
-    case 11: return pw_launch<1, 1>(p, stream);
-    case 12: return pw_launch<1, 2>(p, stream);
-    case 14: return pw_launch<1, 4>(p, stream);
-    case 21: return pw_launch<2, 1>(p, stream);
-    case 22: return pw_launch<2, 2>(p, stream);
-    case 24: return pw_launch<2, 4>(p, stream);
-    case 41: return pw_launch<4, 1>(p, stream);
-    case 51: return pw_launch<5, 1>(p, stream);
+    case 11: return pw_launch<1, 1>(p, stream, io);
+    case 12: return pw_launch<1, 2>(p, stream, io);
+    case 14: return pw_launch<1, 4>(p, stream, io);
+    case 21: return pw_launch<2, 1>(p, stream, io);
+    case 22: return pw_launch<2, 2>(p, stream, io);
+    case 24: return pw_launch<2, 4>(p, stream, io);
+    case 41: return pw_launch<4, 1>(p, stream, io);
+    case 51: return pw_launch<5, 1>(p, stream, io);
     default: return SR_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int sr_pw_conv_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_w,
+                                   const float* bias, const float* gate, const float* residual, int64_t res_batch_stride,
+                                   int res_pix_stride, float* out, int64_t out_batch_stride, int out_pix_stride, int B,
+                                   int HW, int Cin, int Cout, float act_code, void* stream_) {
+  return pw_run(in, in_batch_stride, in_pix_stride, packed_w, bias, gate, residual, res_batch_stride, res_pix_stride, out,
+                out_batch_stride, out_pix_stride, B, HW, Cin, Cout, act_code, stream_, 0);
+}
+
+// The same operator on fp16 (io_dtype = 1) / bf16 (2) activation tensors (input, residual, output; strides in ELEMENTS);
+// weights, bias and the accumulation stay fp32.  No gate (the gated projection is an inference path).
+extern "C" int sr_pw_conv_io_nhwc_fwd(const void* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_w,
+                                      const float* bias, const void* residual, int64_t res_batch_stride, int res_pix_stride,
+                                      void* out, int64_t out_batch_stride, int out_pix_stride, int B, int HW, int Cin, int Cout,
+                                      float act_code, int io_dtype, void* stream_) {
+  return pw_run((const float*)in, in_batch_stride, in_pix_stride, packed_w, bias, nullptr, (const float*)residual,
+                res_batch_stride, res_pix_stride, (float*)out, out_batch_stride, out_pix_stride, B, HW, Cin, Cout, act_code,
+                stream_, io_dtype);
 }

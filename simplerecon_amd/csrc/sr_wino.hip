@@ -89,8 +89,43 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void* base, int6
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, WN_RSRC_FLAGS);
 }
 
-template <int NT, bool VEC4, bool VOUT>
+// ---- 16-bit activation I/O (r04; training under torch.autocast, reference options.py:100-101 / train.py:132) ----
+// IO = 0: fp32 tensors (inference, the measured path).  IO = 1 / 2: the input, the residual and the output are fp16 / bf16
+// tensors in HBM -- four channels are ONE 8-byte load or store --, widened to fp32 on the way into LDS and rounded (to
+// nearest even) on the way out; weights, bias, the transforms and the MFMA accumulation stay fp32.  Offsets are in bytes,
+// so only the element size changes: WN_ES(IO).
+#define WN_ES(io) ((io) == 0 ? 4u : 2u)
+typedef unsigned int wn_u2 __attribute__((ext_vector_type(2)));
+template <int IO>
+__device__ __forceinline__ float wn_widen(unsigned short h) {
+  if (IO == 1) return (float)__builtin_bit_cast(_Float16, h);
+  return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+template <int IO>
+__device__ __forceinline__ unsigned short wn_narrow(float f) {
+  if (IO == 1) return __builtin_bit_cast(unsigned short, (_Float16)f);
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+template <int IO>
+__device__ __forceinline__ float4 wn_io_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if (IO == 0) return wn_buf_load(r, voff, soff);
+  const wn_u2 v = __builtin_bit_cast(wn_u2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+  return make_float4(wn_widen<IO>((unsigned short)(v.x & 0xffffu)), wn_widen<IO>((unsigned short)(v.x >> 16)),
+                     wn_widen<IO>((unsigned short)(v.y & 0xffffu)), wn_widen<IO>((unsigned short)(v.y >> 16)));
+}
+template <int IO>
+__device__ __forceinline__ void wn_io_store(const float4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if (IO == 0) { wn_buf_store(v, r, voff, soff); return; }
+  wn_u2 t;
+  t.x = (unsigned)wn_narrow<IO>(v.x) | ((unsigned)wn_narrow<IO>(v.y) << 16);
+  t.y = (unsigned)wn_narrow<IO>(v.z) | ((unsigned)wn_narrow<IO>(v.w) << 16);
+  __builtin_amdgcn_raw_buffer_store_b64(t, r, (int)(voff + soff), 0, 0);
+}
+
+template <int NT, bool VEC4, bool VOUT, int IO = 0>
 __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) void sr_wino_kernel(SrWinoParams p) {
+  static_assert(IO == 0 || (VEC4 && VOUT), "16-bit I/O exists for the vector staging / epilogue instantiation only");
+  constexpr unsigned ES = WN_ES(IO);   // bytes per activation element
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* O = lds;                           // [4 ur][2][32 tiles][32*NT co]   (epilogue only; aliases raw A)
   float* rawA = lds + WN_V_FLOATS(NT);      // [10*18][20]  odd slabs  (inside the O area: dead by the epilogue)
@@ -158,21 +193,21 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
   unsigned s_org = 0;
   const float* in_b = p.in;
   __amdgpu_buffer_rsrc_t rs_in = wn_rsrc(p.in, 0);
-  const int64_t in_img_bytes = ((int64_t)(p.H * p.W - 1) * p.in_sp + p.Cin) * 4;
+  const int64_t in_img_bytes = ((int64_t)(p.H * p.W - 1) * p.in_sp + p.Cin) * ES;
   const int c_quad = 4 * (tid & 3);      // (tid + 256 it) & 3 == tid & 3: a thread stages the same channel quad of a slab
   auto aim = [&](const Region& r) {  // point the staging loads at region r
-    in_b = p.in + (int64_t)r.b * p.in_sb;
+    in_b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in) + (int64_t)r.b * p.in_sb * ES);
     if (VEC4) {
       rs_in = wn_rsrc(in_b, in_img_bytes);
       const bool interior = (r.oy0 >= 1) & (r.oy0 + 2 * WN_TR + 1 <= p.H) & (r.ox0 >= 1) & (r.ox0 + 2 * WN_TC + 1 <= p.W);
       if (interior) {   // no image test: offsets relative to the patch origin, which rides in the scalar operand
-        s_org = (unsigned)(((r.oy0 - 1) * p.W + (r.ox0 - 1)) * p.in_sp * 4);
+        s_org = (unsigned)(((r.oy0 - 1) * p.W + (r.ox0 - 1)) * p.in_sp) * ES;
 #pragma unroll
         for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) {
           const int e = tid + it * 256;
           const int px = e >> 2;
           const int py = px / WN_PW, pxx = px - py * WN_PW;
-          offs[it] = (it < WN_STAGE_PER_THREAD - 1 || e < WN_STAGE_ELEMS) ? ((py * p.W + pxx) * p.in_sp + c_quad) * 4
+          offs[it] = (it < WN_STAGE_PER_THREAD - 1 || e < WN_STAGE_ELEMS) ? (int)(((py * p.W + pxx) * p.in_sp + c_quad) * ES)
                                                                           : (int)WN_OOB;
         }
       } else {
@@ -184,7 +219,7 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
           const int py = px / WN_PW, pxx = px - py * WN_PW;
           const int iy = r.oy0 - 1 + py, ix = r.ox0 - 1 + pxx;
           const bool ok = (e < WN_STAGE_ELEMS) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
-          offs[it] = ok ? ((iy * p.W + ix) * p.in_sp + c_quad) * 4 : (int)WN_OOB;
+          offs[it] = ok ? (int)(((iy * p.W + ix) * p.in_sp + c_quad) * ES) : (int)WN_OOB;
         }
       }
     } else {
@@ -202,14 +237,14 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
   const bool c_tail = (p.Cin & 15) != 0;   // the last slab is cut by Cin: channel quads at or beyond it read 0
   auto stage_load = [&](int c0, float4 (&stg)[WN_STAGE_PER_THREAD]) {
     if (VEC4) {
-      const unsigned so = s_org + (unsigned)c0 * 4u;
+      const unsigned so = s_org + (unsigned)c0 * ES;
       if (c_tail && c0 + c_quad >= p.Cin) {   // (lane-divergent only in the last slab of a ragged channel count)
 #pragma unroll
         for (int it = 0; it < WN_STAGE_PER_THREAD; ++it) stg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
 #pragma unroll
         for (int it = 0; it < WN_STAGE_PER_THREAD; ++it)
-          stg[it] = SR_WN_DBG(4) ? make_float4(0.f, 0.f, 0.f, 0.f) : wn_buf_load(rs_in, (unsigned)offs[it], so);
+          stg[it] = SR_WN_DBG(4) ? make_float4(0.f, 0.f, 0.f, 0.f) : wn_io_load<IO>(rs_in, (unsigned)offs[it], so);
       }
     } else {
 #pragma unroll
@@ -424,9 +459,12 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
 
     // ---- epilogue: Y = A^T M A, + bias + residual, LeakyReLU, store ----
     const bool partial = p.ksplit > 1;
-    const float* __restrict__ resp = (p.res && !partial) ? p.res + (int64_t)b * p.res_sb : nullptr;
+    // (image bases in BYTES of the activation element: with 16-bit I/O p.res / p.out point at fp16 / bf16 data; the
+    // split-K partial workspace is always fp32 and 16-bit I/O launches never split K)
+    const float* __restrict__ resp = (p.res && !partial)
+        ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.res) + (int64_t)b * p.res_sb * ES) : nullptr;
     float* __restrict__ outp = partial ? p.part + reg.ks * p.part_stride + (int64_t)b * p.H * p.W * p.Cout
-                                       : p.out + (int64_t)b * p.out_sb;
+                                       : reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + (int64_t)b * p.out_sb * ES);
     const unsigned out_sp = partial ? (unsigned)p.Cout : (unsigned)p.out_sp;
     const float* bias_p = partial ? nullptr : p.bias;
     const float slope = sr_uniform(partial ? -1.0f : p.slope);   // scalar: the activation code is tested once per group
@@ -467,10 +505,10 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
         const int cg = tid % CG;
         const int tile0 = tid / CG;
         const int tr0 = tile0 >> 3, tc0 = tile0 & 7;
-        const __amdgpu_buffer_rsrc_t rs_out = wn_rsrc(outp, ((int64_t)(p.H * p.W - 1) * out_sp + p.Cout) * 4);
+        const __amdgpu_buffer_rsrc_t rs_out = wn_rsrc(outp, ((int64_t)(p.H * p.W - 1) * out_sp + p.Cout) * ES);
         const __amdgpu_buffer_rsrc_t rs_res =
             wn_rsrc(resp ? (const void*)resp : (const void*)p.wu,
-                    resp ? ((int64_t)(p.H * p.W - 1) * p.res_sp + p.Cout) * 4 : (int64_t)0);
+                    resp ? ((int64_t)(p.H * p.W - 1) * p.res_sp + p.Cout) * ES : (int64_t)0);
         const __amdgpu_buffer_rsrc_t rs_bias = wn_rsrc(bias_p ? (const void*)bias_p : (const void*)p.wu,
                                                        bias_p ? (int64_t)p.Cout * 4 : (int64_t)0);
         const bool okc = co0 + 4 * cg < p.Cout;
@@ -480,9 +518,9 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
         const bool full = (oy0 + 2 * WN_TR <= p.H) & (ox0 + 2 * WN_TC <= p.W) & (co0 + CO <= p.Cout);   // uniform
 #endif
         const unsigned pix0 = (unsigned)((2 * tr0) * p.W + 2 * tc0);
-        const unsigned v_out = (pix0 * out_sp + 4u * cg) * 4u, v_res = (pix0 * (unsigned)p.res_sp + 4u * cg) * 4u;
-        const unsigned s_out0 = ((unsigned)(oy0 * p.W + ox0) * out_sp + (unsigned)co0) * 4u;
-        const unsigned s_res0 = ((unsigned)(oy0 * p.W + ox0) * (unsigned)p.res_sp + (unsigned)co0) * 4u;
+        const unsigned v_out = (pix0 * out_sp + 4u * cg) * ES, v_res = (pix0 * (unsigned)p.res_sp + 4u * cg) * ES;
+        const unsigned s_out0 = ((unsigned)(oy0 * p.W + ox0) * out_sp + (unsigned)co0) * ES;
+        const unsigned s_res0 = ((unsigned)(oy0 * p.W + ox0) * (unsigned)p.res_sp + (unsigned)co0) * ES;
         auto d_pix = [&](int it, int q) {   // scalar: pixel delta of (unit, pixel) from the unit-0 / pixel-0 position
           return (unsigned)((2 * TILE_ROWS_PER_UNIT * it + (q >> 1)) * p.W + (q & 1));
         };
@@ -499,7 +537,7 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
         float neg1s = -1.0f;
         asm volatile("" : "+s"(neg1s));
         const wn_f2 neg1 = {neg1s, neg1s};
-        unsigned rsp4 = (unsigned)p.res_sp * 4u, osp4 = out_sp * 4u;   // (pinned: the eight scalar deltas are recomputed per
+        unsigned rsp4 = (unsigned)p.res_sp * ES, osp4 = out_sp * ES;   // (pinned: the eight scalar deltas are recomputed per
         SR_WN_PIN("+s"(rsp4), "+s"(osp4));                             //  region on the SALU, not parked in VGPR lanes)
         const bool fast_leaky = slope >= 0.0f && slope <= 1.0f;        // LeakyReLU as max(v, slope v): v_pk_mul + 2 v_max per pair
         const wn_f2 slope2 = {slope, slope};
@@ -522,7 +560,7 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
             for (int it = 0; it < UNITS; ++it)
 #pragma unroll
               for (int q = 0; q < 4; ++q)
-                rv[it][q] = wn_buf_load(rs_res, lane_off(v_res, it, q), s_res0 + d_pix(it, q) * rsp4);
+                rv[it][q] = wn_io_load<IO>(rs_res, lane_off(v_res, it, q), s_res0 + d_pix(it, q) * rsp4);
           }
           const float4 bv = wn_buf_load(rs_bias, (FULL || okc) ? 16u * cg : WN_OOB, (unsigned)co0 * 4u);
           SR_TR(10);
@@ -573,7 +611,7 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               if (!SR_WN_DBG(1) || o16[4 * q] == 1.2345e33f)
-                wn_buf_store(make_float4(o16[4 * q], o16[4 * q + 1], o16[4 * q + 2], o16[4 * q + 3]), rs_out,
+                wn_io_store<IO>(make_float4(o16[4 * q], o16[4 * q + 1], o16[4 * q + 2], o16[4 * q + 3]), rs_out,
                              lane_off(v_out, it, q), s_out0 + d_pix(it, q) * osp4);
             }
           }
@@ -784,7 +822,9 @@ extern "C" const char* sr_wino_kernel_name(int B, int H, int W, int Cin, int Cou
 static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u,
                        const float* bias, const float* residual, int64_t res_batch_stride, int res_pix_stride,
                        float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin, int Cout,
-                       float leaky_slope, void* workspace, size_t workspace_bytes, void* stream_) {
+                       float leaky_slope, void* workspace, size_t workspace_bytes, void* stream_, int io = 0) {
+  if (io < 0 || io > 2) return SR_ERR_INVALID_ARGUMENT;
+  const uintptr_t amask = io ? 7 : 15;   // 4 channels = 16 bytes of fp32 or 8 bytes of fp16 / bf16
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (B == 0) return SR_OK;
   if (!in || !packed_u || !out) return SR_ERR_INVALID_ARGUMENT;
@@ -799,13 +839,18 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   p.regions_x = (W + 2 * WN_TC - 1) / (2 * WN_TC);
   p.regions_y = (H + 2 * WN_TR - 1) / (2 * WN_TR);
   p.slope = leaky_slope;
-  p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0) && (Cin % 4 == 0);
-  // vector epilogue: whole float4 channel groups, 16-byte aligned output / residual / bias rows
-  const bool vout = p.vec4 && (Cout % 4 == 0) && (((uintptr_t)out & 15) == 0) && (out_pix_stride % 4 == 0) &&
+  p.vec4 = (((uintptr_t)in & amask) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0) && (Cin % 4 == 0);
+  // vector epilogue: whole 4-channel groups, aligned output / residual / bias rows
+  const bool vout = p.vec4 && (Cout % 4 == 0) && (((uintptr_t)out & amask) == 0) && (out_pix_stride % 4 == 0) &&
                     (out_batch_stride % 4 == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
-                    (!residual || ((((uintptr_t)residual & 15) == 0) && (res_pix_stride % 4 == 0) &&
+                    (!residual || ((((uintptr_t)residual & amask) == 0) && (res_pix_stride % 4 == 0) &&
                                    (res_batch_stride % 4 == 0)));
-  const bool can_split = vout && workspace && (((uintptr_t)workspace & 15) == 0);
+  if (io && !vout) return SR_ERR_UNSUPPORTED;   // 16-bit I/O: the vector instantiation only
+  const int64_t lim = (int64_t)1 << 31;          // per-image byte offsets are 32-bit (buffer addressing)
+  if (vout && (((int64_t)(H * W - 1) * in_pix_stride + Cin) * 4 >= lim || ((int64_t)(H * W - 1) * out_pix_stride + Cout) * 4 >= lim ||
+               (residual && ((int64_t)(H * W - 1) * res_pix_stride + Cout) * 4 >= lim)))
+    return SR_ERR_UNSUPPORTED;
+  const bool can_split = !io && vout && workspace && (((uintptr_t)workspace & 15) == 0);   // (partials are fp32: fp32 I/O only)
   SrWinoPlan plan = sr_wino_plan(B, H, W, Cin, Cout, can_split);
   if (plan.ks > 1 && workspace_bytes < (size_t)plan.ks * B * H * W * Cout * sizeof(float))
     plan = sr_wino_plan(B, H, W, Cin, Cout, false);
@@ -834,6 +879,13 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   (void)hipMemsetAsync(trace_buf, 0, trace_n * 8, stream);
   p.trace = trace_buf;
 #endif
+#define SR_WINO_LAUNCH_IO(NTV, IOV)                                                                              \
+  {                                                                                                               \
+    hipError_t e = hipFuncSetAttribute((const void*)sr_wino_kernel<NTV, true, true, IOV>,                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+    if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
+    hipLaunchKernelGGL((sr_wino_kernel<NTV, true, true, IOV>), dim3(blocks), dim3(256), lds, stream, p);          \
+  }
 #define SR_WINO_LAUNCH(NTV, V4, VO)                                                                               \
   {                                                                                                               \
     hipError_t e = hipFuncSetAttribute((const void*)sr_wino_kernel<NTV, V4, VO>,                                  \
@@ -841,13 +893,18 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
     if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
     hipLaunchKernelGGL((sr_wino_kernel<NTV, V4, VO>), dim3(blocks), dim3(256), lds, stream, p);                   \
   }
-  if (nt == 2 && vout) SR_WINO_LAUNCH(2, true, true)
+  if (io == 1 && nt == 2) SR_WINO_LAUNCH_IO(2, 1)
+  else if (io == 1) SR_WINO_LAUNCH_IO(1, 1)
+  else if (io == 2 && nt == 2) SR_WINO_LAUNCH_IO(2, 2)
+  else if (io == 2) SR_WINO_LAUNCH_IO(1, 2)
+  else if (nt == 2 && vout) SR_WINO_LAUNCH(2, true, true)
   else if (nt == 2 && p.vec4) SR_WINO_LAUNCH(2, true, false)
   else if (nt == 2) SR_WINO_LAUNCH(2, false, false)
   else if (vout) SR_WINO_LAUNCH(1, true, true)
   else if (p.vec4) SR_WINO_LAUNCH(1, true, false)
   else SR_WINO_LAUNCH(1, false, false)
 #undef SR_WINO_LAUNCH
+#undef SR_WINO_LAUNCH_IO
 #ifdef SR_WINO_TRACE
   {
     const char* path = getenv("SR_WINO_TRACE_FILE");
@@ -877,6 +934,17 @@ extern "C" int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride
                                         int Cout, float leaky_slope, void* stream_) {
   return sr_wino_run(in, in_batch_stride, in_pix_stride, packed_u, bias, residual, res_batch_stride, res_pix_stride, out,
                      out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, leaky_slope, nullptr, 0, stream_);
+}
+
+// The same operator on fp16 (io_dtype = 1) / bf16 (2) activation tensors: input, residual and output in HBM are 16-bit
+// (strides in ELEMENTS), weights / bias / transforms / accumulation fp32; io_dtype = 0 is sr_conv3x3_wino_nhwc_fwd.
+extern "C" int sr_conv3x3_wino_io_nhwc_fwd(const void* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u,
+                                           const float* bias, const void* residual, int64_t res_batch_stride,
+                                           int res_pix_stride, void* out, int64_t out_batch_stride, int out_pix_stride, int B,
+                                           int H, int W, int Cin, int Cout, float leaky_slope, int io_dtype, void* stream_) {
+  return sr_wino_run((const float*)in, in_batch_stride, in_pix_stride, packed_u, bias, (const float*)residual,
+                     res_batch_stride, res_pix_stride, (float*)out, out_batch_stride, out_pix_stride, B, H, W, Cin, Cout,
+                     leaky_slope, nullptr, 0, stream_, io_dtype);
 }
 
 extern "C" int sr_conv3x3_wino_splitk_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,

@@ -352,6 +352,8 @@ def test_training_step_under_autocast_runs_the_fp32_kernels(monkeypatch):
 
     ref_out, ref_g, bytes_fp32 = step(False)
     scale = float(np.median([float(v.pow(2).mean().sqrt()) for v in ref_g.values()]))
+    # (a) + (b): the fp32-kernel mode (SR_AUTOCAST_HALF_IO=0, the r03 behaviour); 16-bit kernel I/O (the r04 default) is (c)
+    monkeypatch.setattr(autograd_ops, "HALF_IO", False)
     # (a) fp32 storage under autocast: the same numbers
     monkeypatch.setattr(autograd_ops, "STORE_HALF", False)
     out, g, bytes_a = step(True)
@@ -368,6 +370,16 @@ def test_training_step_under_autocast_runs_the_fp32_kernels(monkeypatch):
     errs = {n: rel_l2(g[n], ref_g[n], floor=1e-2 * scale) for n in g}
     assert all(torch.isfinite(v).all() for v in g.values()) and max(errs.values()) < 5e-2 and np.median(list(errs.values())) < 5e-3, \
         (max(errs.values()), np.median(list(errs.values())))
+    # (c) 16-bit kernel I/O in the conv stack (default): the forward now carries fp16 activations between the layers of
+    # CVEncoder / DepthDecoderPP -- half-precision agreement with the fp32 run, every gradient finite
+    monkeypatch.setattr(autograd_ops, "HALF_IO", True)
+    out_c, g_c, bytes_c = step(True)
+    assert out_c["depth_pred_s0_b1hw"].dtype == torch.float32 and torch.isfinite(out_c["depth_pred_s0_b1hw"]).all()
+    assert rel_err(out_c["depth_pred_s0_b1hw"], ref_out["depth_pred_s0_b1hw"]) < 5e-2 and bytes_c < 0.6 * bytes_fp32
+    errs_c = {n: rel_l2(g_c[n], ref_g[n], floor=1e-2 * scale) for n in g_c}
+    assert sorted(g_c) == sorted(ref_g) and all(torch.isfinite(v).all() for v in g_c.values())
+    assert np.median(list(errs_c.values())) < 5e-2, (max(errs_c.values()), np.median(list(errs_c.values())))
+    monkeypatch.setattr(autograd_ops, "HALF_IO", False)
     # half-precision images (a caller that casts its batch): upcast at the first operator, fp32 from there on
     out_h, _, _ = step(True, half_images=True)
     assert out_h["depth_pred_s0_b1hw"].dtype == torch.float32 and torch.isfinite(out_h["depth_pred_s0_b1hw"]).all()
