@@ -218,7 +218,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": getattr(wl, "dtype", "f32"),
         "data": "synthetic",
         "config": wl.config(world),
     }

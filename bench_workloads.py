@@ -20,10 +20,14 @@ from simplerecon_amd.cost_volume import CostVolumeManager  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
 FP32_MFMA_PEAK_TF = 157.3
+F16_MFMA_PEAK_TF = 2500.0   # dense bf16 / f16 MFMA (MI355X_MICROARCH.md)
 
 
 def _mlp_kernel_name(K):
     """Which sr_mlp_volume_kernel<W1_LDS, W2_LDS> sr_mlp_volume_sweep dispatches (mirrors sr_mlp_volume.hip)."""
+    split = os.environ.get("SR_MLP_SPLIT", "0")
+    if split in ("bf16", "f16", "fp16"):
+        return f"sr_mlp_volume_split_kernel<{1 if split == 'bf16' else 2}>"
     w1, w2, w3 = 12 * K * 1024, 65 * 1024, 1024
     if w1 + w2 + w3 <= 160 * 1024:
         return "sr_mlp_volume_kernel<true, true>"
@@ -238,9 +242,18 @@ class HeroCfg3:
     B, K, Cc, D, h, w = 8, 7, 16, 64, 120, 160
     feature_volume_type = "mlp_feature_volume"
 
-    def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None, graph=False, prior=None):
+    dtype = "f32"
+
+    def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None, graph=False, prior=None, split=None):
         from simplerecon_amd import depth_model as dm
         self.prior = with_encoder if prior is None else (prior and with_encoder)
+        if split is not None:
+            # FENCED EXPERIMENT, never the headline: layers 1-2 of the metadata-MLP sweep on the 16-bit
+            # matrix pipe, every fp32 operand as two 16-bit pieces, three products, fp32 accumulate.  The switch is read by
+            # the library per call; a bench process runs one workload.
+            os.environ["SR_MLP_SPLIT"] = split
+            self.dtype = (f"f32 I/O and accumulate; MLP-sweep layers 1-2: operands as 2 x {split} pieces, 3 MFMA products "
+                          f"(fenced experiment, not the headline arithmetic)")
         if B is not None:
             self.B = B
         if name is not None:
@@ -458,10 +471,15 @@ class HeroCfg3:
             N = self.h * self.w
             cin = self.Cc * (self.K + 1) + 10 * self.K + 4
             flops = 2.0 * (cin * 128 + 128 * 128 + 128) * self.B * self.D * N
-            out.append({"kernel": _mlp_kernel_name(self.K), "bound": "mfma", "achieved": flops / t / 1e12,
-                        "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF,
-                        "avg_launch_us": t * 1e6, "algorithmic_flops_per_launch": flops,
-                        "algorithmic_bytes_per_launch": self.B * (4 * ((self.K + 1) * self.Cc * N + self.D * N + N))})
+            e = {"kernel": _mlp_kernel_name(self.K), "bound": "mfma", "achieved": flops / t / 1e12,
+                 "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF,
+                 "avg_launch_us": t * 1e6, "algorithmic_flops_per_launch": flops,
+                 "algorithmic_bytes_per_launch": self.B * (4 * ((self.K + 1) * self.Cc * N + self.D * N + N))}
+            if "split" in e["kernel"]:   # fenced experiment: three 16-bit products per fp32 product, priced on the 16-bit pipe
+                e.update({"achieved": 3 * flops / t / 1e12, "peak": F16_MFMA_PEAK_TF, "frac": 3 * flops / t / 1e12 / F16_MFMA_PEAK_TF,
+                          "algorithmic_tflops": flops / t / 1e12,
+                          "note": "executed = 3 x algorithmic flops (two 16-bit pieces per operand, three products)"})
+            out.append(e)
         return out
 
     def cpu_baseline(self):
@@ -769,6 +787,9 @@ WORKLOADS = {
     "hero_cfg3_core": lambda dev, rank: HeroCfg3(dev, rank, with_encoder=False, name="hero_cfg3_core"),
     "hero_b1_core": lambda dev, rank: HeroCfg3(dev, rank, B=1, with_encoder=False, name="hero_b1_core"),
     "hero_cfg3_graph": lambda dev, rank: HeroCfg3(dev, rank, graph=True, name="hero_cfg3_graph"),
+    # fenced experiments: split-precision MLP sweep; everything else as hero_cfg3
+    "hero_cfg3_bf16x3": lambda dev, rank: HeroCfg3(dev, rank, split="bf16", name="hero_cfg3_bf16x3"),
+    "hero_cfg3_f16x3": lambda dev, rank: HeroCfg3(dev, rank, split="f16", name="hero_cfg3_f16x3"),
     "hero_b1_graph": lambda dev, rank: HeroCfg3(dev, rank, B=1, graph=True, name="hero_b1_graph"),
     "hero_b1_core_graph": lambda dev, rank: HeroCfg3(dev, rank, B=1, with_encoder=False, graph=True,
                                                      name="hero_b1_core_graph"),

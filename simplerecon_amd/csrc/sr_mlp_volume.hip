@@ -15,6 +15,7 @@
 //   * W1 (packed in k-step order) lives in LDS for the whole persistent block; W2 streams from
 //     L2 with a register prefetch (both do not fit the 160 KB LDS in fp32).
 #include <stdlib.h>
+#include <string.h>
 
 #include "sr_common.h"
 
@@ -519,6 +520,415 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_kernel(SrMlpParams p) {
   }
 }
 
+// ------------------------------------------------------------------ split-precision variant (fenced experiment) ----
+// SR_MLP_SPLIT=bf16|f16 (read per call; default off): layers 1 (depth-variant part) and 2 run on the 16-bit matrix pipe
+// (v_mfma_f32_32x32x16_{bf16,f16}: 16x the fp32 rate) with every fp32 operand split into two 16-bit pieces,
+// x = x_hi + x_lo (round-to-nearest each), and three products per k-step, x_hi w_hi + x_hi w_lo + x_lo w_hi, accumulated in
+// fp32 by the MFMA (the dropped x_lo w_lo term is 2^-18 (bf16) / 2^-24 (f16) of the product).  Inputs, outputs, the
+// depth-invariant part of layer 1, layer 3 and every accumulator stay fp32.  Same wave-owns-64-points structure as the
+// fp32 kernel; a k-step now covers 16 inputs (8 per half-wave), so a view is two steps: its 16 warped channels, then its 8
+// metadata slots (upper k-half zero).  The layer-1 accumulators still ARE the layer-2 B operands (after LeakyReLU and
+// the split).  Not the default and not what bench.py's headline measures.
+typedef unsigned sr_u4v __attribute__((ext_vector_type(4)));
+
+template <int FMT> struct SrSplitFmt;
+template <> struct SrSplitFmt<1> {   // two bf16 pieces: 16-17 significant bits, fp32 exponent range
+  typedef __bf16 e2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 e8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ void split(float a, float b, unsigned& hi, unsigned& lo) {
+    const sr_f2v v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, e2));
+    const sr_f2v v0 = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - v0, e2));
+  }
+  static __device__ __forceinline__ f32x16 mfma(sr_u4v a, sr_u4v b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(e8, a), __builtin_bit_cast(e8, b), c, 0, 0, 0);
+  }
+};
+template <> struct SrSplitFmt<2> {   // two fp16 pieces: 22-24 significant bits for 2^-14 <= |x| < 65504 (denormal pieces are
+  typedef _Float16 e2 __attribute__((ext_vector_type(2)));   // honoured by v_cvt_pk_f16_f32 and the MFMA: measured on gfx950)
+  typedef _Float16 e8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ void split(float a, float b, unsigned& hi, unsigned& lo) {
+    const sr_f2v lim = {65504.0f, 65504.0f};
+    sr_f2v v = {a, b};
+    v = __builtin_elementwise_min(__builtin_elementwise_max(v, -lim), lim);   // saturate instead of inf - inf
+    const e2 h = __builtin_convertvector(v, e2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - __builtin_convertvector(h, sr_f2v), e2));
+  }
+  static __device__ __forceinline__ f32x16 mfma(sr_u4v a, sr_u4v b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(e8, a), __builtin_bit_cast(e8, b), c, 0, 0, 0);
+  }
+};
+
+// LDS / packed layout of the split variant (32-bit words):
+//   table  [0,512):   w3tab (128) | b3 (1) | pad | b2tab at 256 (128: C layout, [half][mt][r])
+//   W2     8 steps x [mt 4][piece 2][lane 64][4 words]                        = 16384 words
+//   W1var  per view: step A [mt 4][piece 2][lane 64][4] (2048) + metadata step [mt 4][piece 2][lane 32][4] (1024)
+#define SR_SPL_TAB 512
+#define SR_SPL_W2_WORDS 16384
+#define SR_SPL_VIEW_WORDS 3072
+
+template <int FMT>
+__global__ void sr_mlp_pack_split_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+                                         const float* __restrict__ W2, const float* __restrict__ b2,
+                                         const float* __restrict__ W3, const float* __restrict__ b3,
+                                         float* __restrict__ packed, int K, int C) {
+  typedef SrSplitFmt<FMT> S;
+  const int steps_var = (SR_VIEW_SLOTS / 2) * K;
+  const int steps_inv = (SR_INV_FIXED + 3 * K + 1) / 2;
+  const int steps1 = steps_var + steps_inv;
+  const int Cin = C * (K + 1) + 10 * K + 4;
+  const int o_cur = K * C, o_mask = o_cur + C, o_z = o_mask + K, o_d = o_z + K, o_dot = o_d + 1;
+  const int o_ang = o_dot + K, o_cray = o_ang + K, o_sray = o_cray + 3, o_pd = o_sray + 3 * K;
+  const int o_rm = o_pd + K, o_tm = o_rm + K;
+  unsigned* pk = reinterpret_cast<unsigned*>(packed);
+  auto var_col = [&](int k, int s) {   // column of W1 for slot s of view k (-1: none)
+    if (s < 16) return k * C + s;
+    if (s == 16) return o_mask + k;
+    if (s == 17) return o_z + k;
+    if (s == 18) return o_dot + k;
+    if (s == 19) return o_ang + k;
+    if (s < 23) return o_sray + 3 * k + (s - 20);
+    return (k == 0) ? o_d : -1;
+  };
+  auto put = [&](size_t word, int piece, float wa, float wb) {
+    unsigned hi, lo;
+    S::split(wa, wb, hi, lo);
+    pk[word] = piece ? lo : hi;
+  };
+  const int total = (steps1 + SR_MLP_STEPS2) * 256 + 128 + 1;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    if (e < steps_var * 256) {
+      const int k = e / SR_SPL_VIEW_WORDS, q = e - k * SR_SPL_VIEW_WORDS;
+      int mt, piece, lane, dw, slot0;
+      if (q < 2048) { mt = q >> 9; piece = (q >> 8) & 1; lane = (q >> 2) & 63; dw = q & 3; slot0 = 8 * (lane >> 5) + 2 * dw; }
+      else { const int q2 = q - 2048; mt = q2 >> 8; piece = (q2 >> 7) & 1; lane = (q2 >> 2) & 31; dw = q2 & 3; slot0 = 16 + 2 * dw; }
+      const int row = 32 * mt + (lane & 31);
+      const int ca = var_col(k, slot0), cb = var_col(k, slot0 + 1);
+      put(e, piece, ca >= 0 ? W1[(size_t)row * Cin + ca] : 0.0f, cb >= 0 ? W1[(size_t)row * Cin + cb] : 0.0f);
+    } else if (e < steps1 * 256) {   // depth-invariant part: fp32, the layout of sr_mlp_pack_kernel
+      const int e1 = e - steps_var * 256;
+      const int t = e1 >> 8, lane = (e1 >> 2) & 63, mt = e1 & 3;
+      const int row = 32 * mt + (lane & 31);
+      const int u = 2 * t + (lane >> 5);
+      int col = -1;
+      if (u < 16) col = o_cur + u;
+      else if (u < 19) col = o_cray + (u - 16);
+      else if (u == 19) col = -2;
+      else if (u < SR_INV_FIXED + 3 * K) {
+        const int k = (u - SR_INV_FIXED) / 3, i = (u - SR_INV_FIXED) - 3 * k;
+        col = (i == 0 ? o_pd : (i == 1 ? o_rm : o_tm)) + k;
+      }
+      packed[e] = (col >= 0) ? W1[(size_t)row * Cin + col] : (col == -2 ? b1[row] : 0.0f);
+    } else if (e < steps1 * 256 + SR_SPL_W2_WORDS) {
+      const int q = e - steps1 * 256;
+      const int s = q >> 11, mt = (q >> 9) & 3, piece = (q >> 8) & 1, lane = (q >> 2) & 63, dw = q & 3;
+      const int row = 32 * mt + (lane & 31);
+      // k-slot (s, lane >> 5, i): the hidden feature held in accumulator register r = 8 (s & 1) + i of tile s >> 1
+      auto feat = [&](int i) { const int r = 8 * (s & 1) + i; return 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); };
+      put(e, piece, W2[(size_t)row * SR_HID + feat(2 * dw)], W2[(size_t)row * SR_HID + feat(2 * dw + 1)]);
+    } else if (e < (steps1 + SR_MLP_STEPS2) * 256) {
+      const int i = e - steps1 * 256 - SR_SPL_W2_WORDS;   // 0..255: b2tab in the first 128
+      const int half = i >> 6, mt = (i >> 4) & 3, r = i & 15;
+      packed[e] = (i < 128) ? b2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half] : 0.0f;
+    } else if (e < (steps1 + SR_MLP_STEPS2) * 256 + 128) {
+      const int i = e - (steps1 + SR_MLP_STEPS2) * 256;
+      const int half = i >> 6, mt = (i >> 4) & 3, r = i & 15;
+      packed[e] = W3[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * half];
+    } else {
+      packed[e] = b3[0];
+    }
+  }
+}
+
+__device__ __forceinline__ void sr_swap_halves_u4(const sr_u4v fa, const sr_u4v fb, sr_u4v& bP, sr_u4v& bQ) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    auto r = __builtin_amdgcn_permlane32_swap(fa[i], fb[i], false, false);
+    bP[i] = r[0];
+    bQ[i] = r[1];
+  }
+}
+
+// one 16-input k-step of layer 1 or 2: 4 output tiles x 2 point groups x 3 products
+// INIT: 0 accumulate, 1 the first products take c0 as their C operand, 2 they take zero
+template <int FMT, int INIT>
+__device__ __forceinline__ void sr_spl_step(f32x16 (&acc)[2][4], const f32x16 (&c0)[2][4], const sr_u4v* aw, int ls,
+                                            const sr_u4v bPh, const sr_u4v bPl, const sr_u4v bQh, const sr_u4v bQl) {
+  typedef SrSplitFmt<FMT> S;
+  sr_u4v ah[4], al[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { ah[m] = aw[(2 * m) * ls]; al[m] = aw[(2 * m + 1) * ls]; }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc[0][m] = S::mfma(ah[m], bPh, INIT == 1 ? c0[0][m] : (INIT == 2 ? zero16 : acc[0][m]));
+    acc[1][m] = S::mfma(ah[m], bQh, INIT == 1 ? c0[1][m] : (INIT == 2 ? zero16 : acc[1][m]));
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    acc[0][m] = S::mfma(ah[m], bPl, acc[0][m]);
+    acc[1][m] = S::mfma(ah[m], bQl, acc[1][m]);
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    acc[0][m] = S::mfma(al[m], bPh, acc[0][m]);
+    acc[1][m] = S::mfma(al[m], bQh, acc[1][m]);
+  }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256, 1) void sr_mlp_volume_split_kernel(SrMlpParams p) {
+  typedef SrSplitFmt<FMT> S;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int C = 16;
+  const int lane = threadIdx.x & 63;
+  const int steps_var = (SR_VIEW_SLOTS / 2) * p.K;
+  const int steps1 = steps_var + (SR_INV_FIXED + 3 * p.K + 1) / 2;
+  const float4* gW1inv = reinterpret_cast<const float4*>(p.packed) + (size_t)steps_var * 64;
+  const float* gW2 = p.packed + (size_t)steps1 * 256;
+  const float* gW3 = p.packed + (size_t)(steps1 + SR_MLP_STEPS2) * 256;
+
+  for (int i = threadIdx.x; i < 129; i += blockDim.x) lds[i] = gW3[i];
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) lds[256 + i] = gW2[SR_SPL_W2_WORDS + i];
+  {
+    float4* l4 = reinterpret_cast<float4*>(lds + SR_SPL_TAB);
+    const float4* g4 = reinterpret_cast<const float4*>(gW2);
+    for (int i = threadIdx.x; i < SR_SPL_W2_WORDS / 4; i += blockDim.x) l4[i] = g4[i];
+    l4 += SR_SPL_W2_WORDS / 4;
+    g4 = reinterpret_cast<const float4*>(p.packed);
+    for (int i = threadIdx.x; i < p.K * (SR_SPL_VIEW_WORDS / 4); i += blockDim.x) l4[i] = g4[i];
+  }
+  __syncthreads();
+  const sr_u4v* W2s = reinterpret_cast<const sr_u4v*>(lds + SR_SPL_TAB);
+  const sr_u4v* W1s = W2s + SR_SPL_W2_WORDS / 4;
+
+  const int N = p.h * p.w;
+  const long nunits = (long)p.B * p.tiles * p.chunks;
+  long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  long unit_end = nunits;
+  if (p.xcd_order && (gridDim.x & 7) == 0) {   // XCD-contiguous unit ranges, as in sr_mlp_volume_kernel
+    const long u8 = (nunits + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    nwaves = (long)(gridDim.x >> 3) * (blockDim.x >> 6);
+    wave0 = xcd * u8 + (long)(blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    unit_end = min(nunits, (xcd + 1) * u8);
+  }
+  const int half = lane >> 5;
+  const sr_u4v zero4 = {0u, 0u, 0u, 0u};
+
+  for (long unit = wave0; unit < unit_end; unit += nwaves) {
+    const int chunk = (int)(unit % p.chunks);
+    const long tb = unit / p.chunks;
+    const int tile = (int)(tb % p.tiles);
+    const int b = (int)(tb / p.tiles);
+    const int j0 = chunk * p.chunk, j1 = min(p.D, j0 + p.chunk);
+    const int pix = tile * 64 + lane;
+    const bool active = pix < N;
+    const int pc = active ? pix : N - 1;
+    const int y = pc / p.w, x = pc - y * p.w;
+    const float* plane_ptr = p.planes.ptr + b * p.planes.sb + y * p.planes.sy + x * p.planes.sx;
+    const float* geom_b = p.geom + (size_t)b * p.K * SR_GEOM_STRIDE;
+    const float* src_b = p.src_nhwc + (size_t)b * p.K * N * C;
+
+    float cur[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) cur[c] = p.cur[((size_t)b * C + c) * N + pc];
+
+    float r0, r1, r2;
+    {
+#pragma clang fp contract(off)
+      const float* iK = p.invK + 16 * (size_t)b;
+      const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+      r0 = iK[0] * px + iK[1] * py + iK[2];
+      r1 = iK[4] * px + iK[5] * py + iK[6];
+      r2 = iK[8] * px + iK[9] * py + iK[10];
+    }
+    float cr0, cr1, cr2, crn0, crn1, crn2;
+    {
+#pragma clang fp contract(off)
+      const float d0 = plane_ptr[0];
+      const float X0 = d0 * r0, X1 = d0 * r1, X2 = d0 * r2;
+      const float cden = fmaxf(sqrtf((X0 * X0 + X1 * X1) + X2 * X2), 1e-12f);
+      cr0 = X0 / cden; cr1 = X1 / cden; cr2 = X2 / cden;
+      const float n1 = fmaxf(sqrtf((cr0 * cr0 + cr1 * cr1) + cr2 * cr2), 1e-5f);
+      crn0 = cr0 / n1; crn1 = cr1 / n1; crn2 = cr2 / n1;
+    }
+
+    // depth-invariant part of layer 1: fp32 MFMA, once per unit (as in sr_mlp_volume_kernel)
+    f32x16 hc[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hc[g][m][r] = 0.0f;
+    {
+      const float4* wi = gW1inv + lane;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) sr_l1_step(hc, wi[t * 64], cur[2 * t], cur[2 * t + 1]);
+      sr_l1_step(hc, wi[8 * 64], cr0, cr1);
+      sr_l1_step(hc, wi[9 * 64], cr2, 1.0f);
+      const int npose = 3 * p.K;
+#pragma unroll 1
+      for (int u = 0; u < npose; u += 2) {
+        const int ka = u / 3, ia = u - 3 * ka, kb = (u + 1) / 3, ib = (u + 1) - 3 * kb;
+        const float fa = geom_b[ka * SR_GEOM_STRIDE + 15 + ia];
+        const float fb = (u + 1 < npose) ? geom_b[kb * SR_GEOM_STRIDE + 15 + ib] : 0.0f;
+        sr_l1_step(hc, wi[(size_t)(10 + (u >> 1)) * 64], fa, fb);
+      }
+    }
+
+    SrSample smp;
+    float4 taps[16];
+    float fn[SR_VIEW_SLOTS];
+    unsigned ph[SR_VIEW_SLOTS / 2], pl[SR_VIEW_SLOTS / 2];   // the assembled view as 12 pairs of 16-bit pieces
+    float X0, X1, X2, d;
+    bool any_depth, any_bounds;
+    auto issue_view = [&](int k) {
+      sr_project_sample(geom_b + k * SR_GEOM_STRIDE, X0, X1, X2, p.h, p.w, p.inv_w, p.inv_h, smp);
+      const float* img = src_b + (size_t)k * N * C;
+      const float4* t_nw = reinterpret_cast<const float4*>(img + (size_t)smp.o_nw * C);
+      const float4* t_ne = reinterpret_cast<const float4*>(img + (size_t)smp.o_ne * C);
+      const float4* t_sw = reinterpret_cast<const float4*>(img + (size_t)smp.o_sw * C);
+      const float4* t_se = reinterpret_cast<const float4*>(img + (size_t)smp.o_se * C);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { taps[i] = t_nw[i]; taps[4 + i] = t_ne[i]; taps[8 + i] = t_sw[i]; taps[12 + i] = t_se[i]; }
+    };
+    float rv0, rv1, rv2, rsd, rdot;
+#define SR_SPLIT_VIEW                                                                     \
+    _Pragma("unroll") for (int i = 0; i < SR_VIEW_SLOTS / 2; ++i) S::split(fn[2 * i], fn[2 * i + 1], ph[i], pl[i]);
+
+    float cst[SR_PLANE_CHUNK];
+#pragma unroll
+    for (int q = 0; q < SR_PLANE_CHUNK; ++q) cst[q] = 0.0f;
+#pragma unroll 1
+    for (int j = j0; j < j1; ++j) {
+      d = plane_ptr[j * p.planes.sd];
+      {
+#pragma clang fp contract(off)
+        X0 = d * r0; X1 = d * r1; X2 = d * r2;
+      }
+      any_depth = false; any_bounds = false;
+      f32x16 acc[2][4];
+
+      {  // view 0, not overlapped
+        issue_view(0);
+        SR_RAY_A(fn, geom_b, 0) SR_RAY_B(fn) SR_RAY_C(fn)
+        SR_INTERP2(fn, 0, 0) SR_INTERP2(fn, 0, 1) SR_INTERP2(fn, 1, 0) SR_INTERP2(fn, 1, 1)
+        SR_INTERP2(fn, 2, 0) SR_INTERP2(fn, 2, 1) SR_INTERP2(fn, 3, 0) SR_INTERP2(fn, 3, 1)
+        SR_DOT(fn)
+        SR_SPLIT_VIEW
+      }
+      // layer 1 (depth-variant part), software-pipelined over views: view k+1 is assembled (fp32) and split beside the
+      // 2 x 24 MFMAs of view k
+#define SR_SPL_VIEW_BODY(FIRST)                                                                          \
+      {                                                                                                  \
+        const int kn = min(k + 1, p.K - 1);                                                              \
+        const float* g = geom_b + kn * SR_GEOM_STRIDE;                                                   \
+        const sr_u4v* wk = W1s + (size_t)k * (SR_SPL_VIEW_WORDS / 4);                                    \
+        sr_u4v bPh, bPl, bQh, bQl;                                                                       \
+        sr_swap_halves_u4(sr_u4v{ph[0], ph[1], ph[2], ph[3]}, sr_u4v{ph[4], ph[5], ph[6], ph[7]}, bPh, bQh); \
+        sr_swap_halves_u4(sr_u4v{pl[0], pl[1], pl[2], pl[3]}, sr_u4v{pl[4], pl[5], pl[6], pl[7]}, bPl, bQl); \
+        sr_u4v mPh, mPl, mQh, mQl;                                                                       \
+        sr_swap_halves_u4(sr_u4v{ph[8], ph[9], ph[10], ph[11]}, zero4, mPh, mQh);                        \
+        sr_swap_halves_u4(sr_u4v{pl[8], pl[9], pl[10], pl[11]}, zero4, mPl, mQl);                        \
+        issue_view(kn);                                                                                  \
+        sr_spl_step<FMT, (FIRST) ? 1 : 0>(acc, hc, wk + lane, 64, bPh, bPl, bQh, bQl);                             \
+        SR_RAY_A(fn, g, kn) SR_RAY_B(fn) SR_RAY_C(fn)                                                    \
+        SR_SB                                                                                            \
+        sr_spl_step<FMT, 0>(acc, hc, wk + 512 + (lane & 31), 32, mPh, mPl, mQh, mQl);                \
+        SR_INTERP2(fn, 0, 0) SR_INTERP2(fn, 0, 1) SR_INTERP2(fn, 1, 0) SR_INTERP2(fn, 1, 1)              \
+        SR_INTERP2(fn, 2, 0) SR_INTERP2(fn, 2, 1) SR_INTERP2(fn, 3, 0) SR_INTERP2(fn, 3, 1)              \
+        SR_DOT(fn)                                                                                       \
+        SR_SPLIT_VIEW                                                                                    \
+        SR_SB                                                                                            \
+      }
+      {
+        const int k = 0;
+        SR_SPL_VIEW_BODY(true)
+      }
+#pragma unroll 1
+      for (int k = 1; k < p.K; ++k) SR_SPL_VIEW_BODY(false)
+
+      // layer 2: 8 k-steps; step s takes accumulator registers 8 (s & 1) .. + 7 of tile s >> 1 through LeakyReLU and the split
+      f32x16 acc2[2][4];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        sr_u4v bh[2], bl[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float a0 = acc[g][s >> 1][8 * (s & 1) + 2 * i], a1 = acc[g][s >> 1][8 * (s & 1) + 2 * i + 1];
+            unsigned hi, lo;
+            S::split(sr_vmax(a0, p.slope * a0), sr_vmax(a1, p.slope * a1), hi, lo);
+            bh[g][i] = hi;
+            bl[g][i] = lo;
+          }
+        const sr_u4v* w2 = W2s + (size_t)s * 512 + lane;
+        if (s == 0) sr_spl_step<FMT, 2>(acc2, acc2, w2, 64, bh[0], bl[0], bh[1], bl[1]);
+        else sr_spl_step<FMT, 0>(acc2, acc2, w2, 64, bh[0], bl[0], bh[1], bl[1]);
+      }
+
+      // layer 3 (128 -> 1) on acc2 + b2; w3tab and b2tab in LDS (C layout)
+      const float4* w3 = reinterpret_cast<const float4*>(lds + half * 64);
+      const float4* b2t = reinterpret_cast<const float4*>(lds + 256 + half * 64);
+      sr_f2v oPQ = {0.0f, 0.0f};
+      const sr_f2v slope2 = {p.slope, p.slope};
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 wv = w3[m * 4 + q], bv = b2t[m * 4 + q];
+          const float wr[4] = {wv.x, wv.y, wv.z, wv.w}, br[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const sr_f2v h2 = sr_f2v{acc2[0][m][4 * q + i], acc2[1][m][4 * q + i]} + sr_f2v{br[i], br[i]};
+            const sr_f2v s2 = slope2 * h2;
+            oPQ = __builtin_elementwise_fma(sr_f2v{wr[i], wr[i]}, sr_f2v{sr_vmax(h2.x, s2.x), sr_vmax(h2.y, s2.y)}, oPQ);
+          }
+        }
+      float oP = oPQ.x, oQ = oPQ.y;
+      oP += __shfl_xor(oP, 32);
+      oQ += __shfl_xor(oQ, 32);
+      const float cost = (half ? oQ : oP) + lds[128];
+
+      if (p.vec_store) {
+#pragma unroll
+        for (int q = 0; q < SR_PLANE_CHUNK; ++q) cst[q] = (j - j0 == q) ? cost : cst[q];
+      }
+      if (active) {
+        if (!p.vec_store) p.out.cv[b * p.out.sb + j * p.out.sd + (int64_t)pix * p.out.sp] = cost;
+        if (j == p.D - 1 && p.out.mask) p.out.mask[(size_t)b * N + pix] = (uint8_t)(any_depth && any_bounds);
+      }
+    }
+    if (p.vec_store && active) {
+      float* row = p.out.cv + b * p.out.sb + (int64_t)pix * p.out.sp + j0;
+#pragma unroll
+      for (int q = 0; q < SR_PLANE_CHUNK; q += 4) {
+        if (j0 + q + 4 <= j1) *reinterpret_cast<float4*>(row + q) = make_float4(cst[q], cst[q + 1], cst[q + 2], cst[q + 3]);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (j0 + q + i < j1) row[q + i] = cst[q + i];
+        }
+      }
+    }
+  }
+}
+
+// SR_MLP_SPLIT (read per call): 0 / unset = fp32 MFMA (the product path), "bf16" = 1, "f16" = 2
+static int sr_mlp_split_mode() {
+  const char* e = getenv("SR_MLP_SPLIT");
+  if (!e || !*e || !strcmp(e, "0") || !strcmp(e, "off") || !strcmp(e, "fp32")) return 0;
+  if (!strcmp(e, "bf16")) return 1;
+  if (!strcmp(e, "f16") || !strcmp(e, "fp16")) return 2;
+  return -1;
+}
+
 // lowest_cost = planes[argmax_d volume] (cost_volume.py:338-342, 374-378); first maximum wins
 __global__ void sr_argmax_planes_kernel(const float* __restrict__ cv, int64_t sb, int64_t sd, int64_t sp,
                                         SrPlanes planes, int h, int w, int D, float* __restrict__ lowest) {
@@ -614,6 +1024,21 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
   const size_t w1_bytes = (size_t)sr_mlp_steps_var(K) * 1024;
   const size_t w2_bytes = (size_t)SR_MLP_STEPS2 * 1024;
   const size_t lds_max = 160 * 1024;
+  const int split = sr_mlp_split_mode();
+  if (split < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (split) {   // fenced experiment: both weight blocks must fit the LDS (K <= 7)
+    const size_t bytes = ((size_t)SR_SPL_TAB + SR_SPL_W2_WORDS + (size_t)K * SR_SPL_VIEW_WORDS) * 4;
+    if (bytes > lds_max) return SR_ERR_UNSUPPORTED;
+    const void* fn = split == 1 ? (const void*)sr_mlp_volume_split_kernel<1> : (const void*)sr_mlp_volume_split_kernel<2>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return sr_hip_rc(e);
+    if (split == 1) hipLaunchKernelGGL((sr_mlp_volume_split_kernel<1>), dim3(blocks), dim3(256), bytes, stream, p);
+    else hipLaunchKernelGGL((sr_mlp_volume_split_kernel<2>), dim3(blocks), dim3(256), bytes, stream, p);
+    int rc = sr_hip_rc(hipGetLastError());
+    if (rc) return rc;
+    if (out_lowest) rc = sr_launch_argmax_planes(out_cv, cv_sb, cv_sd, cv_sp, p.planes, B, h, w, D, out_lowest, stream);
+    return rc;
+  }
 #define SR_MLP_LAUNCH(L1, L2, BYTES)                                                                              \
   {                                                                                                               \
     hipError_t e = hipFuncSetAttribute((const void*)sr_mlp_volume_kernel<L1, L2>,                                 \
@@ -644,8 +1069,12 @@ extern "C" int sr_mlp_pack_weights(const float* W1, const float* b1, const float
   if (!W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !workspace || K <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (hidden != SR_HID || C != 16) return SR_ERR_UNSUPPORTED;
   if (workspace_bytes < sr_mlp_volume_workspace_bytes(B, K, C, h, w, hidden)) return SR_ERR_WORKSPACE_TOO_SMALL;
-  hipLaunchKernelGGL(sr_mlp_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream_, W1, b1, W2, b2, W3, b3,
-                     sr_ws_packed(workspace, B, K, C, h, w), K, C);
+  const int split = sr_mlp_split_mode();
+  if (split < 0) return SR_ERR_INVALID_ARGUMENT;
+  float* packed = sr_ws_packed(workspace, B, K, C, h, w);
+  if (split == 1) hipLaunchKernelGGL((sr_mlp_pack_split_kernel<1>), dim3(64), dim3(256), 0, (hipStream_t)stream_, W1, b1, W2, b2, W3, b3, packed, K, C);
+  else if (split == 2) hipLaunchKernelGGL((sr_mlp_pack_split_kernel<2>), dim3(64), dim3(256), 0, (hipStream_t)stream_, W1, b1, W2, b2, W3, b3, packed, K, C);
+  else hipLaunchKernelGGL(sr_mlp_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream_, W1, b1, W2, b2, W3, b3, packed, K, C);
   return sr_hip_rc(hipGetLastError());
 }
 

@@ -159,6 +159,15 @@ def test_batch_1_at_benchmarked_shape_matches_oracle_chain(case):
     case.check(out, 0, 0, "batch 1, frame 0")
 
 
+@pytest.mark.parametrize("split", ["bf16", "f16"])
+def test_batch_1_with_split_precision_mlp_sweep(case, split, monkeypatch):
+    """The fenced split-precision sweep (SR_MLP_SPLIT) through the SAME end-to-end check at the SAME
+    tolerances -- including the element-wise bounds on depth_pred_s0 -- as the fp32-MFMA sweep."""
+    monkeypatch.setenv("SR_MLP_SPLIT", split)
+    out = case.run_hip(slice(0, 1))
+    case.check(out, 0, 0, f"batch 1, frame 0, SR_MLP_SPLIT={split}")
+
+
 def test_batch_8_at_benchmarked_shape_matches_oracle_chain(case):
     """bench.py's timed configuration (hero_cfg3: batch 8): first and last frame of the batch against the oracle."""
     out = case.run_hip(slice(0, B))

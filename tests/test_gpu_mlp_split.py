@@ -1,0 +1,80 @@
+"""The split-precision variant of the metadata-MLP sweep (SR_MLP_SPLIT=bf16|f16: layers 1-2 on the 16-bit matrix pipe with
+every fp32 operand as two 16-bit pieces and three products; a fenced experiment) against the SAME oracle /
+golden checks, at the SAME tolerances, as the fp32-MFMA kernel (tests/test_gpu_mlp_volume.py)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from parity import assert_close, assert_lowest_cost, mismatch_fraction, rel_err
+from simplerecon_amd import synthetic
+from test_gpu_mlp_volume import _manager, _oracle, _run
+
+pytestmark = pytest.mark.gpu
+MODES = ["bf16", "f16"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", [n for n, c in gc.VOLUME_CASES.items() if c["model"] == "hero" and c["K"] <= 7])
+def test_split_sweep_matches_oracle_and_golden(name, mode, monkeypatch):
+    case = gc.VOLUME_CASES[name]
+    inp = gc.volume_inputs(case)
+    gold = gc.load_golden("volume", name)
+    mgr = _manager(case)
+    ref = _run(mgr, inp)[0]                      # fp32-MFMA kernel
+    monkeypatch.setenv("SR_MLP_SPLIT", mode)
+    vol, lowest, planes, mask = _run(mgr, inp)
+    planes_np = planes.cpu().numpy() if "depth_planes_bdhw" in inp else planes[:, :, 0, 0].cpu().numpy()
+    cv_o, low_o, mask_o = _oracle(mgr, inp, planes_np)
+    assert_close(vol, cv_o, tol=2e-5, what=f"{name} [{mode}] vs oracle")
+    assert_close(vol, gold["cost_volume"], what=f"{name} [{mode}] vs reference golden")
+    assert mismatch_fraction(mask, mask_o) == 0.0 and mismatch_fraction(mask, gold["overall_mask"]) == 0.0
+    assert_lowest_cost(lowest, vol, planes_np, gold["lowest_cost"], name)
+    assert not torch.equal(vol, ref), "the switch did not select the split kernel"
+    cv64, _, _ = _oracle(mgr, inp, planes_np, "f64")
+    e_split, e_ref32 = rel_err(vol, cv64), rel_err(gold["cost_volume"], cv64)
+    print(f"{name} [{mode}]: error vs f64 oracle {e_split:.3e} (reference fp32: {e_ref32:.3e})")
+    if mode == "f16":
+        # two fp16 pieces carry 22-24 bits: as close to the fp64 truth as the reference's own fp32 result is (the UNCHANGED
+        # bound of the fp32 kernel's test) and indistinguishable from the fp32 kernel at this scale
+        assert e_split < 2 * max(e_ref32, 1e-6)
+        assert rel_err(vol, ref.cpu().numpy()) < 2e-6
+    else:
+        # two bf16 pieces carry 16-18 bits: inside every parity tolerance above, but NOT inside "2x the reference's own fp32
+        # error" on every case (hero_k7: measured 1.1e-5 vs the bound 9.7e-6) -- recorded as such in DESIGN.md 3.2b
+        assert e_split < 2e-5
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_split_sweep_cfg3_batch8(mode, monkeypatch):
+    """BASELINE.json configs[2] at the benchmarked batch, channels-last volume, all frames on a plane subset."""
+    B = 8
+    case = dict(B=B, K=7, C=16, D=64, h=120, w=160, seed=58)
+    inp = synthetic.cost_volume_inputs(B, 7, 16, 120, 160, seed=case["seed"])
+    mgr = _manager(case)
+    mgr.volume_memory_format = torch.channels_last
+    monkeypatch.setenv("SR_MLP_SPLIT", mode)
+    vol, lowest, planes, mask = _run(mgr, inp)
+    planes_np = planes[:, :, 0, 0].cpu().numpy()
+    sub = [0, 31, 63]
+    cv_o, _, mask_o = _oracle(mgr, inp, planes_np[:, sub])
+    for b in range(B):
+        assert_close(vol[b:b + 1, sub], cv_o[b:b + 1], tol=2e-5, what=f"cfg3 B=8 frame {b} [{mode}] vs oracle")
+    assert mismatch_fraction(mask, mask_o) == 0.0
+    again = _run(mgr, inp)[0]
+    assert torch.equal(vol, again), "the split sweep is deterministic"
+
+
+def test_split_sweep_refuses_what_it_does_not_cover(monkeypatch):
+    """More than 7 source views (the split weights no longer fit the LDS) and unknown modes fail loudly."""
+    from simplerecon_amd._lib import HipLibraryError
+    case = dict(B=1, K=9, C=16, D=5, h=12, w=20, seed=79)
+    inp = synthetic.cost_volume_inputs(1, 9, 16, 12, 20, seed=79)
+    mgr = _manager(case)
+    monkeypatch.setenv("SR_MLP_SPLIT", "bf16")
+    with pytest.raises(HipLibraryError):
+        _run(mgr, inp)
+    case = gc.VOLUME_CASES["hero_small"]
+    monkeypatch.setenv("SR_MLP_SPLIT", "int8")
+    with pytest.raises(HipLibraryError):
+        _run(_manager(case), gc.volume_inputs(case))
