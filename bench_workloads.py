@@ -244,16 +244,19 @@ class HeroCfg3:
 
     dtype = "f32"
 
-    def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None, graph=False, prior=None, split=None):
+    def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None, graph=False, prior=None, split=None, split_convs=False):
         from simplerecon_amd import depth_model as dm
         self.prior = with_encoder if prior is None else (prior and with_encoder)
         if split is not None:
-            # FENCED EXPERIMENT, never the headline: layers 1-2 of the metadata-MLP sweep on the 16-bit
-            # matrix pipe, every fp32 operand as two 16-bit pieces, three products, fp32 accumulate.  The switch is read by
-            # the library per call; a bench process runs one workload.
+            # FENCED EXPERIMENTS, never the headline: layers 1-2 of the metadata-MLP sweep -- and with
+            # split_convs the Winograd 3x3 convolutions -- multiply on the 16-bit matrix pipe, every fp32 operand as two 16-bit
+            # pieces, three products, fp32 accumulate.  The switches are read by the library per call; a bench process runs
+            # one workload.
             os.environ["SR_MLP_SPLIT"] = split
-            self.dtype = (f"f32 I/O and accumulate; MLP-sweep layers 1-2: operands as 2 x {split} pieces, 3 MFMA products "
-                          f"(fenced experiment, not the headline arithmetic)")
+            if split_convs:
+                os.environ["SR_WINO_SPLIT"] = split
+            self.dtype = (f"f32 I/O and accumulate; MLP-sweep layers 1-2{' and the Winograd 3x3 convolutions' if split_convs else ''}"
+                          f": operands as 2 x {split} pieces, 3 MFMA products (fenced experiment, not the headline arithmetic)")
         if B is not None:
             self.B = B
         if name is not None:
@@ -419,9 +422,12 @@ class HeroCfg3:
         # 36 multiplies per 2x2 tile and channel pair), so frac = MFMA utilisation <= 1; the direct-convolution
         # (algorithmic) count is reported beside it
         achieved = (executed if wino else flops) / t / 1e12
+        peak = FP32_MFMA_PEAK_TF
+        if "split" in name:   # fenced experiment: three 16-bit products per fp32 product, priced on the 16-bit matrix pipe
+            achieved, peak = 3 * achieved, F16_MFMA_PEAK_TF
         traffic = _pmc_traffic(self.name)
-        out = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-               "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": traffic,
+        out = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+               "frac": achieved / peak, "traffic": traffic,
                "algorithmic_bytes_per_launch": (self._conv_bytes.get(name, 0.0) / calls) or None,
                "traffic_over_algorithmic": (traffic / (self._conv_bytes[name] / calls))
                if traffic and self._conv_bytes.get(name) else None,
@@ -463,8 +469,11 @@ class HeroCfg3:
         out = []
         for name, (calls, flops, t, executed) in sorted(self._conv_agg.items(), key=lambda kv: -kv[1][2])[1:]:
             ex = executed if "wino" in name else flops
-            out.append({"kernel": name, "bound": "mfma", "achieved": ex / t / 1e12, "peak": FP32_MFMA_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": ex / t / 1e12 / FP32_MFMA_PEAK_TF, "algorithmic_tflops": flops / t / 1e12,
+            peak = FP32_MFMA_PEAK_TF
+            if "split" in name:
+                ex, peak = 3 * ex, F16_MFMA_PEAK_TF
+            out.append({"kernel": name, "bound": "mfma", "achieved": ex / t / 1e12, "peak": peak,
+                        "unit": "TFLOP/s", "frac": ex / t / 1e12 / peak, "algorithmic_tflops": flops / t / 1e12,
                         "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // self._prof_n})
         if self.feature_volume_type == "mlp_feature_volume":
             t = self._mlp_sweep_time(max(3, min(n, 10)))
@@ -790,6 +799,10 @@ WORKLOADS = {
     # fenced experiments: split-precision MLP sweep; everything else as hero_cfg3
     "hero_cfg3_bf16x3": lambda dev, rank: HeroCfg3(dev, rank, split="bf16", name="hero_cfg3_bf16x3"),
     "hero_cfg3_f16x3": lambda dev, rank: HeroCfg3(dev, rank, split="f16", name="hero_cfg3_f16x3"),
+    "hero_cfg3_bf16x3_convs": lambda dev, rank: HeroCfg3(dev, rank, split="bf16", split_convs=True, name="hero_cfg3_bf16x3_convs"),
+    "hero_cfg3_f16x3_convs": lambda dev, rank: HeroCfg3(dev, rank, split="f16", split_convs=True, name="hero_cfg3_f16x3_convs"),
+    "hero_b1_graph_f16x3_convs": lambda dev, rank: HeroCfg3(dev, rank, B=1, graph=True, split="f16", split_convs=True,
+                                                            name="hero_b1_graph_f16x3_convs"),
     "hero_b1_graph": lambda dev, rank: HeroCfg3(dev, rank, B=1, graph=True, name="hero_b1_graph"),
     "hero_b1_core_graph": lambda dev, rank: HeroCfg3(dev, rank, B=1, with_encoder=False, graph=True,
                                                      name="hero_b1_core_graph"),

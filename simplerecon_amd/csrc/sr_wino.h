@@ -99,4 +99,42 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) {
 }
 #endif
 
+// ---- buffer addressing (r04) ----------------------------------------------------------------------------------------
+// Every VALU instruction the kernel issues outside its MFMA stream costs ~13 clocks while the co-resident workgroup
+// keeps the matrix pipe busy, and r03's epilogue + prologue issued ~680 of them per region (64-bit
+// address arithmetic, eight predicated residual-load / store branches, a 3 x division-by-18 re-aim of the staging
+// loads).  The vector instantiations now address global memory through buffer descriptors: a wave-uniform descriptor
+// (image base, byte range) + a 32-bit lane offset + a scalar offset operand.  A lane is switched off by its OFFSET
+// (WN_OOB: the load returns 0, the store is dropped) instead of a branch, the per-(tile, pixel) deltas ride in the
+// scalar offset operand (SALU work), and an interior region -- every one at 240x320 / 120x160 -- needs no per-lane
+// predicate at all.
+typedef unsigned int wn_u4 __attribute__((ext_vector_type(4)));
+typedef float wn_f4 __attribute__((ext_vector_type(4)));
+#define WN_RSRC_FLAGS 0x00020000      // raw buffer descriptor word 3 on gfx9-family parts
+#define WN_OOB 0x7fffffffu            // a lane offset beyond any num_records
+__device__ __forceinline__ float4 wn_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const wn_f4 v = __builtin_bit_cast(wn_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+// Stores take their scalar delta through the LANE offset (one v_add), not through the scalar-offset operand: a 16-byte
+// buffer store reads its data registers some cycles after it issues, and a VALU write to them in that window corrupts the
+// store ("VMEM store of more than 8 bytes" hazard, 2 wait states on gfx940+).  The compiler inserts those wait states only
+// when the scalar-offset operand is NOT a register -- with an SGPR offset it assumes there is no hazard, and on gfx950
+// there is: the border-region epilogue, which recomputes a lane offset between two stores, wrote the OFFSET into the
+// first channel of the previous store (found by tests/test_gpu_image_encoder.py at 480x640, r04).
+__device__ __forceinline__ void wn_buf_store(const float4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const wn_f4 t = {v.x, v.y, v.z, v.w};
+  // (WN_OOB + soff stays below 2^32 and above every num_records: a switched-off lane stays switched off)
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, t), r, (int)(voff + soff), 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, WN_RSRC_FLAGS);
+}
 
+// (`SR_WN_PIN`: an empty asm that makes a value opaque at that point, so that addresses derived from it are formed there
+// as register + immediate instead of being hoisted out of the loops, one register -- then one spill -- each)
+
+// ---- split-precision variant (sr_wino_split.hip; fenced experiment, SR_WINO_SPLIT=bf16|f16) ----
+int sr_wino_split_mode();   // 0 off, 1 bf16, 2 f16, -1 unknown value (read per call)
+int sr_wino_split_pack(const float* weight, int Cout, int Cin, float* packed, int mode, hipStream_t stream);
+int sr_wino_split_launch(const SrWinoParams& p, int nt, int blocks, int mode, hipStream_t stream);

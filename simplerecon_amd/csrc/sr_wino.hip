@@ -57,38 +57,6 @@ __global__ void sr_wino_pack_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
-// ---- buffer addressing (r04) ----------------------------------------------------------------------------------------
-// Every VALU instruction the kernel issues outside its MFMA stream costs ~13 clocks while the co-resident workgroup
-// keeps the matrix pipe busy, and r03's epilogue + prologue issued ~680 of them per region (64-bit
-// address arithmetic, eight predicated residual-load / store branches, a 3 x division-by-18 re-aim of the staging
-// loads).  The vector instantiations now address global memory through buffer descriptors: a wave-uniform descriptor
-// (image base, byte range) + a 32-bit lane offset + a scalar offset operand.  A lane is switched off by its OFFSET
-// (WN_OOB: the load returns 0, the store is dropped) instead of a branch, the per-(tile, pixel) deltas ride in the
-// scalar offset operand (SALU work), and an interior region -- every one at 240x320 / 120x160 -- needs no per-lane
-// predicate at all.
-typedef unsigned int wn_u4 __attribute__((ext_vector_type(4)));
-typedef float wn_f4 __attribute__((ext_vector_type(4)));
-#define WN_RSRC_FLAGS 0x00020000      // raw buffer descriptor word 3 on gfx9-family parts
-#define WN_OOB 0x7fffffffu            // a lane offset beyond any num_records
-__device__ __forceinline__ float4 wn_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const wn_f4 v = __builtin_bit_cast(wn_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-// Stores take their scalar delta through the LANE offset (one v_add), not through the scalar-offset operand: a 16-byte
-// buffer store reads its data registers some cycles after it issues, and a VALU write to them in that window corrupts the
-// store ("VMEM store of more than 8 bytes" hazard, 2 wait states on gfx940+).  The compiler inserts those wait states only
-// when the scalar-offset operand is NOT a register -- with an SGPR offset it assumes there is no hazard, and on gfx950
-// there is: the border-region epilogue, which recomputes a lane offset between two stores, wrote the OFFSET into the
-// first channel of the previous store (found by tests/test_gpu_image_encoder.py at 480x640, r04).
-__device__ __forceinline__ void wn_buf_store(const float4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const wn_f4 t = {v.x, v.y, v.z, v.w};
-  // (WN_OOB + soff stays below 2^32 and above every num_records: a switched-off lane stays switched off)
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_u4, t), r, (int)(voff + soff), 0, 0);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void* base, int64_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, WN_RSRC_FLAGS);
-}
-
 // ---- 16-bit activation I/O (r04; training under torch.autocast, reference options.py:100-101 / train.py:132) ----
 // IO = 0: fp32 tensors (inference, the measured path).  IO = 1 / 2: the input, the residual and the output are fp16 / bf16
 // tensors in HBM -- four channels are ONE 8-byte load or store --, widened to fp32 on the way into LDS and rounded (to
@@ -739,6 +707,9 @@ extern "C" size_t sr_wino_packed_weight_floats(int Cout, int Cin) {
 extern "C" int sr_wino_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream_) {
   if (!weight || !packed || Cout <= 0 || Cin <= 0) return SR_ERR_INVALID_ARGUMENT;
   const int G = ((Cin + 15) / 16) * 2, Co_pad = ((Cout + 31) / 32) * 32;
+  const int split = sr_wino_split_mode();   // fenced experiment (sr_wino_split.hip): the same buffer, 16-bit pieces inside
+  if (split < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (split) return sr_wino_split_pack(weight, Cout, Cin, packed, split, (hipStream_t)stream_);
   hipLaunchKernelGGL(sr_wino_pack_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream_, weight, packed, Cout, Cin, G,
                      Co_pad);
   return sr_hip_rc(hipGetLastError());
@@ -846,6 +817,9 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
                     (!residual || ((((uintptr_t)residual & amask) == 0) && (res_pix_stride % 4 == 0) &&
                                    (res_batch_stride % 4 == 0)));
   if (io && !vout) return SR_ERR_UNSUPPORTED;   // 16-bit I/O: the vector instantiation only
+  const int split = sr_wino_split_mode();
+  if (split < 0) return SR_ERR_INVALID_ARGUMENT;
+  if (split && (io || !vout)) return SR_ERR_UNSUPPORTED;   // split precision: fp32 tensors, the vector instantiation only
   const int64_t lim = (int64_t)1 << 31;          // per-image byte offsets are 32-bit (buffer addressing)
   if (vout && (((int64_t)(H * W - 1) * in_pix_stride + Cin) * 4 >= lim || ((int64_t)(H * W - 1) * out_pix_stride + Cout) * 4 >= lim ||
                (residual && ((int64_t)(H * W - 1) * res_pix_stride + Cout) * 4 >= lim)))
@@ -893,7 +867,8 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
     if (e != hipSuccess) return sr_hip_rc(e);                                                                     \
     hipLaunchKernelGGL((sr_wino_kernel<NTV, V4, VO>), dim3(blocks), dim3(256), lds, stream, p);                   \
   }
-  if (io == 1 && nt == 2) SR_WINO_LAUNCH_IO(2, 1)
+  if (split) { const int rc = sr_wino_split_launch(p, nt, blocks, split, stream); if (rc) return rc; }
+  else if (io == 1 && nt == 2) SR_WINO_LAUNCH_IO(2, 1)
   else if (io == 1) SR_WINO_LAUNCH_IO(1, 1)
   else if (io == 2 && nt == 2) SR_WINO_LAUNCH_IO(2, 2)
   else if (io == 2) SR_WINO_LAUNCH_IO(1, 2)

@@ -257,9 +257,15 @@ def linear(x, lin: nn.Linear, leaky=None):
 _PACKED_WINO = weakref.WeakKeyDictionary()  # nn.Conv2d -> (weight version, data_ptr, Winograd-packed tensor)
 
 
+def wino_split_mode():
+    """'' (off: fp32 MFMA, the product path), 'bf16' or 'f16': the fenced split-precision Winograd variant, read per call."""
+    v = os.environ.get("SR_WINO_SPLIT", "")
+    return "" if v in ("", "0", "off", "fp32") else v
+
+
 def packed_wino_weight(conv: nn.Conv2d, bn=None):
     """(Winograd-packed weight U = G g G^T, bias); cached until a parameter changes."""
-    key = _state_key(conv, bn)
+    key = (_state_key(conv, bn), wino_split_mode())   # (the fenced split-precision variant packs 16-bit pieces)
     hit = _PACKED_WINO.get(conv)
     if hit is not None and hit[0] == key:
         _await_packed(conv, "wino", hit[1].device)
@@ -331,6 +337,12 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
     osb, osp = _strides(out)
     rsb, rsp = _strides(residual) if residual is not None else (0, 0)
     prof = PROFILE
+    if use_wino and wino_split_mode():
+        # fenced split-precision Winograd (SR_WINO_SPLIT, csrc/sr_wino_split.hip): the vector instantiation only -- layers with
+        # unaligned tensors or channel counts that are no multiple of 4 take the direct fp32 kernel instead
+        al = lambda t, sb_, sp_: t is None or (t.data_ptr() % 16 == 0 and sp_ % 4 == 0 and sb_ % 4 == 0)
+        if not (ci % 4 == 0 and co % 4 == 0 and al(x, isb, isp) and al(out, osb, osp) and al(residual, rsb, rsp)):
+            use_wino = False
     if gate is not None:
         _lib.require_device_f32("gate", gate)
         if k != 1 or s != 1 or tuple(gate.shape) != (b, ci) or not gate.is_contiguous():
@@ -447,6 +459,9 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 vout = vin and co % 4 == 0 and al(out, osb, osp) and al(residual, rsb, rsp) and \
                     (bias is None or bias.data_ptr() % 16 == 0)
                 name = lib.sr_wino_kernel_name(b, h, w, ci, co, int(vin), int(vout)).decode()
+                if wino_split_mode():   # (the fenced variant: sr_wino_split_kernel<NT, FMT>)
+                    name = name.replace("sr_wino_kernel<", "sr_wino_split_kernel<").replace(
+                        ", true, true>", f", {1 if wino_split_mode() == 'bf16' else 2}>")
             else:
                 name = lib.sr_conv_kernel_name(b, h, w, ci, co, k, s, v4).decode()
             executed = None

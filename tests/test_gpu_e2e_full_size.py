@@ -168,6 +168,16 @@ def test_batch_1_with_split_precision_mlp_sweep(case, split, monkeypatch):
     case.check(out, 0, 0, f"batch 1, frame 0, SR_MLP_SPLIT={split}")
 
 
+@pytest.mark.parametrize("split", ["bf16", "f16"])
+def test_batch_1_with_split_precision_sweep_and_convs(case, split, monkeypatch):
+    """Both fenced split-precision kernels at once (SR_MLP_SPLIT + SR_WINO_SPLIT): every Winograd 3x3
+    convolution of both encoders, the CVEncoder and the decoder multiplies 16-bit pieces.  Same check, same tolerances."""
+    monkeypatch.setenv("SR_MLP_SPLIT", split)
+    monkeypatch.setenv("SR_WINO_SPLIT", split)
+    out = case.run_hip(slice(0, 1))
+    case.check(out, 0, 0, f"batch 1, frame 0, SR_MLP_SPLIT=SR_WINO_SPLIT={split}")
+
+
 def test_batch_8_at_benchmarked_shape_matches_oracle_chain(case):
     """bench.py's timed configuration (hero_cfg3: batch 8): first and last frame of the batch against the oracle."""
     out = case.run_hip(slice(0, B))
