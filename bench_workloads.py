@@ -472,9 +472,18 @@ class HeroCfg3:
             peak = FP32_MFMA_PEAK_TF
             if "split" in name:
                 ex, peak = 3 * ex, F16_MFMA_PEAK_TF
-            out.append({"kernel": name, "bound": "mfma", "achieved": ex / t / 1e12, "peak": peak,
-                        "unit": "TFLOP/s", "frac": ex / t / 1e12 / peak, "algorithmic_tflops": flops / t / 1e12,
-                        "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // self._prof_n})
+            e = {"kernel": name, "bound": "mfma", "achieved": ex / t / 1e12, "peak": peak,
+                 "unit": "TFLOP/s", "frac": ex / t / 1e12 / peak, "algorithmic_tflops": flops / t / 1e12,
+                 "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // self._prof_n}
+            nbytes = self._conv_bytes.get(name)
+            if nbytes:   # both rooflines of the kernel: the larger fraction names the resource that binds it
+                e["mfma_frac"] = e["frac"]
+                e["hbm_frac"] = nbytes / t / 1e9 / HBM_PEAK_GBS
+                e["algorithmic_bytes_per_launch"] = nbytes / calls
+                if e["hbm_frac"] > e["mfma_frac"]:
+                    e.update({"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": e["hbm_frac"]})
+            out.append(e)
         if self.feature_volume_type == "mlp_feature_volume":
             t = self._mlp_sweep_time(max(3, min(n, 10)))
             N = self.h * self.w

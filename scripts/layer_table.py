@@ -6,7 +6,8 @@ import bench_workloads as bw
 from simplerecon_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-wl = bw.HeroCfg3(torch.device("cuda", 0), 0, B=B, with_encoder=False)
+ALL = len(sys.argv) > 2 and sys.argv[2] == "all"   # include both encoders (the whole DepthModel.forward)
+wl = bw.HeroCfg3(torch.device("cuda", 0), 0, B=B, with_encoder=ALL)
 inp = wl.inp
 with torch.inference_mode():
     vol = wl.model.cost_volume(cur_feats=inp["cur_feats"], src_feats=inp["src_feats"], src_extrinsics=inp["src_extrinsics"],
@@ -14,8 +15,11 @@ with torch.inference_mode():
                                min_depth=inp["min_depth"], max_depth=inp["max_depth"])[0]
     for it in range(4):
         ops.PROFILE = [] if it == 3 else None
-        feats = wl.model.cost_volume_net(vol, wl.pyramid[1:])
-        wl.model.depth_decoder(wl.pyramid[:1] + feats)
+        pyramid = list(wl.model.encoder(wl.cur_image)) if ALL else wl.pyramid
+        if ALL:
+            wl.model.compute_matching_feats(wl.cur_image, wl.src_image, False)
+        feats = wl.model.cost_volume_net(vol, pyramid[1:])
+        wl.model.depth_decoder(pyramid[:1] + feats)
     torch.cuda.synchronize()
 rec = ops.PROFILE; ops.PROFILE = None
 agg = collections.OrderedDict()

@@ -546,12 +546,10 @@ template <> struct SrSplitFmt<1> {   // two bf16 pieces: 16-17 significant bits,
   }
 };
 template <> struct SrSplitFmt<2> {   // two fp16 pieces: 22-24 significant bits for 2^-14 <= |x| < 65504 (denormal pieces are
-  typedef _Float16 e2 __attribute__((ext_vector_type(2)));   // honoured by v_cvt_pk_f16_f32 and the MFMA: measured on gfx950)
-  typedef _Float16 e8 __attribute__((ext_vector_type(8)));
-  static __device__ __forceinline__ void split(float a, float b, unsigned& hi, unsigned& lo) {
-    const sr_f2v lim = {65504.0f, 65504.0f};
-    sr_f2v v = {a, b};
-    v = __builtin_elementwise_min(__builtin_elementwise_max(v, -lim), lim);   // saturate instead of inf - inf
+  typedef _Float16 e2 __attribute__((ext_vector_type(2)));   // honoured by v_cvt_pk_f16_f32 and the MFMA: measured on gfx950);
+  typedef _Float16 e8 __attribute__((ext_vector_type(8)));   // beyond +-65504 the high piece is inf and the result NaN -- loud,
+  static __device__ __forceinline__ void split(float a, float b, unsigned& hi, unsigned& lo) {   // not a saturated wrong value
+    const sr_f2v v = {a, b};
     const e2 h = __builtin_convertvector(v, e2);
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - __builtin_convertvector(h, sr_f2v), e2));

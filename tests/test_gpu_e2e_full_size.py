@@ -28,7 +28,7 @@ DEV = "cuda:0"
 B, K, D, H, W = 8, 7, 64, 480, 640
 h, w = H // 4, W // 4
 FORCING = ("SR_CONV_WINO", "SR_WINO_XCD", "SR_WINO_NT", "SR_WINO_KSPLIT", "SR_DOT_LDS", "SR_CONV1X1_GEMM", "SR_PRIOR_SIDE",
-           "SR_MLP_BWD_VALU", "SR_MLP_VEC_STORE")
+           "SR_MLP_BWD_VALU", "SR_MLP_VEC_STORE", "SR_MLP_SPLIT", "SR_WINO_SPLIT")
 
 
 def _sd(m):

@@ -78,3 +78,21 @@ def test_split_sweep_refuses_what_it_does_not_cover(monkeypatch):
     monkeypatch.setenv("SR_MLP_SPLIT", "int8")
     with pytest.raises(HipLibraryError):
         _run(_manager(case), gc.volume_inputs(case))
+
+
+def test_f16_pieces_fail_loudly_outside_fp16_range(monkeypatch):
+    """Matching features beyond fp16's range: the f16 variant returns non-finite costs (never a silently saturated value);
+    the bf16 variant, with fp32's exponent range, still matches the oracle."""
+    case = gc.VOLUME_CASES["hero_small"]
+    inp = gc.volume_inputs(case)
+    inp = dict(inp, cur_feats=inp["cur_feats"] * 3e5, src_feats=inp["src_feats"] * 3e5)
+    mgr = _manager(case)
+    monkeypatch.setenv("SR_MLP_SPLIT", "f16")
+    vol = _run(mgr, inp)[0]
+    assert not bool(torch.isfinite(vol).all())
+    monkeypatch.setenv("SR_MLP_SPLIT", "bf16")
+    vol, lowest, planes, mask = _run(mgr, inp)
+    planes_np = planes.cpu().numpy() if "depth_planes_bdhw" in inp else planes[:, :, 0, 0].cpu().numpy()
+    cv_o, _, _ = _oracle(mgr, inp, planes_np)
+    assert bool(torch.isfinite(vol).all())
+    assert_close(vol, cv_o, tol=2e-5, what="bf16 pieces at 3e5 x feature scale vs oracle")

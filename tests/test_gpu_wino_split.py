@@ -81,3 +81,19 @@ def test_unknown_mode_fails_loudly(monkeypatch):
     monkeypatch.setenv("SR_WINO_SPLIT", "int8")
     with pytest.raises(HipLibraryError), torch.inference_mode():
         ops.conv2d(x, conv)
+
+
+def test_f16_pieces_fail_loudly_outside_fp16_range(monkeypatch):
+    """|V| >= 65504 has no fp16 high piece: the f16 variant returns non-finite values there (never a silently saturated
+    one); the bf16 variant, which has fp32's exponent range, computes the layer."""
+    g = torch.Generator().manual_seed(3)
+    conv = torch.nn.Conv2d(16, 32, 3, padding=1).to(DEV)
+    x = (torch.randn((1, 16, 24, 32), generator=g) * 1e5).to(DEV)
+    ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+    with torch.inference_mode():
+        monkeypatch.setenv("SR_WINO_SPLIT", "f16")
+        y = ops.conv2d(x, conv)
+        assert not bool(torch.isfinite(y).all())
+        monkeypatch.setenv("SR_WINO_SPLIT", "bf16")
+        y = ops.conv2d(x, conv)
+        assert bool(torch.isfinite(y).all()) and rel_err(y, ref.float()) < 2e-5

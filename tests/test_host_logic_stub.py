@@ -203,3 +203,43 @@ def test_per_shape_library_answers_are_asked_once(stub):
     stub.prefer_wino = True     # the library's answer is a pure function of the shape: the cached one is returned
     assert ops._shape_query(lib, "sr_conv_prefers_wino", 1, 8, 16, 16, 32, 3, 1) == 0 and len(stub) == n
     assert ops._shape_query(lib, "sr_conv_prefers_wino", 2, 8, 16, 16, 32, 3, 1) == 1 and len(stub) == n + 1
+
+
+def test_split_precision_switch_repacks_the_winograd_weight(stub, monkeypatch):
+    """SR_WINO_SPLIT (the fenced split-precision Winograd variant) changes what a packed weight CONTAINS (16-bit pieces in the
+    fp32 layout's buffer): the cache must re-pack when the switch changes and hit otherwise; off-values mean the fp32 path."""
+    from torch import nn
+
+    from simplerecon_amd import ops
+    monkeypatch.setattr(ops, "_await_packed", lambda *a, **k: None)
+    monkeypatch.setattr(ops, "_packed_here", lambda *a, **k: None)
+    conv = nn.Conv2d(16, 32, 3, padding=1)
+    for off in ("", "0", "off", "fp32"):
+        monkeypatch.setenv("SR_WINO_SPLIT", off)
+        assert ops.wino_split_mode() == ""
+    monkeypatch.delenv("SR_WINO_SPLIT")
+    ops.packed_wino_weight(conv)
+    n = stub.count("sr_wino_pack_weights")
+    ops.packed_wino_weight(conv)
+    assert stub.count("sr_wino_pack_weights") == n            # cache hit
+    monkeypatch.setenv("SR_WINO_SPLIT", "f16")
+    assert ops.wino_split_mode() == "f16"
+    ops.packed_wino_weight(conv)
+    assert stub.count("sr_wino_pack_weights") == n + 1        # re-packed as 16-bit pieces
+    ops.packed_wino_weight(conv)
+    assert stub.count("sr_wino_pack_weights") == n + 1
+    monkeypatch.setenv("SR_WINO_SPLIT", "bf16")
+    ops.packed_wino_weight(conv)
+    assert stub.count("sr_wino_pack_weights") == n + 2
+    monkeypatch.setenv("SR_WINO_SPLIT", "0")
+    ops.packed_wino_weight(conv)
+    assert stub.count("sr_wino_pack_weights") == n + 3        # and back to fp32 fragments
+
+
+def test_fenced_workloads_label_their_arithmetic():
+    """The split-precision workloads are separate registry entries whose bench line says what they compute with; the default
+    workload is the fp32 one."""
+    import bench_workloads as bw
+    assert bw.DEFAULT == "hero_cfg3" and bw.HeroCfg3.dtype == "f32"
+    for name in ("hero_cfg3_bf16x3", "hero_cfg3_f16x3", "hero_cfg3_bf16x3_convs", "hero_cfg3_f16x3_convs"):
+        assert name in bw.WORKLOADS
