@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 GPU suite: smoke + full GPU tests + bench lines + rocprofv3 kernel stats + PMC passes.
-# usage: scripts/gpu_suite_r04.sh [tests|bench|prof|pmc|pmcdot ...]   (default: everything)
+# usage: scripts/gpu_suite_r04.sh [tests|bench|fenced|prof|pmc|pmcdot ...]   (default: everything but `fenced`)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; export TMPDIR=/tmp; O=$R/gpurun_out; mkdir -p $O
 WHAT=${@:-tests bench prof pmc pmcdot}
@@ -16,6 +16,16 @@ bench)
   done
   timeout 300 python bench.py --gpus 1 --force-collective --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_hero_cfg3_rccl_world1.json 2> $O/bench_rccl.err
   cut -c1-400 $O/bench_hero_cfg3.json; for wl in hero_b1 hero_cfg3_noprior hero_cfg3_graph hero_b1_graph hero_cfg4_stream hero_cfg5_volume hero_cfg5 dot_cfg2 dot_b8 hero_cfg3_rccl_world1; do cut -c1-190 $O/bench_$wl.json; done ;;
+fenced)   # the split-precision experiments: never the headline
+  for wl in hero_cfg3_bf16x3 hero_cfg3_f16x3 hero_cfg3_bf16x3_convs hero_cfg3_f16x3_convs hero_b1_graph_f16x3_convs; do
+    timeout 400 python bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_$wl.json 2> $O/bench_$wl.err
+    cut -c1-190 $O/bench_$wl.json
+  done
+  timeout 300 python scripts/mlp_split_check.py > $O/mlp_split_check.txt 2>&1
+  timeout 300 python scripts/wino_split_check.py > $O/wino_split_check.txt 2>&1
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_hero_cfg3_f16x3_convs -o f16x3 -- python $R/bench.py --workload hero_cfg3_f16x3_convs --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/prof_f16x3.log 2>&1
+  cd $R; head -8 $O/prof_hero_cfg3_f16x3_convs/f16x3_kernel_stats.csv | cut -c1-150 ;;
 prof)
   cd /tmp
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_hero_cfg3 -o hero_cfg3 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/prof_hero_cfg3.log 2>&1
