@@ -563,6 +563,9 @@ template <> struct SrSplitFmt<2> {   // two fp16 pieces: 22-24 significant bits 
 //   table  [0,512):   w3tab (128) | b3 (1) | pad | b2tab at 256 (128: C layout, [half][mt][r])
 //   W2     8 steps x [mt 4][piece 2][lane 64][4 words]                        = 16384 words
 //   W1var  per view: step A [mt 4][piece 2][lane 64][4] (2048) + metadata step [mt 4][piece 2][lane 32][4] (1024)
+#ifndef SR_SPL_ABL
+#define SR_SPL_ABL 0   // phase ablation (tuning builds only; wrong results): 1 no tap loads, 2 no layer-1 MFMAs, 4 no layer-2 MFMAs
+#endif
 #define SR_SPL_TAB 512
 #define SR_SPL_W2_WORDS 16384
 #define SR_SPL_VIEW_WORDS 3072
@@ -793,7 +796,10 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_split_kernel(SrMlpParams
       const float4* t_sw = reinterpret_cast<const float4*>(img + (size_t)smp.o_sw * C);
       const float4* t_se = reinterpret_cast<const float4*>(img + (size_t)smp.o_se * C);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { taps[i] = t_nw[i]; taps[4 + i] = t_ne[i]; taps[8 + i] = t_sw[i]; taps[12 + i] = t_se[i]; }
+      for (int i = 0; i < 4; ++i) {
+        if (SR_SPL_ABL & 1) { taps[i] = taps[4 + i] = taps[8 + i] = taps[12 + i] = make_float4(smp.w_nw, smp.w_ne, smp.w_sw, smp.w_se); }
+        else { taps[i] = t_nw[i]; taps[4 + i] = t_ne[i]; taps[8 + i] = t_sw[i]; taps[12 + i] = t_se[i]; }
+      }
     };
     float rv0, rv1, rv2, rsd, rdot;
 #define SR_SPLIT_VIEW                                                                     \
@@ -834,10 +840,10 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_split_kernel(SrMlpParams
         sr_swap_halves_u4(sr_u4v{ph[8], ph[9], ph[10], ph[11]}, zero4, mPh, mQh);                        \
         sr_swap_halves_u4(sr_u4v{pl[8], pl[9], pl[10], pl[11]}, zero4, mPl, mQl);                        \
         issue_view(kn);                                                                                  \
-        sr_spl_step<FMT, (FIRST) ? 1 : 0>(acc, hc, wk + lane, 64, bPh, bPl, bQh, bQl);                             \
+        if (!(SR_SPL_ABL & 2) || (FIRST)) sr_spl_step<FMT, (FIRST) ? 1 : 0>(acc, hc, wk + lane, 64, bPh, bPl, bQh, bQl); \
         SR_RAY_A(fn, g, kn) SR_RAY_B(fn) SR_RAY_C(fn)                                                    \
         SR_SB                                                                                            \
-        sr_spl_step<FMT, 0>(acc, hc, wk + 512 + (lane & 31), 32, mPh, mPl, mQh, mQl);                \
+        if (!(SR_SPL_ABL & 2)) sr_spl_step<FMT, 0>(acc, hc, wk + 512 + (lane & 31), 32, mPh, mPl, mQh, mQl); \
         SR_INTERP2(fn, 0, 0) SR_INTERP2(fn, 0, 1) SR_INTERP2(fn, 1, 0) SR_INTERP2(fn, 1, 1)              \
         SR_INTERP2(fn, 2, 0) SR_INTERP2(fn, 2, 1) SR_INTERP2(fn, 3, 0) SR_INTERP2(fn, 3, 1)              \
         SR_DOT(fn)                                                                                       \
@@ -868,7 +874,7 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_split_kernel(SrMlpParams
           }
         const sr_u4v* w2 = W2s + (size_t)s * 512 + lane;
         if (s == 0) sr_spl_step<FMT, 2>(acc2, acc2, w2, 64, bh[0], bl[0], bh[1], bl[1]);
-        else sr_spl_step<FMT, 0>(acc2, acc2, w2, 64, bh[0], bl[0], bh[1], bl[1]);
+        else if (!(SR_SPL_ABL & 4)) sr_spl_step<FMT, 0>(acc2, acc2, w2, 64, bh[0], bl[0], bh[1], bl[1]);
       }
 
       // layer 3 (128 -> 1) on acc2 + b2; w3tab and b2tab in LDS (C layout)
