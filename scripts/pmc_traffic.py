@@ -23,7 +23,7 @@ def main(rnd):
     path = os.path.join(R, "profiles", "traffic.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
     lines = []
-    for wl, tag, kerns in (("hero_cfg3", "hero", {"hero_cfg3": "sr_wino_kernel<2, true, true>", "hero_cfg3:mlp_sweep": "sr_mlp_volume_kernel"}),
+    for wl, tag, kerns in (("hero_cfg3", "hero", {"hero_cfg3": "sr_wino_kernel<2, true, true", "hero_cfg3:mlp_sweep": "sr_mlp_volume_kernel"}),
                            ("hero_cfg5_volume", "cfg5", {"hero_cfg5_volume": "sr_mlp_volume_kernel"})):
         f, w = agg(tag, "FETCH_SIZE"), agg(tag, "WRITE_SIZE")
         if not f:

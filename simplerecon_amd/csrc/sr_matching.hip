@@ -191,59 +191,77 @@ __device__ __forceinline__ float4 sr_maxblur_generic(const float* __restrict__ i
   return acc;
 }
 
-// One thread = a 2x2 block of output pixels x 4 channels.  Interior blocks stream their 7x7 input window row by
-// row (49 float4 loads for 4 outputs): vertical max with the previous row, horizontal max, horizontal blur for the
-// two output columns, then the row's contribution to the two output rows.
+// One thread = a block of 2 x BW output pixels x 4 channels (BW = 2 or 4).  Interior blocks stream their 7 x (2 BW + 3) input
+// window row by row (49 float4 loads for 4 outputs, 77 for 8): vertical max with the previous row, horizontal max,
+// horizontal blur for the BW output columns, then the row's contribution to the two output rows.  (BW = 4 is an ablation
+// switch: measured slower, see sr_maxblurpool_nhwc_fwd.)
+template <int BW>
 __global__ __launch_bounds__(256) void sr_maxblurpool_kernel(const float* __restrict__ in, int64_t in_sb, int in_sp,
                                                              float* __restrict__ out, int64_t out_sb, int out_sp,
-                                                             int H, int W, int Ho, int Wo, int C4) {
+                                                             int H, int W, int Ho, int Wo, int C4, int xcd_order) {
+  constexpr int WC = 2 * BW + 3;   // input columns of a block's window
   const int Hm = H - 1, Wm = W - 1;
-  const int bx = (Wo + 1) / 2, by = (Ho + 1) / 2;
+  const int bx = (Wo + BW - 1) / BW, by = (Ho + 1) / 2;
   const int64_t total = (int64_t)bx * by * C4;
-  const float* __restrict__ ib = in + (int64_t)blockIdx.y * in_sb;
-  float* __restrict__ ob = out + (int64_t)blockIdx.y * out_sb;
   const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+  // XCD-aware work order (r04): workgroups are dispatched round-robin over the 8 XCDs, each with its own L2, and vertically
+  // adjacent block rows share 3 of their 7 input rows -- 5 workgroups apart at 120x160, i.e. always in another L2 (r02-r03 PMC:
+  // 1.75 x the algorithmic bytes = exactly 7 / 4).  When the grid covers the map without striding, XCD x takes the contiguous
+  // eighth [x T / 8, (x + 1) T / 8) of the launch's workgroups (images included), so neighbouring rows meet in one L2
+  // (r04 PMC: 2 755 -> 1 612 MB per launch = 1.02 x the algorithmic bytes).
+  unsigned bxi = blockIdx.x, byi = blockIdx.y;
+  if (xcd_order) {
+    const unsigned T = gridDim.x * gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned Lp = (L & 7u) * (T >> 3) + (L >> 3);
+    byi = Lp / gridDim.x;
+    bxi = Lp - byi * gridDim.x;
+  }
+  const float* __restrict__ ib = in + (int64_t)byi * in_sb;
+  float* __restrict__ ob = out + (int64_t)byi * out_sb;
+  for (int64_t idx = (int64_t)bxi * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % C4);
     const int blk = (int)(idx / C4);
-    const int oy0 = 2 * (blk / bx), ox0 = 2 * (blk % bx);
+    const int oy0 = 2 * (blk / bx), ox0 = BW * (blk % bx);
     const int y0 = 2 * oy0 - 1, x0 = 2 * ox0 - 1;  // first max-pooled row / column of the window
-    if (y0 >= 0 && y0 + 5 < Hm && x0 >= 0 && x0 + 5 < Wm && oy0 + 1 < Ho && ox0 + 1 < Wo) {
+    if (y0 >= 0 && y0 + 5 < Hm && x0 >= 0 && x0 + 2 * BW + 1 < Wm && oy0 + 1 < Ho && ox0 + BW - 1 < Wo) {
       const float* q = ib + ((int64_t)y0 * W + x0) * in_sp + 4 * c4;
-      float4 prev[7], acc[2][2];
+      float4 prev[WC], acc[2][BW];
 #pragma unroll
-      for (int j = 0; j < 7; ++j) prev[j] = sr_ld4(q + (int64_t)j * in_sp);
+      for (int j = 0; j < WC; ++j) prev[j] = sr_ld4(q + (int64_t)j * in_sp);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b2 = 0; b2 < BW; ++b2) acc[a][b2] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         q += (int64_t)W * in_sp;
-        float4 vm[7];
+        float4 vm[WC];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
+        for (int j = 0; j < WC; ++j) {
           const float4 cur = sr_ld4(q + (int64_t)j * in_sp);
           vm[j] = sr_max4(prev[j], cur);
           prev[j] = cur;
         }
-        float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f), h1 = h0;
+        float4 mp[WC - 1];   // the max-pooled row: horizontal max of neighbouring columns
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          h0 = sr_axpy4(f[j], sr_max4(vm[j], vm[j + 1]), h0);
-          h1 = sr_axpy4(f[j], sr_max4(vm[j + 2], vm[j + 3]), h1);
+        for (int j = 0; j < WC - 1; ++j) mp[j] = sr_max4(vm[j], vm[j + 1]);
+#pragma unroll
+        for (int b2 = 0; b2 < BW; ++b2) {
+          float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h = sr_axpy4(f[j], mp[2 * b2 + j], h);
+          if (i < 4) acc[0][b2] = sr_axpy4(f[i], h, acc[0][b2]);
+          if (i >= 2) acc[1][b2] = sr_axpy4(f[i - 2], h, acc[1][b2]);
         }
-        if (i < 4) { acc[0][0] = sr_axpy4(f[i], h0, acc[0][0]); acc[0][1] = sr_axpy4(f[i], h1, acc[0][1]); }
-        if (i >= 2) { acc[1][0] = sr_axpy4(f[i - 2], h0, acc[1][0]); acc[1][1] = sr_axpy4(f[i - 2], h1, acc[1][1]); }
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b2 = 0; b2 < 2; ++b2)
+        for (int b2 = 0; b2 < BW; ++b2)
           *reinterpret_cast<float4*>(ob + ((int64_t)(oy0 + a) * Wo + ox0 + b2) * out_sp + 4 * c4) = acc[a][b2];
     } else {
       for (int a = 0; a < 2; ++a)
-        for (int b2 = 0; b2 < 2; ++b2) {
+        for (int b2 = 0; b2 < BW; ++b2) {
           const int oy = oy0 + a, ox = ox0 + b2;
           if (oy < Ho && ox < Wo)
             *reinterpret_cast<float4*>(ob + ((int64_t)oy * Wo + ox) * out_sp + 4 * c4) =
@@ -533,6 +551,7 @@ struct SrT16Params {
   int H, W, Cin, Cout, replicate;
   int tiles_x, tiles_y, total;
   float out_slope;
+  int xcd_order;                      // 1: tiles of a round are dealt to the XCDs in contiguous eighths (SR_T16_XCD, default 1)
 };
 
 __global__ void sr_t16_pack_kernel(const float* __restrict__ w /*[Cout,Cin,3,3]*/, float* __restrict__ packed, int Cout,
@@ -554,7 +573,14 @@ __global__ __launch_bounds__(256, 3) void sr_t16_kernel(SrT16Params p) {
   const int cq = tid & 7;  // this thread stages channels 4*cq .. 4*cq+3 of every slab
   const float4* wl = reinterpret_cast<const float4*>(p.wp) + lane;
 
-  for (int tile = blockIdx.x; tile < p.total; tile += gridDim.x) {
+  for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
+    // XCD-aware work order (r04; as in sr_wino_kernel): in a full round the grid's tiles are dealt to the XCDs in contiguous
+    // eighths, so that the halo two neighbouring tiles share is fetched into one L2
+    int tile = work;
+    if (p.xcd_order && (gridDim.x & 7) == 0) {
+      const int G = (int)gridDim.x, r0 = work / G * G;
+      if (r0 + G <= p.total) { const int bb = work - r0; tile = r0 + (bb & 7) * (G >> 3) + (bb >> 3); }
+    }
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
     const int oy0 = 8 * ty, ox0 = 16 * tx;
     const float* __restrict__ in_b = p.in + (int64_t)b * p.in_sb;
@@ -704,6 +730,7 @@ extern "C" int sr_conv3x3_c16_nhwc_fwd(const float* in, int64_t in_batch_stride,
   p.out_slope = leaky_slope;
   int blocks = 3 * sr_cus();
   if (blocks > p.total) blocks = p.total;
+  { const char* e = getenv("SR_T16_XCD"); p.xcd_order = e ? atoi(e) : 1; }   // (ablation; results are identical)
   const bool norm = in_stats != nullptr, act = in_leaky_slope >= 0.f;
   if (norm && act) hipLaunchKernelGGL((sr_t16_kernel<true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
   else if (norm) hipLaunchKernelGGL((sr_t16_kernel<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
@@ -753,10 +780,19 @@ extern "C" int sr_maxblurpool_nhwc_fwd(const float* in, int64_t in_batch_stride,
       ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
     return SR_ERR_UNSUPPORTED;
   const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
-  const int64_t total = (int64_t)((Ho + 1) / 2) * ((Wo + 1) / 2) * (C / 4);
+  int bw = 2;   // output columns per thread.  4 (SR_POOL_BW=4, Wo % 4 == 0) issues 9.6 instead of 12.25 loads per output and is
+  { const char* e = getenv("SR_POOL_BW"); if (e && atoi(e) == 4 && Wo % 4 == 0) bw = 4; }   // SLOWER: 0.70 vs 0.45 ms per 64 images
+                                                                                            // (half the threads, twice the registers)
+  const int64_t total = (int64_t)((Ho + 1) / 2) * ((Wo + bw - 1) / bw) * (C / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(sr_maxblurpool_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, in, in_batch_stride,
-                     in_pix_stride, out, out_batch_stride, out_pix_stride, H, W, Ho, Wo, C / 4);
+  int xcd = ((int64_t)blocks * 256 >= total) && (((int64_t)blocks * B) % 8 == 0);   // no striding, whole eighths
+  { const char* e = getenv("SR_POOL_XCD"); if (e && atoi(e) == 0) xcd = 0; }          // (ablation; results are identical)
+  if (bw == 4)
+    hipLaunchKernelGGL((sr_maxblurpool_kernel<4>), dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, in, in_batch_stride,
+                       in_pix_stride, out, out_batch_stride, out_pix_stride, H, W, Ho, Wo, C / 4, xcd);
+  else
+    hipLaunchKernelGGL((sr_maxblurpool_kernel<2>), dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, in, in_batch_stride,
+                       in_pix_stride, out, out_batch_stride, out_pix_stride, H, W, Ho, Wo, C / 4, xcd);
   return sr_hip_rc(hipGetLastError());
 }
 
