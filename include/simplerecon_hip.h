@@ -208,7 +208,11 @@ int sr_warp_features_fwd(const float* src, const float* K_src, const float* T_sr
  */
 size_t sr_mlp_volume_workspace_bytes(int B, int K, int C, int h, int w, int hidden);
 
-/* Packs the MLP parameters into the k-step order of the sweep kernel (into `workspace`). */
+/* Packs the MLP parameters into the k-step order of the sweep kernel (into `workspace`).
+ * Experiment switch (off by default, read per call by the pack AND the sweep, which must agree): environment
+ * SR_MLP_SPLIT=bf16|f16 packs layers 1-2 as two 16-bit pieces per weight and selects the split-precision sweep kernel
+ * (three exact 16-bit MFMA products per fp32 product, fp32 accumulate; K <= 7 source views, SR_ERR_UNSUPPORTED beyond;
+ * unknown values: SR_ERR_INVALID_ARGUMENT).  Tensors handed in and results are fp32 either way. */
 int sr_mlp_pack_weights(const float* W1, const float* b1, const float* W2, const float* b2,
                         const float* W3, const float* b3, int hidden, int B, int K, int C, int h, int w,
                         void* workspace, size_t workspace_bytes, void* stream);
@@ -297,6 +301,9 @@ int sr_conv2d_splitk_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_p
  * sr_wino_pack_weights (U = G g G^T in MFMA B-fragment order).  sr_conv_prefers_wino() tells whether this kernel
  * is expected to beat the direct one for a shape (enough 8x16-pixel regions, little padding). */
 size_t sr_wino_packed_weight_floats(int Cout, int Cin);
+/* Experiment switch (off by default, read per call by the pack AND the convolution, which must agree): environment
+ * SR_WINO_SPLIT=bf16|f16 packs U as two 16-bit pieces (same buffer size) and selects the split-precision kernel (vector
+ * instantiation and fp32 tensors only: SR_ERR_UNSUPPORTED otherwise; unknown values: SR_ERR_INVALID_ARGUMENT). */
 int sr_wino_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream);
 int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
