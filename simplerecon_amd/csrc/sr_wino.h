@@ -66,6 +66,7 @@ struct SrWinoParams {
   // activation) to part + ks * part_stride (dense channels-last [B, H*W, Cout]); sr_wino_reduce_kernel finishes.
   int ksplit; float* part; int64_t part_stride;
   int xcd_order;   // 1: items of a round are dealt to the XCDs in contiguous eighths (SR_WINO_XCD, default 1)
+  int stagger;     // the second half of the persistent grid (the second workgroup of every CU) starts this many s_sleep(127) late
 #ifdef SR_WINO_TRACE
   unsigned long long* trace;  // [blocks][SR_TR_REGIONS][SR_TR_EVENTS] shader-clock stamps (debug builds only)
 #endif

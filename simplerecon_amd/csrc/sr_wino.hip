@@ -294,6 +294,11 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES) v
   float4 av[2][4];   // A operands of the current slab: [g][uc]
   float4 wq[4];
   Region reg = decode(blockIdx.x < (unsigned)p.total ? (int)blockIdx.x : 0), nxt = reg;
+  // SR_WINO_STAGGER (experiment, default 0): two persistent workgroups share a CU and run items of equal length; if they start
+  // together they stay in phase -- both in their MFMA streams, then both in their epilogues.  The switch delays the second half
+  // of the grid once, at launch (host side: what it does and does not buy).
+  if (p.stagger > 0 && blockIdx.x >= (gridDim.x >> 1))
+    for (int s = 0; s < p.stagger; ++s) __builtin_amdgcn_s_sleep(127);
   for (int work = blockIdx.x; work < p.total; work += gridDim.x) {
     const int b = reg.b, oy0 = reg.oy0, ox0 = reg.ox0, co0 = reg.co0, sl0 = reg.ks * chunks;
     wu_lane = (unsigned)(kk * p.Co_pad + co0 + i) * 16u;
@@ -840,10 +845,17 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   p.debug = 0;
 #endif
   { const char* e = getenv("SR_WINO_XCD"); p.xcd_order = e ? atoi(e) : 1; }
+  p.stagger = -1;
+  { const char* e = getenv("SR_WINO_STAGGER"); if (e) p.stagger = atoi(e); }   // experiment switch, see below
   hipStream_t stream = (hipStream_t)stream_;
   int blocks = sr_wino_num_cus() * (nt == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES);
   { const char* e = getenv("SR_WINO_WG_PER_CU"); if (e && atoi(e) == 1) blocks = sr_wino_num_cus(); }  // ablation
   if (blocks > p.total) blocks = p.total;
+  if (p.stagger < 0) p.stagger = 0;
+  // (Measured, r04: an offset of 3 x s_sleep(127) is -14 % / -15 % on 64 -> 64 / 192 -> 64 @ 8x240x320 in an isolated loop over
+  // one layer -- 250 -> 216 us, 614 -> 519 us -- and NOTHING in the step: the same layers run 142 us on average inside the model
+  // with or without it, 28.44 vs 28.64 ms per step.  Launched back to back from a queue that runs ahead of the GPU the
+  // workgroups of a launch do not start in phase in the first place; the loop's launch gaps made them.  Off by default.)
   const size_t lds = (size_t)WN_LDS_FLOATS(nt) * sizeof(float);
 #ifdef SR_WINO_TRACE
   static unsigned long long* trace_buf = nullptr;
