@@ -3,6 +3,7 @@ against the ctypes signature table (argument count and kinds) and returns succes
 argument packing, output allocation, mask handling, the autograd seams and their bookkeeping -- runs without a GPU.
 No numerics here: the kernels themselves are covered by the `-m gpu` tests."""
 import contextlib
+import os
 import ctypes
 
 import pytest
@@ -243,3 +244,18 @@ def test_fenced_workloads_label_their_arithmetic():
     assert bw.DEFAULT == "hero_cfg3" and bw.HeroCfg3.dtype == "f32"
     for name in ("hero_cfg3_bf16x3", "hero_cfg3_f16x3", "hero_cfg3_bf16x3_convs", "hero_cfg3_f16x3_convs"):
         assert name in bw.WORKLOADS
+
+
+def test_split_precision_context_manager_sets_and_restores_the_switches(monkeypatch):
+    from simplerecon_amd import experimental, ops
+    monkeypatch.delenv("SR_MLP_SPLIT", raising=False)
+    monkeypatch.setenv("SR_WINO_SPLIT", "bf16")
+    with experimental.split_precision("f16"):
+        assert os.environ["SR_MLP_SPLIT"] == "f16" and ops.wino_split_mode() == "f16"
+        with experimental.split_precision("bf16", convs=False):
+            assert os.environ["SR_MLP_SPLIT"] == "bf16" and ops.wino_split_mode() == "f16"
+        assert os.environ["SR_MLP_SPLIT"] == "f16"
+    assert "SR_MLP_SPLIT" not in os.environ and ops.wino_split_mode() == "bf16"
+    with pytest.raises(ValueError):
+        with experimental.split_precision("int8"):
+            pass
