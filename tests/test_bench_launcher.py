@@ -72,3 +72,25 @@ def test_rank_pinning_gives_local_ranks_disjoint_core_slices():
 def bench_cpu_list():
     import bench
     return bench._cpu_list("0-3,8,10-11")
+
+
+def test_fenced_experiment_field_never_costs_the_line(monkeypatch):
+    """bench._fenced_experiment parses the child's JSON line into a `"headline": false` record and turns any failure of the
+    child (crash, time-out, no line) into a record that says so."""
+    import json
+    import subprocess
+
+    import bench
+
+    class R:
+        stdout = 'noise\n' + json.dumps({"metric": "m", "value": 400.0, "unit": "frames/s", "ms_per_step": 20.0, "steps": 10,
+                                         "dtype": "f32 I/O ...; 2 x f16 pieces"}).replace('{"metric"', '{"metric"') + "\n"
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R())
+    rec = bench._fenced_experiment("hero_cfg3_f16x3_convs", 10, 3)
+    assert rec["headline"] is False and rec["value"] == 400.0 and rec["ms_per_step"] == 20.0 and "f16" in rec["dtype"]
+
+    def boom(*a, **k):
+        raise subprocess.TimeoutExpired(cmd="bench", timeout=180)
+    monkeypatch.setattr(subprocess, "run", boom)
+    rec = bench._fenced_experiment("hero_cfg3_f16x3_convs", 10, 3)
+    assert rec["headline"] is False and rec["value"] is None and "TimeoutExpired" in rec["note"]
