@@ -312,6 +312,23 @@ int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pi
                              int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
                              int Cout, float leaky_slope, void* stream);
 
+/* The same operator through Winograd F(4x4, 3x3) (csrc/sr_wino4.hip, r05): 2.25 multiplies per output and channel pair
+ * instead of F(2x2)'s 4 -- 1.78x fewer MFMAs on the full-resolution 64-channel layers of the UNet++ decoder (reference
+ * modules/networks.py:20-96, BasicBlock modules/layers.py:24-85).  Interpolation points (0, +-1/2, +-2, inf): exact fp32
+ * transforms, fp32 products and accumulation; fp32 error ~1.3e-6 of the output range on a 64-channel layer (F(2x2): 3e-7).
+ * `packed_u` comes from sr_wino4_pack_weights (U = G g G^T, computed in double, in MFMA A-fragment order).  Needs channel
+ * counts in whole quads and 16-byte aligned rows (SR_ERR_UNSUPPORTED otherwise: use sr_conv3x3_wino_nhwc_fwd).
+ * sr_conv_prefers_wino4(): 1 when this kernel is expected to beat F(2x2) for the shape (16x16-pixel regions with little
+ * padding, whole 64-channel output blocks, several rounds of work items); `mode` 0 = never, 1 = that rule, 2 = wherever it
+ * applies.  The mode is an ARGUMENT (the Python host reads SR_CONV_WINO4 once at import): no environment reads in here. */
+size_t sr_wino4_packed_weight_floats(int Cout, int Cin);
+int sr_wino4_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream);
+int sr_conv_prefers_wino4(int B, int H, int W, int Cin, int Cout, int mode);
+int sr_conv3x3_wino4_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u,
+                              const float* bias, const float* residual, int64_t res_batch_stride, int res_pix_stride,
+                              float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                              int Cout, float leaky_slope, void* stream);
+
 /* Split-K variant for layers with few output regions and a long chain of input slabs (deep low-resolution levels,
  * batch 1): work items cover Cin / ks input channels each and store raw partial outputs to `workspace`
  * ([ks][B, H*W, Cout] floats, 16-byte aligned); a second kernel adds them in index order (deterministic) and applies

@@ -122,6 +122,10 @@ SIGNATURES = {
                                              _p, _sz, _p]),
     "sr_wino_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "sr_conv3x3_wino_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "sr_wino4_packed_weight_floats": (_sz, [_i, _i]),
+    "sr_wino4_pack_weights": (_i, [_p, _i, _i, _p, _p]),
+    "sr_conv_prefers_wino4": (_i, [_i, _i, _i, _i, _i, _i]),
+    "sr_conv3x3_wino4_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _p]),
     "sr_conv_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "sr_upsample2x_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "sr_exp_fwd": (_i, [_p, _p, _i64, _p]),

@@ -1,0 +1,458 @@
+// sr_wino4.hip -- 3x3 / stride-1 convolutions through Winograd F(4x4, 3x3) on the fp32 matrix cores (gfx950), r05.
+//
+// Same operator as sr_conv3x3_wino_nhwc_fwd (conv + bias + residual + LeakyReLU of the reference's BasicBlock,
+// modules/layers.py:24-85), same arithmetic class (fp32 products, fp32 accumulation).  F(4x4, 3x3) needs 36 multiplies per
+// 4x4 output tile and (input, output) channel pair -- 2.25 per output instead of F(2x2)'s 4 and the direct algorithm's 9 --
+// so the full-resolution 64-channel layers of the UNet++ decoder (179 of the conv stack's 327 GFLOP per frame, SURVEY.md
+// appendix B) issue 1.78x fewer MFMAs than sr_wino_kernel.  Interpolation points (0, +-1/2, +-2, inf): every entry of B^T and
+// A^T is a dyadic rational (exact in fp32); measured fp32 error 1.3e-6 of the output range on a 64-channel layer (points
+// 0, +-1, +-2: 2.4e-6; F(2x2): 3e-7), far inside the 1e-4 parity bar -- tests/test_gpu_wino4.py holds it against fp64.
+//
+// Work item = 4 x 4 Winograd tiles (16 x 16 output pixels) x 64 output channels; a workgroup (4 waves, 2 per CU) walks
+// items persistently.  Per 16-channel slab of the input:
+//   S  the 18 x 18 pixel patch goes global -> registers -> LDS (`raw`, 20 floats per pixel); the loads of slab s + 1 are
+//      issued before the transform of slab s and have a whole slab of lead,
+//   T  thread (tile, ci) applies V = B^T d B to its 6 x 6 patch: 36 ds_read_b32, 144 VALU, 36 ds_write_b32 into
+//      V[36 frequencies][16 tiles][16 ci] (the channel quads of a tile row XOR-swizzled so that the MFMA phase's
+//      ds_read_b128 are conflict-free),
+//   M  wave w owns output channels [16 w, 16 w + 16) for ALL 36 frequencies: v_mfma_f32_16x16x4_f32 with
+//      A = U_f[co][ci] (one 16-byte load per lane and frequency from the packed weights, L2-resident) and
+//      B = V_f[ci][tile] (one ds_read_b128 per lane and frequency), D[co][tile] -- 144 accumulator registers.
+// Because a lane holds all 36 frequencies of (4 consecutive output channels) x (one tile), the output transform
+// Y = A^T M A runs entirely in registers, IN PLACE over the accumulators (no LDS exchange, no barrier): a lane ends up with
+// 16 pixels x 4 channels = 16 float4: bias + residual + activation, 16-byte stores into the consumer's concat slice.
+#include <stdlib.h>
+
+#include "sr_common.h"
+
+namespace {
+
+typedef float w4_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int w4_u4 __attribute__((ext_vector_type(4)));
+#define W4_RSRC_FLAGS 0x00020000
+#define W4_OOB 0x7fffffffu
+
+constexpr int W4_PS = 18;                                // patch side: 16 output pixels + 2
+constexpr int W4_RS = 20;                                // floats per staged pixel (16 channels + 4 pad: tiles 4 px apart -> other banks)
+constexpr int W4_RAW_FLOATS = W4_PS * W4_PS * W4_RS;     // 6480
+constexpr int W4_V_FLOATS = 36 * 16 * 16;                // 9216
+constexpr int W4_LDS_BYTES = (W4_RAW_FLOATS + W4_V_FLOATS) * 4;   // 62 784: two workgroups per CU
+constexpr int W4_STAGE = 6;                              // float4 loads per thread and slab (1296 of 1536 slots)
+#ifndef SR_W4_NA
+#define SR_W4_NA 3
+#define SR_W4_PD 2
+#endif
+constexpr int W4_NA = SR_W4_NA, W4_PD = SR_W4_PD;                      // weight-fragment register sets / prefetch distance (frequency pairs)
+
+// Phase ablations (timing experiments only, results are wrong): -DSR_W4_ABL=<bits>  1: no transform, 2: no MFMA phase,
+// 4: no epilogue, 8: every weight fragment from one cached address, 16: no staging loads / stores, 32: no operand loads in
+// the MFMA phase (bare MFMAs).  0 in the product build.
+#ifndef SR_W4_ABL
+#define SR_W4_ABL 0
+#endif
+
+struct SrWino4Params {
+  const float* in; int64_t in_sb; int in_sp;
+  const float* wu;                   // packed U: [36][S][4 kq][Co_pad][4]
+  const float* bias;
+  const float* res; int64_t res_sb; int res_sp;
+  float* out; int64_t out_sb; int out_sp;
+  int B, H, W, Cin, Cout, Co_pad, S;
+  int regions_x, regions_y, co_blocks, total;
+  float slope;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_rsrc(const void* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, W4_RSRC_FLAGS);
+}
+__device__ __forceinline__ w4_f4 w4_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(w4_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+// (the delta rides in the LANE offset: a 16-byte buffer store with an SGPR offset operand followed by a VALU write to its
+// data registers stores the new contents on gfx950 -- sr_wino.h, r04)
+__device__ __forceinline__ void w4_store(w4_f4 v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, v), r, (int)voff, 0, 0);
+}
+
+// B^T for the points (0, 1/2, -1/2, 2, -2, inf):
+//   [1 0 -17/4 0 1 0; 0 -2 -4 1/2 1 0; 0 2 -4 -1/2 1 0; 0 -1/2 -1/4 2 1 0; 0 1/2 -1/4 -2 1 0; 0 1 0 -17/4 0 1]
+__device__ __forceinline__ void w4_bt(float d0, float d1, float d2, float d3, float d4, float d5, float& t0, float& t1,
+                                      float& t2, float& t3, float& t4, float& t5) {
+  const float a = fmaf(-4.0f, d2, d4), b = fmaf(-4.0f, d1, d3);
+  const float c = fmaf(-0.25f, d2, d4), e = fmaf(-0.25f, d1, d3);
+  t0 = fmaf(-4.25f, d2, d0) + d4;
+  t1 = fmaf(0.5f, b, a);
+  t2 = fmaf(-0.5f, b, a);
+  t3 = fmaf(2.0f, e, c);
+  t4 = fmaf(-2.0f, e, c);
+  t5 = fmaf(-4.25f, d3, d1) + d5;
+}
+// A^T = [1 1 1 1 1 0; 0 1/2 -1/2 2 -2 0; 0 1/4 1/4 4 4 0; 0 1/8 -1/8 8 -8 1] on four channels at once
+__device__ __forceinline__ void w4_at(w4_f4 m0, w4_f4 m1, w4_f4 m2, w4_f4 m3, w4_f4 m4, w4_f4 m5, w4_f4& s0, w4_f4& s1,
+                                      w4_f4& s2, w4_f4& s3) {
+  const w4_f4 p = m1 + m2, q = m1 - m2, u = m3 + m4, v = m3 - m4;
+  s0 = (m0 + p) + u;
+  s1 = 0.5f * q + 2.0f * v;
+  s2 = 0.25f * p + 4.0f * u;
+  s3 = 0.125f * q + (8.0f * v + m5);
+}
+
+struct W4Item { int b, oy0, ox0, co0; };
+__device__ __forceinline__ W4Item w4_decode(const SrWino4Params& p, int work) {
+  W4Item it;
+  int rem = work;
+  const int rx = rem % p.regions_x; rem /= p.regions_x;
+  const int ry = rem % p.regions_y; rem /= p.regions_y;
+  it.b = rem % p.B;
+  it.co0 = (rem / p.B) * 64;
+  it.oy0 = ry * 16;
+  it.ox0 = rx * 16;
+  return it;
+}
+
+// `off` if `ok`, else an out-of-range offset (the load returns 0, the store is dropped).  The empty asm materialises the
+// offset first: left alone the compiler turns the select into a branch around the address arithmetic (and then waits for
+// every load in flight at each of those branches).
+__device__ __forceinline__ unsigned w4_sel(bool ok, unsigned off) {
+  asm volatile("" : "+v"(off));
+  return ok ? off : W4_OOB;
+}
+
+// loads of slab `s` of the patch of item `it` into st[]: out-of-image pixels and channels past Cin read 0
+__device__ __forceinline__ void w4_stage(const SrWino4Params& p, const W4Item& it, int s, int st_q, int st_pp0,
+                                         w4_f4 (&st)[W4_STAGE]) {
+  const unsigned in_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.in_sp + p.Cin) * 4);
+  const __amdgpu_buffer_rsrc_t rs_in = w4_rsrc(p.in + (int64_t)it.b * p.in_sb, in_img_bytes);
+  const bool chan_ok = 16 * s + 4 * st_q + 4 <= p.Cin;
+  const bool interior = (it.oy0 >= 1) & (it.ox0 >= 1) & (it.oy0 + 17 <= p.H) & (it.ox0 + 17 <= p.W);   // uniform
+  const unsigned q_off = (unsigned)(16 * s + 4 * st_q) * 4u;
+  if (interior) {
+    const unsigned base = (unsigned)(((it.oy0 - 1) * p.W + (it.ox0 - 1)) * p.in_sp) * 4u;   // scalar offset operand
+#pragma unroll
+    for (int j = 0; j < W4_STAGE; ++j) {
+      const int pp = st_pp0 + 64 * j;
+      const int r = (pp * 3641) >> 16, c = pp - 18 * r;   // (recomputed per slab: six live registers less)
+      const bool ok = j < W4_STAGE - 1 ? chan_ok : (chan_ok & (pp < W4_PS * W4_PS));
+      st[j] = w4_load(rs_in, w4_sel(ok, (unsigned)((r * p.W + c) * p.in_sp) * 4u + q_off), base);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < W4_STAGE; ++j) {
+      const int pp = st_pp0 + 64 * j;
+      const int r = (pp * 3641) >> 16, c = pp - 18 * r;
+      const int y = it.oy0 - 1 + r, x = it.ox0 - 1 + c;
+      const bool ok = chan_ok & (pp < W4_PS * W4_PS) & (y >= 0) & (y < p.H) & (x >= 0) & (x < p.W);
+      st[j] = w4_load(rs_in, w4_sel(ok, (unsigned)((y * p.W + x) * p.in_sp) * 4u + q_off), 0u);
+    }
+  }
+}
+
+// epilogue of one item: Y = A^T M A in place over the accumulators (acc[6 i + j][r] = M[i][j] of output channel
+// cq + r and this lane's tile), then per output row: + bias + residual, activation, 16-byte stores.  FULL: every pixel of
+// the 16 x 16 region is inside the image (no per-lane predicate).
+template <bool FULL, bool RES>
+__device__ __forceinline__ void w4_epilogue(const SrWino4Params& p, const W4Item& it, w4_f4 (&acc)[36], int cq, int m_j) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    w4_at(acc[j], acc[6 + j], acc[12 + j], acc[18 + j], acc[24 + j], acc[30 + j], acc[j], acc[6 + j], acc[12 + j],
+          acc[18 + j]);
+  const int oy = it.oy0 + 4 * (m_j >> 2), ox = it.ox0 + 4 * (m_j & 3);
+  const bool cq_ok = cq < p.Cout;
+  const unsigned out_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.out_sp + p.Cout) * 4);
+  const __amdgpu_buffer_rsrc_t rs_out = w4_rsrc(p.out + (int64_t)it.b * p.out_sb, out_img_bytes);
+  const unsigned res_img_bytes = RES ? (unsigned)(((int64_t)(p.H * p.W - 1) * p.res_sp + p.Cout) * 4) : 0u;
+  const __amdgpu_buffer_rsrc_t rs_res = w4_rsrc(RES ? p.res + (int64_t)it.b * p.res_sb : p.wu, res_img_bytes);
+  // lane offsets of the tile's first pixel; a lane whose channel quad is past Cout is switched off for good
+  const unsigned o0 = w4_sel(cq_ok, (unsigned)((oy * p.W + ox) * p.out_sp + cq) * 4u);
+  const unsigned r0 = RES ? w4_sel(cq_ok, (unsigned)((oy * p.W + ox) * p.res_sp + cq) * 4u) : 0u;
+  w4_f4 bv = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (p.bias) bv = __builtin_bit_cast(w4_f4, __builtin_amdgcn_raw_buffer_load_b128(w4_rsrc(p.bias, (int64_t)p.Cout * 4),
+                                                                                   (int)w4_sel(cq_ok, (unsigned)cq * 4u), 0, 0));
+  const float slope = sr_uniform(p.slope);
+  w4_f4 rv[2][4];
+  if (RES) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const bool ok = FULL ? true : ((oy < p.H) & (ox + l < p.W));
+      rv[0][l] = w4_load(rs_res, FULL ? r0 + (unsigned)(l * p.res_sp) * 4u : w4_sel(ok, r0 + (unsigned)(l * p.res_sp) * 4u), 0u);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (RES && k + 1 < 4) {
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const unsigned d = (unsigned)(((k + 1) * p.W + l) * p.res_sp) * 4u;
+        const bool ok = FULL ? true : ((oy + k + 1 < p.H) & (ox + l < p.W));
+        rv[(k + 1) & 1][l] = w4_load(rs_res, FULL ? r0 + d : w4_sel(ok, r0 + d), 0u);
+      }
+    }
+    w4_at(acc[6 * k], acc[6 * k + 1], acc[6 * k + 2], acc[6 * k + 3], acc[6 * k + 4], acc[6 * k + 5], acc[6 * k],
+          acc[6 * k + 1], acc[6 * k + 2], acc[6 * k + 3]);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      w4_f4 y = acc[6 * k + l] + bv;
+      if (RES) y = y + rv[k & 1][l];
+      float o4[4] = {y[0], y[1], y[2], y[3]};
+      sr_activate_group(o4, slope);
+      const unsigned d = (unsigned)((k * p.W + l) * p.out_sp) * 4u;
+      const bool ok = FULL ? true : ((oy + k < p.H) & (ox + l < p.W));
+      w4_store(w4_f4{o4[0], o4[1], o4[2], o4[3]}, rs_out, FULL ? o0 + d : w4_sel(ok, o0 + d));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void sr_wino4_kernel(SrWino4Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // transform role: thread (tile, ci)
+  const int t_ci = tid & 15, t_tile = tid >> 4;
+  const int t_sig = (0x1230 >> (t_tile & 12)) & 3;   // sigma(tile >> 2) = (0, 3, 2, 1)
+  const float* t_rd = lds + ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3)) * W4_RS + t_ci;
+  float* t_wr = lds + W4_RAW_FLOATS + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
+  // MFMA role: lane (j = tile / output-channel row, kq = K quarter)
+  const int m_j = lane & 15, m_kq = lane >> 4;
+  const int m_sig = (0x1230 >> (m_j & 12)) & 3;
+  const float* m_rd = lds + W4_RAW_FLOATS + m_j * 16 + 4 * (m_kq ^ m_sig);
+  const unsigned u_voff = (unsigned)(m_kq * p.Co_pad + 16 * wave + m_j) * 16u;
+  const unsigned u_fstride = (SR_W4_ABL & 8) ? 0u : (unsigned)p.S * 4u * (unsigned)p.Co_pad * 16u;   // bytes between two frequencies
+  // staging role: float4 e = tid + 256 j of the patch, pixel pp = e >> 2 (row-major 18 x 18), channel quad q = e & 3
+  const int st_q = tid & 3, st_pp0 = tid >> 2;
+  float* st_wr = lds + st_pp0 * W4_RS + 4 * st_q;
+
+  int work = blockIdx.x;
+  if (work >= p.total) return;
+  W4Item it = w4_decode(p, work);
+  w4_f4 st[W4_STAGE];
+  w4_stage(p, it, 0, st_q, st_pp0, st);
+
+  for (;;) {
+    const int next_work = work + (int)gridDim.x;
+    const bool has_next = next_work < p.total;
+    const W4Item nxt = w4_decode(p, has_next ? next_work : work);
+    w4_f4 acc[36];
+#pragma unroll
+    for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    const unsigned u_item = (unsigned)it.co0 * 16u;
+    const __amdgpu_buffer_rsrc_t rs_u = w4_rsrc(p.wu, (int64_t)36 * p.S * 4 * p.Co_pad * 16);
+
+    for (int s = 0; s < p.S; ++s) {
+      // ---- S: this slab's patch registers -> LDS; then the next slab's (or the next item's first) loads
+      if (!(SR_W4_ABL & 16)) {
+#pragma unroll
+        for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(st_wr + j * 64 * W4_RS) = st[j];
+        if (tid < 16) *reinterpret_cast<w4_f4*>(st_wr + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
+        if (s + 1 < p.S) w4_stage(p, it, s + 1, st_q, st_pp0, st);
+        else if (has_next) w4_stage(p, nxt, 0, st_q, st_pp0, st);
+      }
+      __syncthreads();   // raw visible; every wave is past the previous slab's V reads
+
+      // ---- T: V = B^T d B for (tile, ci), in two halves of the vertical frequencies (18 instead of 36 live temporaries;
+      // the 6 x 6 patch is read twice -- LDS reads are not what this phase waits for)
+#pragma unroll
+      for (int half = 0; half < ((SR_W4_ABL & 1) ? 0 : 2); ++half) {
+        float t[3][6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          float d[6];
+#pragma unroll
+          for (int r = 0; r < 6; ++r) d[r] = t_rd[(r * W4_PS + c) * W4_RS];
+          if (half == 0) {   // rows 0, 1, 2 of B^T d
+            const float a = fmaf(-4.0f, d[2], d[4]), b = fmaf(-4.0f, d[1], d[3]);
+            t[0][c] = fmaf(-4.25f, d[2], d[0]) + d[4];
+            t[1][c] = fmaf(0.5f, b, a);
+            t[2][c] = fmaf(-0.5f, b, a);
+          } else {           // rows 3, 4, 5
+            const float cc = fmaf(-0.25f, d[2], d[4]), e = fmaf(-0.25f, d[1], d[3]);
+            t[0][c] = fmaf(2.0f, e, cc);
+            t[1][c] = fmaf(-2.0f, e, cc);
+            t[2][c] = fmaf(-4.25f, d[3], d[1]) + d[5];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          float v[6];
+          w4_bt(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) t_wr[((3 * half + i) * 6 + j) * 256] = v[j];
+        }
+      }
+      __syncthreads();   // V visible (and raw free for the next slab's store)
+
+      // ---- M: 36 frequencies x (16 co x 16 tiles x 16 ci), pairs of frequencies interleaved (dependent MFMAs 64 clk apart)
+      if (!(SR_W4_ABL & 2)) {
+        const unsigned u_slab = (SR_W4_ABL & 8) ? 0u : u_item + (unsigned)s * 4u * (unsigned)p.Co_pad * 16u;
+        w4_f4 ua[W4_NA][2], vb[2][2];
+        if (SR_W4_ABL & 32) {
+#pragma unroll
+          for (int a = 0; a < W4_NA; ++a) ua[a][0] = ua[a][1] = w4_f4{1.0f, 2.0f, 3.0f, (float)s};
+          vb[0][0] = vb[0][1] = vb[1][0] = vb[1][1] = w4_f4{1.0f, 0.5f, 0.25f, (float)lane};
+        }
+#pragma unroll
+        for (int fp = 0; fp < ((SR_W4_ABL & 32) ? 0 : W4_PD); ++fp) {
+          ua[fp][0] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * fp) * u_fstride);
+          ua[fp][1] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * fp + 1) * u_fstride);
+        }
+        if (!(SR_W4_ABL & 32)) {
+          vb[0][0] = *reinterpret_cast<const w4_f4*>(m_rd);
+          vb[0][1] = *reinterpret_cast<const w4_f4*>(m_rd + 256);
+        }
+#pragma unroll
+        for (int fp = 0; fp < 18; ++fp) {
+          if (!(SR_W4_ABL & 32) && fp + W4_PD < 18) {
+            ua[(fp + W4_PD) % W4_NA][0] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + W4_PD)) * u_fstride);
+            ua[(fp + W4_PD) % W4_NA][1] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + W4_PD) + 1) * u_fstride);
+          }
+          if (!(SR_W4_ABL & 32) && fp + 1 < 18) {
+            vb[(fp + 1) & 1][0] = *reinterpret_cast<const w4_f4*>(m_rd + (2 * fp + 2) * 256);
+            vb[(fp + 1) & 1][1] = *reinterpret_cast<const w4_f4*>(m_rd + (2 * fp + 3) * 256);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % W4_NA][0][e], vb[fp & 1][0][e], acc[2 * fp], 0, 0, 0);
+            acc[2 * fp + 1] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % W4_NA][1][e], vb[fp & 1][1][e], acc[2 * fp + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep the two accumulators interleaved (left alone hipcc issues 4 dependent MFMAs in a row)
+          }
+        }
+      }
+    }
+
+    if (SR_W4_ABL & 4) {   // keep the accumulators alive without an epilogue
+      w4_f4 sum = acc[0];
+#pragma unroll
+      for (int f = 1; f < 36; ++f) sum = sum + acc[f];
+      if (sum[0] + sum[1] + sum[2] + sum[3] == 1.2345e33f) p.out[tid] = sum[0];
+    } else {
+      const int cq = it.co0 + 16 * wave + 4 * m_kq;           // first of this lane's 4 output channels
+      const bool full = (it.oy0 + 16 <= p.H) & (it.ox0 + 16 <= p.W);   // uniform
+      if (p.res != nullptr) {
+        if (full) w4_epilogue<true, true>(p, it, acc, cq, m_j);
+        else w4_epilogue<false, true>(p, it, acc, cq, m_j);
+      } else {
+        if (full) w4_epilogue<true, false>(p, it, acc, cq, m_j);
+        else w4_epilogue<false, false>(p, it, acc, cq, m_j);
+      }
+    }
+    if (!has_next) break;
+    work = next_work;
+    it = nxt;
+  }
+}
+
+// U = G g G^T per (co, ci) for the points (0, 1/2, -1/2, 2, -2, inf), in double, rounded once; stored in MFMA A-fragment
+// order: element (f, s, kq, co, e) = U_f[co][16 s + 4 kq + e], f = 6 i + j (i vertical, j horizontal frequency).
+__global__ void sr_wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ wu, int Co, int Ci, int S, int Co_pad) {
+  const double G[6][3] = {{1.0, 0.0, 0.0},
+                          {-8.0 / 15.0, -4.0 / 15.0, -2.0 / 15.0},
+                          {-8.0 / 15.0, 4.0 / 15.0, -2.0 / 15.0},
+                          {1.0 / 30.0, 1.0 / 15.0, 2.0 / 15.0},
+                          {1.0 / 30.0, -1.0 / 15.0, 2.0 / 15.0},
+                          {0.0, 0.0, 1.0}};
+  const int64_t total = (int64_t)36 * S * 4 * Co_pad * 4;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 3);
+    int64_t r = idx >> 2;
+    const int co = (int)(r % Co_pad); r /= Co_pad;
+    const int kq = (int)(r & 3); r >>= 2;
+    const int s = (int)(r % S);
+    const int f = (int)(r / S);
+    const int ci = 16 * s + 4 * kq + e;
+    double v = 0.0;
+    if (co < Co && ci < Ci) {
+      const float* g = w + ((int64_t)co * Ci + ci) * 9;
+      const int i = f / 6, j = f % 6;
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) v += G[i][a] * (double)g[a * 3 + c] * G[j][c];
+    }
+    wu[idx] = (float)v;
+  }
+}
+
+int w4_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else cus = 256;
+  }
+  return cus;
+}
+
+inline bool w4_al16(const void* ptr) { return (((uintptr_t)ptr) & 15) == 0; }
+
+}  // namespace
+
+extern "C" size_t sr_wino4_packed_weight_floats(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return 0;
+  const size_t S = (size_t)(Cin + 15) / 16, Co_pad = (size_t)((Cout + 63) / 64) * 64;
+  return 36 * S * 4 * Co_pad * 4;
+}
+
+extern "C" int sr_wino4_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream_) {
+  if (!weight || !packed || Cout <= 0 || Cin <= 0) return SR_ERR_INVALID_ARGUMENT;
+  const int S = (Cin + 15) / 16, Co_pad = ((Cout + 63) / 64) * 64;
+  hipLaunchKernelGGL(sr_wino4_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream_, weight, packed, Cout, Cin, S, Co_pad);
+  return sr_hip_rc(hipGetLastError());
+}
+
+// 1 when the F(4x4, 3x3) kernel is the better choice for this 3x3 / stride-1 convolution: 16x16-pixel regions with little
+// padding waste, enough work items to fill both workgroup slots of every CU for several rounds, whole 64-channel output
+// blocks.  `mode` 0: never, 1: this rule, 2: wherever the kernel applies (tests).
+extern "C" int sr_conv_prefers_wino4(int B, int H, int W, int Cin, int Cout, int mode) {
+  if (mode == 0 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 4 != 0 || Cout % 4 != 0) return 0;
+  if (mode == 2) return 1;
+  const long regions = (long)((H + 15) / 16) * ((W + 15) / 16);
+  const double util = (double)H * W / (double)(regions * 256);
+  const int co_blocks = (Cout + 63) / 64;
+  const double co_util = (double)Cout / (double)(co_blocks * 64);
+  const long items = regions * B * co_blocks;
+  const long slots = 2L * w4_num_cus();
+  const long rounds = (items + slots - 1) / slots;
+  const double fill = (double)items / (double)(rounds * slots);
+  return (util >= 0.9 && co_util >= 0.99 && Cin >= 16 && items >= 3 * slots && fill >= 0.85) ? 1 : 0;
+}
+
+extern "C" int sr_conv3x3_wino4_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u,
+                                         const float* bias, const float* residual, int64_t res_batch_stride,
+                                         int res_pix_stride, float* out, int64_t out_batch_stride, int out_pix_stride, int B,
+                                         int H, int W, int Cin, int Cout, float leaky_slope, void* stream_) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
+  if (B == 0) return SR_OK;
+  if (!in || !packed_u || !out) return SR_ERR_INVALID_ARGUMENT;
+  // 16-byte channel quads everywhere (the vector staging / epilogue is the only instantiation)
+  if (Cin % 4 != 0 || Cout % 4 != 0 || !w4_al16(in) || !w4_al16(out) || in_pix_stride % 4 != 0 || in_batch_stride % 4 != 0 ||
+      out_pix_stride % 4 != 0 || out_batch_stride % 4 != 0 || (bias && !w4_al16(bias)) ||
+      (residual && (!w4_al16(residual) || res_pix_stride % 4 != 0 || res_batch_stride % 4 != 0)))
+    return SR_ERR_UNSUPPORTED;
+  const int64_t lim = (int64_t)1 << 31;   // per-image byte offsets are 32-bit (buffer addressing)
+  if (((int64_t)(H * (int64_t)W - 1) * in_pix_stride + Cin) * 4 >= lim || ((int64_t)(H * (int64_t)W - 1) * out_pix_stride + Cout) * 4 >= lim ||
+      (residual && ((int64_t)(H * (int64_t)W - 1) * res_pix_stride + Cout) * 4 >= lim))
+    return SR_ERR_UNSUPPORTED;
+  SrWino4Params p;
+  p.in = in; p.in_sb = in_batch_stride; p.in_sp = in_pix_stride;
+  p.wu = packed_u; p.bias = bias;
+  p.res = residual; p.res_sb = res_batch_stride; p.res_sp = res_pix_stride;
+  p.out = out; p.out_sb = out_batch_stride; p.out_sp = out_pix_stride;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.Co_pad = ((Cout + 63) / 64) * 64;
+  p.S = (Cin + 15) / 16;
+  if ((int64_t)36 * p.S * 4 * p.Co_pad * 16 >= lim) return SR_ERR_UNSUPPORTED;
+  p.regions_x = (W + 15) / 16;
+  p.regions_y = (H + 15) / 16;
+  p.co_blocks = p.Co_pad / 64;
+  const int64_t total = (int64_t)p.regions_x * p.regions_y * p.co_blocks * B;
+  if (total >= lim) return SR_ERR_UNSUPPORTED;
+  p.total = (int)total;
+  p.slope = leaky_slope;
+  int blocks = 2 * w4_num_cus();
+  if (blocks > p.total) blocks = p.total;
+  hipError_t e = hipFuncSetAttribute((const void*)sr_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
+  if (e != hipSuccess) return sr_hip_rc(e);
+  hipLaunchKernelGGL(sr_wino4_kernel, dim3(blocks), dim3(256), W4_LDS_BYTES, (hipStream_t)stream_, p);
+  return sr_hip_rc(hipGetLastError());
+}

@@ -283,6 +283,33 @@ def packed_wino_weight(conv: nn.Conv2d, bn=None):
     return packed, bias
 
 
+_PACKED_WINO4 = weakref.WeakKeyDictionary()  # nn.Conv2d -> (state key, F(4x4, 3x3)-packed tensor, bias)
+# Which 3x3 / stride-1 layers take the F(4x4, 3x3) kernel (csrc/sr_wino4.hip): "1" (default) = the library's rule
+# (sr_conv_prefers_wino4: the full-resolution layers at batch 8), "0" = none, "2" = every layer it applies to (tests).
+# Read once, handed to the library as an argument.
+WINO4_MODE = int(os.environ.get("SR_CONV_WINO4", "1"))
+
+
+def packed_wino4_weight(conv: nn.Conv2d, bn=None):
+    """(F(4x4, 3x3)-packed weight U = G g G^T, bias); cached until a parameter changes."""
+    key = _state_key(conv, bn)
+    hit = _PACKED_WINO4.get(conv)
+    if hit is not None and hit[0] == key:
+        _await_packed(conv, "wino4", hit[1].device)
+        return hit[1], hit[2]
+    _check_conv(conv)
+    lib = _lib.lib()
+    w, bias = _effective_weight(conv, bn)
+    co, ci = w.shape[:2]
+    packed = torch.empty(lib.sr_wino4_packed_weight_floats(co, ci), dtype=torch.float32, device=w.device)
+    with _lib.on_device(w.device):
+        rc = lib.sr_wino4_pack_weights(_lib.ptr(w), co, ci, _lib.ptr(packed), _lib.stream_ptr(w.device))
+    _lib.check(rc, "sr_wino4_pack_weights")
+    _packed_here(conv, "wino4", w.device)
+    _PACKED_WINO4[conv] = (key, packed, bias)
+    return packed, bias
+
+
 # Pure functions of the layer shape inside the C library (launch-plan choices): asked once per shape, not once per launch.
 _SHAPE_QUERIES = {}
 
@@ -424,6 +451,28 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 return out
             if rc != 2:   # SR_ERR_UNSUPPORTED: no library algorithm for this shape -> the HIP kernel below
                 _lib.check(rc, "sr_gemm1x1_nhwc_fwd")
+    if use_wino and WINO4_MODE and not wino_split_mode() and \
+            _shape_query(lib, "sr_conv_prefers_wino4", b, h, w, ci, co, WINO4_MODE):
+        al = lambda t, sb_, sp_: t is None or (t.data_ptr() % 16 == 0 and sp_ % 4 == 0 and sb_ % 4 == 0)
+        wp4, bias4 = packed_wino4_weight(conv, bn)
+        if al(x, isb, isp) and al(out, osb, osp) and al(residual, rsb, rsp) and (bias4 is None or bias4.data_ptr() % 16 == 0):
+            with _lib.on_device(x.device):
+                if prof is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                rc = lib.sr_conv3x3_wino4_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp4), _lib.ptr(bias4), _lib.ptr(residual), rsb,
+                                                   rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co,
+                                                   C.c_float(_act_code(leaky, act)), _lib.stream_ptr(x.device))
+                if prof is not None and rc == 0:
+                    ev1.record()
+                    regions = ((h + 15) // 16) * ((w + 15) // 16)   # multiplies issued: 36 per 4x4 tile and (ci, co) pair, padded
+                    executed = 2.0 * b * regions * 16 * 36 * ((ci + 15) // 16 * 16) * ((co + 63) // 64 * 64)
+                    prof.append(("sr_wino4_kernel", 2.0 * b * ho * wo * co * ci * 9, ev0, ev1,
+                                 (b, ci, h, w, co, k, s, ho, wo, residual is not None), executed))
+            if rc == 0:
+                return out
+            if rc != 2:   # SR_ERR_UNSUPPORTED (per-image byte range): the F(2x2) kernel below
+                _lib.check(rc, "sr_conv3x3_wino4_nhwc_fwd")
     wp, bias = packed_wino_weight(conv, bn) if use_wino else packed_weight(conv, bn)
     slope = C.c_float(_act_code(leaky, act))
     with _lib.on_device(x.device):

@@ -1,0 +1,141 @@
+"""GPU parity of the Winograd F(4x4, 3x3) kernel (csrc/sr_wino4.hip; conv3x3 + bias + residual + LeakyReLU of the reference's
+BasicBlock, modules/layers.py:7-85) against an fp64 ATen convolution, the F(2x2) kernel and the direct implicit-GEMM kernel.
+The tolerance is the fp32 bar of the north star relative to the output range, with the measured error printed."""
+import ctypes as C
+
+import pytest
+import torch
+
+from simplerecon_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(kind, x, conv, res, leaky, out=None):
+    """kind: 'w4' F(4x4), 'w2' F(2x2), 'direct' -- each through its C-ABI entry point."""
+    lib = _lib.lib()
+    b, ci, h, w = x.shape
+    co = conv.out_channels
+    out = ops.empty_nhwc(b, co, h, w, x.device) if out is None else out
+    isb, isp = ops._strides(x)
+    osb, osp = ops._strides(out)
+    rsb, rsp = ops._strides(res) if res is not None else (0, 0)
+    slope = C.c_float(ops._act_code(leaky, None))
+    with _lib.on_device(x.device):
+        if kind == "w4":
+            wp, bias = ops.packed_wino4_weight(conv)
+            rc = lib.sr_conv3x3_wino4_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(res), rsb, rsp,
+                                               _lib.ptr(out), osb, osp, b, h, w, ci, co, slope, _lib.stream_ptr(x.device))
+        elif kind == "w2":
+            wp, bias = ops.packed_wino_weight(conv)
+            rc = lib.sr_conv3x3_wino_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(res), rsb, rsp,
+                                              _lib.ptr(out), osb, osp, b, h, w, ci, co, slope, _lib.stream_ptr(x.device))
+        else:
+            wp, bias = ops.packed_weight(conv)
+            rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(res), rsb, rsp,
+                                        _lib.ptr(out), osb, osp, b, h, w, ci, co, 3, 1, slope, _lib.stream_ptr(x.device))
+    _lib.check(rc, kind)
+    return out
+
+
+def _ref64(x, conv, res, leaky):
+    y = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double() if conv.bias is not None else None,
+                                   padding=1)
+    if res is not None:
+        y = y + res.double()
+    return torch.nn.functional.leaky_relu(y, leaky) if leaky is not None else y
+
+
+# (B, Cin, H, W, Cout, residual, bias): interior + border regions, ragged sizes, channel tails in Cin (not a multiple of 16)
+# and Cout (not a multiple of 64 / 16), several items per workgroup, one region smaller than a tile
+SHAPES = [(1, 16, 16, 16, 64, False, True), (2, 64, 48, 64, 64, True, True), (1, 24, 35, 53, 64, True, False),
+          (1, 64, 20, 18, 24, False, True), (2, 192, 32, 48, 64, True, True), (1, 128, 50, 70, 128, True, True),
+          (1, 36, 9, 7, 12, True, True), (3, 64, 240, 320, 64, True, True), (1, 112, 17, 33, 72, False, False)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[str(s) for s in SHAPES])
+def test_wino4_matches_fp64_and_the_other_kernels(shape):
+    b, ci, h, w, co, with_res, with_bias = shape
+    torch.manual_seed(ci * 131 + co)
+    conv = torch.nn.Conv2d(ci, co, 3, padding=1, bias=with_bias).to(DEV)
+    x = torch.randn(b, ci, h, w, device=DEV).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(b, co, h, w, device=DEV).contiguous(memory_format=torch.channels_last) if with_res else None
+    with torch.inference_mode():
+        y4 = _run("w4", x, conv, res, 0.2)
+        y2 = _run("w2", x, conv, res, 0.2)
+        yd = _run("direct", x, conv, res, 0.2)
+        ref = _ref64(x, conv, res, 0.2)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    e4 = (y4.double() - ref).abs().max().item() / scale
+    e2 = (y2.double() - ref).abs().max().item() / scale
+    ed = (yd.double() - ref).abs().max().item() / scale
+    print(f"{shape}: rel-to-range error F(4x4) {e4:.2e}  F(2x2) {e2:.2e}  direct {ed:.2e}")
+    assert e4 < 2e-5, f"F(4x4) error {e4} (F(2x2) {e2}, direct {ed})"
+    assert torch.isfinite(y4).all()
+
+
+def test_wino4_writes_into_a_concat_slice_and_reads_from_one():
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(32, 64, 3, padding=1).to(DEV)
+    buf_in = ops.empty_nhwc(2, 80, 40, 48, DEV).normal_()
+    x = buf_in[:, 16:48]
+    buf_out = ops.empty_nhwc(2, 96, 40, 48, DEV).fill_(7.0)
+    with torch.inference_mode():
+        dense = _run("w4", (x * 1.0).contiguous(memory_format=torch.channels_last), conv, None, 0.2)
+        _run("w4", x, conv, None, 0.2, out=buf_out[:, 16:80])
+    torch.cuda.synchronize()
+    assert torch.equal(buf_out[:, 16:80], dense)
+    assert bool((buf_out[:, :16] == 7).all()) and bool((buf_out[:, 80:] == 7).all())
+
+
+def test_wino4_is_deterministic_and_batch_independent():
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV)
+    x = torch.randn(4, 64, 64, 80, device=DEV).contiguous(memory_format=torch.channels_last)
+    with torch.inference_mode():
+        a = _run("w4", x, conv, None, 0.2)
+        b = _run("w4", x, conv, None, 0.2)
+        one = _run("w4", x[2:3], conv, None, 0.2)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert torch.equal(a[2:3], one)   # per-pixel arithmetic does not depend on the batch
+
+
+def test_wino4_non_finite_inputs_do_not_leak_across_channel_padding():
+    """Channels past Cin inside the pixel stride (a concat buffer) must be masked, not multiplied by zero weights."""
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(24, 64, 3, padding=1).to(DEV)
+    buf = ops.empty_nhwc(1, 40, 32, 32, DEV).normal_()
+    buf[:, 24:] = float("nan")
+    with torch.inference_mode():
+        y = _run("w4", buf[:, :24], conv, None, 0.2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+
+
+def test_ops_conv2d_dispatches_wino4_by_rule_and_by_switch(monkeypatch):
+    lib = _lib.lib()
+    assert lib.sr_conv_prefers_wino4(8, 240, 320, 64, 64, 1) == 1
+    assert lib.sr_conv_prefers_wino4(8, 240, 320, 192, 64, 1) == 1
+    assert lib.sr_conv_prefers_wino4(1, 240, 320, 64, 64, 1) == 0      # too few work items: F(2x2)
+    assert lib.sr_conv_prefers_wino4(8, 120, 160, 64, 64, 1) == 0      # 640 items on 512 slots: a 1.25-round launch
+    assert lib.sr_conv_prefers_wino4(8, 240, 320, 64, 64, 0) == 0
+    assert lib.sr_conv_prefers_wino4(1, 24, 24, 16, 16, 2) == 1
+    torch.manual_seed(6)
+    conv = torch.nn.Conv2d(32, 48, 3, padding=1).to(DEV)
+    x = torch.randn(1, 32, 40, 40, device=DEV).contiguous(memory_format=torch.channels_last)
+    with torch.inference_mode():
+        monkeypatch.setattr(ops, "WINO4_MODE", 2)
+        ops._SHAPE_QUERIES.clear()
+        prof = []
+        monkeypatch.setattr(ops, "PROFILE", prof)
+        y = ops.conv2d(x, conv, leaky=0.2)
+        assert prof[-1][0] == "sr_wino4_kernel"
+        monkeypatch.setattr(ops, "WINO4_MODE", 0)
+        ops._SHAPE_QUERIES.clear()
+        y0 = ops.conv2d(x, conv, leaky=0.2)
+        assert prof[-1][0] != "sr_wino4_kernel"
+    ops._SHAPE_QUERIES.clear()
+    assert (y - y0).abs().max().item() < 2e-5 * y0.abs().max().item()
