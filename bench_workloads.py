@@ -25,8 +25,8 @@ F16_MFMA_PEAK_TF = 2500.0   # dense bf16 / f16 MFMA (MI355X_MICROARCH.md)
 
 def _mlp_kernel_name(K):
     """Which sr_mlp_volume_kernel<W1_LDS, W2_LDS> sr_mlp_volume_sweep dispatches (mirrors sr_mlp_volume.hip)."""
-    split = os.environ.get("SR_MLP_SPLIT", "0")
-    if split in ("bf16", "f16", "fp16"):
+    split = _lib.split_mode_name("SR_MLP_SPLIT")
+    if split in ("bf16", "f16"):
         return f"sr_mlp_volume_split_kernel<{1 if split == 'bf16' else 2}>"
     w1, w2, w3 = 12 * K * 1024, 65 * 1024, 1024
     if w1 + w2 + w3 <= 160 * 1024:
@@ -36,31 +36,38 @@ def _mlp_kernel_name(K):
     return "sr_mlp_volume_kernel<false, true>"
 
 
-def _best_cpu_threads():
-    """Thread count for the ATen CPU baseline: ATen's intra-op scaling on a many-core host is far from monotonic (on the
-    256-thread EPYC bench box the per-plane sweep takes 0.08 s with 16 threads, 0.35 s with 128 and 8.2 s with 256), so
-    the baseline gets the best of a few counts, probed on one small plane of the sweep, and reports the count it used."""
+def _best_cpu_threads(K=7, C=16, h=120, w=160, table=None):
+    """Thread count for the ATen CPU baseline, probed ON THE WORKLOAD'S OWN PLANE SIZE.  ATen's intra-op scaling on a many-core
+    host is far from monotonic and depends on the tensor size (r04: a 60x80 probe picked 64 threads on the driver's box where
+    16 is 2x faster on the real 120x160 sweep), so every count of (4, 8, 16, 32, 64, 128) that the host has is timed on two
+    planes of the real sweep -- best of two runs each, no early exit -- and the fastest wins.  `table` (a dict) receives the
+    per-count seconds per plane, which the bench line reports."""
     import bench_cpu_aten as aten
-    inp = synthetic.cost_volume_inputs(1, 7, 16, 60, 80, seed=0)
-    lin = [(torch.randn(128, 202), torch.zeros(128)), (torch.randn(128, 128), torch.zeros(128)),
+    inp = synthetic.cost_volume_inputs(1, K, C, h, w, seed=0)
+    cin = C * (K + 1) + 10 * K + 4
+    lin = [(torch.randn(128, cin), torch.zeros(128)), (torch.randn(128, 128), torch.zeros(128)),
            (torch.randn(1, 128), torch.zeros(1))]
     planes = torch.tensor([[1.0, 2.0]])
     best, best_t = None, None
-    for nt in (8, 16, 32, 64, 128):
-        if nt > (os.cpu_count() or 1):
+    ncpu = os.cpu_count() or 1
+    for nt in (4, 8, 16, 32, 64, 128):
+        if nt > ncpu and best is not None:
             break
-        torch.set_num_threads(nt)
+        torch.set_num_threads(min(nt, ncpu))
         with torch.inference_mode():
             args = (inp["cur_feats"], inp["src_feats"], inp["src_Ks"], inp["src_extrinsics"], inp["src_poses"],
                     inp["cur_invK"], planes, lin)
-            aten.mlp_volume(*args)
-            t0 = time.perf_counter()
-            aten.mlp_volume(*args)
-            t = time.perf_counter() - t0
+            aten.mlp_volume(*args)   # warm-up: thread pool, oneDNN primitives
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                aten.mlp_volume(*args)
+                ts.append((time.perf_counter() - t0) / planes.shape[1])
+        t = min(ts)
+        if table is not None:
+            table[str(min(nt, ncpu))] = round(t, 4)
         if best_t is None or t < best_t:
-            best, best_t = nt, t
-        elif t > 2.0 * best_t:
-            break
+            best, best_t = min(nt, ncpu), t
     torch.set_num_threads(best or 1)
     return best or 1
 
@@ -68,10 +75,10 @@ def _best_cpu_threads():
 def _dot_kernel_name(B, h, w, D):
     """Which sr_dot_volume_lds_kernel<CAP, WPS, G> sr_dot_volume_sweep dispatches for C = 16 (mirrors
     sr_launch_dot_volume_lds in csrc/sr_dot_volume_lds.hip); the L1-gather kernel when SR_DOT_LDS=0."""
-    if os.environ.get("SR_DOT_LDS", "1") == "0":
+    if _lib.get_option("SR_DOT_LDS") == 0:
         return "sr_dot_volume_kernel16q"
-    cap = 770 if os.environ.get("SR_DOT_LDS_CAP") == "770" else 634
-    g = int(os.environ.get("SR_DOT_LDS_G", "0"))
+    cap = 770 if _lib.get_option("SR_DOT_LDS_CAP") == 770 else 634
+    g = _lib.get_option("SR_DOT_LDS_G")
     if g not in (2, 4, 8):
         g = 2 if B * ((w + 31) // 32) * ((h + 7) // 8) * ((D + 3) // 4) < 2048 else 4
     return f"sr_dot_volume_lds_kernel<{cap}, {3 if cap == 770 else 4}, {g}>"
@@ -252,9 +259,9 @@ class HeroCfg3:
             # split_convs the Winograd 3x3 convolutions -- multiply on the 16-bit matrix pipe, every fp32 operand as two 16-bit
             # pieces, three products, fp32 accumulate.  The switches are read by the library per call; a bench process runs
             # one workload.
-            os.environ["SR_MLP_SPLIT"] = split
+            _lib.set_option("SR_MLP_SPLIT", split)
             if split_convs:
-                os.environ["SR_WINO_SPLIT"] = split
+                _lib.set_option("SR_WINO_SPLIT", split)
             self.dtype = (f"f32 I/O and accumulate; MLP-sweep layers 1-2{' and the Winograd 3x3 convolutions' if split_convs else ''}"
                           f": operands as 2 x {split} pieces, 3 MFMA products (fenced experiment, not the headline arithmetic)")
         if B is not None:
@@ -507,7 +514,8 @@ class HeroCfg3:
         import copy
         import types
         import bench_cpu_aten as aten
-        threads = _best_cpu_threads()
+        probe = {}
+        threads = _best_cpu_threads(self.K, self.Cc, self.h, self.w, probe)
         m = self.model   # CPU copies of the parameter-holding sub-modules only (no streams / workspaces)
         cpu_model = types.SimpleNamespace(
             encoder=copy.deepcopy(m.encoder).cpu() if self.prior else None,
@@ -527,7 +535,7 @@ class HeroCfg3:
         # Bounded sample (the default bench run must finish within minutes): the plane sweep is timed on SAMPLE planes
         # and scaled to the D planes of the workload (its cost is per plane, the reference loops over planes:
         # cost_volume.py:553); everything else (encoders, CVEncoder, decoder) is timed whole, once.
-        SAMPLE = 4
+        SAMPLE = min(16, planes.shape[1])   # (r04: 4 planes -- too few for a number that has to hold from box to box)
         D = planes.shape[1]
         sub = planes[:, torch.linspace(0, D - 1, SAMPLE).round().long()].contiguous()
 
@@ -560,7 +568,7 @@ class HeroCfg3:
             else:
                 feats["vol"] = aten.dot_volume(feats["cur"], feats["src"], c["src_Ks"], c["src_extrinsics"],
                                                c["cur_invK"], sub)[0]
-        t_sweep, n_sweep = timed(sweep, 4.0)
+        t_sweep, n_sweep = timed(sweep, 3.0)
         vol_full = torch.randn((1, D, self.h, self.w))    # the conv stack's cost does not depend on the values
 
         def convs():
@@ -569,11 +577,13 @@ class HeroCfg3:
         t_conv, n_conv = timed(convs, 3.0)
         dt = t_enc + t_sweep * (D / SAMPLE) + t_conv
         return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                "thread_probe_seconds_per_plane": probe,
                 "seconds_per_frame": {"encoders": t_enc, "plane_sweep": t_sweep * (D / SAMPLE), "conv_stack": t_conv},
                 "sample": f"1 frame of {self.name} through bench_cpu_aten.py = the ATen (PyTorch {torch.__version__} CPU, "
                           f"fp32) operator sequence the reference runs on CPU (per-plane F.grid_sample / F.normalize / "
                           f"torch.cat / F.linear of the looped FeatureVolumeManager, F.conv2d BasicBlocks, F.interpolate), "
-                          f"torch.set_num_threads({torch.get_num_threads()}) = the fastest of 8..128 on this host ({os.cpu_count()} CPUs); bounded sample: "
+                          f"torch.set_num_threads({torch.get_num_threads()}) = the fastest of 4..128 probed on two planes of this very sweep "
+                          f"(thread_probe_seconds_per_plane; host has {os.cpu_count()} CPUs); bounded sample: "
                           f"plane sweep timed on {SAMPLE} of {D} planes ({n_sweep} repetition(s)) and scaled by {D}/{SAMPLE}, "
                           f"{'encoders (' + str(n_enc) + ' rep) and ' if n_enc else ''}CVEncoder + DepthDecoderPP "
                           f"({n_conv} rep) timed whole"}

@@ -33,6 +33,29 @@ extern "C" {
 #define SR_ERR_WORKSPACE_TOO_SMALL 3
 #define SR_ERR_HIP_BASE 1000
 
+/* ---- run-time switches (r05) ----------------------------------------------------------------------------------------
+ * Every tuning / ablation switch of the library, and the two fenced split-precision modes (which change the numerics of the
+ * calls that honour them), is an entry of ONE option table: read atomically by the entry points, set explicitly with
+ * sr_option_set().  An entry is initialised once, at the library's first option access, from the environment variable of the
+ * same name (tuning runs: `SR_WINO_XCD=0 python ...`); after that the environment is never read again -- no getenv() on any
+ * launch path, no setenv() by any host.  The table is PROCESS-WIDE: a value set while another thread is launching applies to
+ * that thread's next launch, and a HIP graph captured under a mode keeps the kernels of that mode.  Integer options take the
+ * integer; the split modes take 0 = off (fp32 MFMA: the product path), 1 = bf16 pieces, 2 = f16 pieces (-1 = the unknown
+ * string an environment variable held: the entry points that honour the mode return SR_ERR_INVALID_ARGUMENT). */
+enum {
+  SR_OPT_MLP_SPLIT = 0, SR_OPT_WINO_SPLIT, SR_OPT_WINO_XCD, SR_OPT_WINO_STAGGER, SR_OPT_WINO_WG_PER_CU, SR_OPT_WINO_NT,
+  SR_OPT_WINO_KSPLIT, SR_OPT_CONV_WINO, SR_OPT_CONV_TILE, SR_OPT_CONV_KSPLIT, SR_OPT_MLP_VEC_STORE, SR_OPT_MLP_XCD,
+  SR_OPT_MLP_BWD_VALU, SR_OPT_T16_XCD, SR_OPT_POOL_BW, SR_OPT_POOL_XCD, SR_OPT_PW_NT, SR_OPT_PW_KS, SR_OPT_PT_CFG, SR_OPT_PT_KS,
+  SR_OPT_DOT_LDS, SR_OPT_DOT_QUAD, SR_OPT_DOT_LDS_G, SR_OPT_DOT_LDS_CULL, SR_OPT_DOT_LDS_CAP, SR_OPT_GEMM_AUTOTUNE,
+  SR_OPT_COUNT
+};
+int sr_option_count(void);
+const char* sr_option_name(int id);               /* = the environment variable that seeds it, e.g. "SR_WINO_XCD" */
+int sr_option_id(const char* name);               /* -1: no such option */
+int sr_option_get(int id, int* value);
+int sr_option_set(int id, int value, int* previous /* may be NULL */);
+int sr_option_default(int id, int* value);
+
 /* ABI version; bumped on any signature change. */
 int sr_abi_version(void);
 
@@ -301,9 +324,9 @@ int sr_conv2d_splitk_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_p
  * sr_wino_pack_weights (U = G g G^T in MFMA B-fragment order).  sr_conv_prefers_wino() tells whether this kernel
  * is expected to beat the direct one for a shape (enough 8x16-pixel regions, little padding). */
 size_t sr_wino_packed_weight_floats(int Cout, int Cin);
-/* Experiment switch (off by default, read per call by the pack AND the convolution, which must agree): environment
- * SR_WINO_SPLIT=bf16|f16 packs U as two 16-bit pieces (same buffer size) and selects the split-precision kernel (vector
- * instantiation and fp32 tensors only: SR_ERR_UNSUPPORTED otherwise; unknown values: SR_ERR_INVALID_ARGUMENT). */
+/* Experiment switch (off by default; option SR_OPT_WINO_SPLIT, read by the pack AND the convolution, which must agree):
+ * 1 = bf16 / 2 = f16 packs U as two 16-bit pieces (same buffer size) and selects the split-precision kernel (vector
+ * instantiation and fp32 tensors only: SR_ERR_UNSUPPORTED otherwise; the value -1: SR_ERR_INVALID_ARGUMENT). */
 int sr_wino_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream);
 int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
@@ -328,6 +351,14 @@ int sr_conv3x3_wino4_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_p
                               const float* bias, const float* residual, int64_t res_batch_stride, int res_pix_stride,
                               float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
                               int Cout, float leaky_slope, void* stream);
+
+/* The same with the kernel form chosen by the caller: `variant` 0 = the default (what sr_conv3x3_wino4_nhwc_fwd launches),
+ * 1 = two independent 4-wave workgroups per CU, 2 = one 8-wave workgroup per CU whose halves alternate transform and MFMA
+ * phases (kept for A/B measurements).  Bit-identical results. */
+int sr_conv3x3_wino4_variant_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u,
+                                      const float* bias, const float* residual, int64_t res_batch_stride,
+                                      int res_pix_stride, float* out, int64_t out_batch_stride, int out_pix_stride, int B,
+                                      int H, int W, int Cin, int Cout, float leaky_slope, int variant, void* stream);
 
 /* Split-K variant for layers with few output regions and a long chain of input slabs (deep low-resolution levels,
  * batch 1): work items cover Cin / ks input channels each and store raw partial outputs to `workspace`

@@ -18,10 +18,7 @@ MODES = [("fp32", None), ("bf16", "bf16"), ("f16", "f16")]
 
 
 def set_mode(m):
-    if m is None:
-        os.environ.pop("SR_MLP_SPLIT", None)
-    else:
-        os.environ["SR_MLP_SPLIT"] = m
+    _lib.set_option("SR_MLP_SPLIT", 0 if m is None else m)
 
 
 def main():

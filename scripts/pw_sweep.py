@@ -24,16 +24,16 @@ for (B, ci, H, W, co, gate, res) in shapes:
     out = ops.empty_nhwc(B, co, H, W, dev)
     row = []
     for pl in plans:
-        for k in ("SR_PW_NT", "SR_PW_KS", "SR_PT_CFG", "SR_PT_KS"):
-            os.environ.pop(k, None)
+        for k, dflt in (("SR_PW_NT", 0), ("SR_PW_KS", 0), ("SR_PT_CFG", -1), ("SR_PT_KS", 0)):
+            _lib.set_option(k, dflt)
         ops._SHAPE_QUERIES.clear()
         if pl is not None:
             nt, ks = C.c_int(0), C.c_int(0)
             if TILED:
-                os.environ["SR_PT_CFG"], os.environ["SR_PT_KS"] = str(pl[0]), str(pl[1])
+                _lib.set_option("SR_PT_CFG", pl[0]); _lib.set_option("SR_PT_KS", pl[1])
                 lib.sr_pw_conv_tiled_plan(B * H * W, ci, co, 1, C.byref(nt), C.byref(ks))
             else:
-                os.environ["SR_PW_NT"], os.environ["SR_PW_KS"] = str(pl[0]), str(pl[1])
+                _lib.set_option("SR_PW_NT", pl[0]); _lib.set_option("SR_PW_KS", pl[1])
                 lib.sr_pw_conv_plan(B, H * W, ci, co, C.byref(nt), C.byref(ks))
             if (nt.value, ks.value) != pl:
                 row.append("      -"); continue

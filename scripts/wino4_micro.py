@@ -21,7 +21,7 @@ for (B, ci, H, W, co) in shapes:
     line = f"{str((B, ci, H, W, co)):26s}"
     with torch.inference_mode():
         ref = _ref64(x[:1], conv, res[:1], 0.2)
-        for kind in ("w2", "w4"):
+        for kind in ("w2", "w4", "w4_pp"):
             f = lambda: _run(kind, x, conv, res, 0.2, out=out)
             for _ in range(3): f()
             torch.cuda.synchronize()
@@ -34,5 +34,5 @@ for (B, ci, H, W, co) in shapes:
             err = (out[:1].double() - ref).abs().max().item() / ref.abs().max().item()
             fl = 2.0 * B * H * W * co * ci * 9
             mult = 16 / 36 if kind == "w2" else 36 / 144
-            line += f"  {kind}: {t * 1e6:8.1f} us  mfma-util {fl * mult / t / 1e12 / 157.3:5.3f}  err {err:.1e}"
+            line += f"  {kind}: {t * 1e6:7.1f} us util {fl * mult / t / 1e12 / 157.3:5.3f} err {err:.0e}"
     print(line, flush=True)

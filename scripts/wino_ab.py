@@ -21,7 +21,7 @@ for (B, ci, H, W, co) in shapes:
     out = ops.empty_nhwc(B, co, H, W, dev)
     ts, ys = [], []
     for v in vals:
-        os.environ[var] = v
+        _lib.set_option(var, int(v))   # (the library's option table: include/simplerecon_hip.h)
         with torch.inference_mode():
             f = lambda: ops.conv2d(x, conv, residual=res, leaky=0.2, out=out)
             for _ in range(3): f()

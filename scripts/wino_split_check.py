@@ -24,7 +24,7 @@ for (B, ci, H, W, co) in shapes:
     rng = float(ref.abs().max())
     line = f"{str((B, ci, H, W, co)):26s}"
     for name, v in MODES:
-        os.environ["SR_WINO_SPLIT"] = v
+        _lib.set_option("SR_WINO_SPLIT", v)
         out = ops.empty_nhwc(B, co, H, W, dev)
         with torch.inference_mode():
             f = lambda: ops.conv2d(x, conv, residual=res, leaky=0.2, out=out)
@@ -41,5 +41,5 @@ for (B, ci, H, W, co) in shapes:
             t = e0.elapsed_time(e1) * 1e-3 / n
         err = (out.double() - ref).abs()
         line += f"  {name}: {t*1e6:7.1f} us  max {float(err.max())/rng:.2e} rms {float((err**2).mean().sqrt())/rng:.2e}"
-    os.environ["SR_WINO_SPLIT"] = "0"
+    _lib.set_option("SR_WINO_SPLIT", 0)
     print(line, flush=True)

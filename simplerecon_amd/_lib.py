@@ -23,6 +23,12 @@ _sz = C.c_size_t
 # name -> (restype, argtypes); must list every symbol declared in include/simplerecon_hip.h
 SIGNATURES = {
     "sr_abi_version": (_i, []),
+    "sr_option_count": (_i, []),
+    "sr_option_name": (C.c_char_p, [_i]),
+    "sr_option_id": (_i, [C.c_char_p]),
+    "sr_option_get": (_i, [_i, C.POINTER(C.c_int)]),
+    "sr_option_set": (_i, [_i, _i, C.POINTER(C.c_int)]),
+    "sr_option_default": (_i, [_i, C.POINTER(C.c_int)]),
     "sr_target_arch": (C.c_char_p, []),
     "sr_volume_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sr_volume_prepare": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
@@ -126,6 +132,8 @@ SIGNATURES = {
     "sr_wino4_pack_weights": (_i, [_p, _i, _i, _p, _p]),
     "sr_conv_prefers_wino4": (_i, [_i, _i, _i, _i, _i, _i]),
     "sr_conv3x3_wino4_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "sr_conv3x3_wino4_variant_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _i,
+                                               _p]),
     "sr_conv_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "sr_upsample2x_nhwc_fwd": (_i, [_p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "sr_exp_fwd": (_i, [_p, _p, _i64, _p]),
@@ -175,6 +183,52 @@ def check(rc, what):
     if rc != 0:
         msg = _ERRORS.get(rc, f"hipError {rc - 1000}" if rc >= 1000 else f"error {rc}")
         raise HipLibraryError(f"{what} failed: {msg}")
+
+
+# ---- run-time switches: the library's option table (include/simplerecon_hip.h, SR_OPT_*; r05) --------------------------
+# Options are named like the environment variable that seeds them at the library's first access ("SR_WINO_XCD"); after that
+# the library never reads the environment again and hosts change a switch through these calls.  Process-wide.
+SPLIT_MODES = {"": 0, "0": 0, "off": 0, "fp32": 0, "bf16": 1, "f16": 2, "fp16": 2}
+_SPLIT_NAMES = {0: "", 1: "bf16", 2: "f16"}
+
+
+def _option_id(name):
+    oid = lib().sr_option_id(name.encode())
+    if oid < 0:
+        raise KeyError(f"libsimplerecon_hip.so has no option {name!r}")
+    return oid
+
+
+def get_option(name):
+    v = C.c_int(0)
+    check(lib().sr_option_get(_option_id(name), C.byref(v)), "sr_option_get")
+    return v.value
+
+
+def set_option(name, value):
+    """Sets option `name` (an int; the split modes also take 'bf16' / 'f16' / '' / an unknown string = -1: refused by the
+    entry points).  Returns the previous value."""
+    if isinstance(value, str):
+        value = SPLIT_MODES.get(value, -1)
+    prev = C.c_int(0)
+    check(lib().sr_option_set(_option_id(name), int(value), C.byref(prev)), "sr_option_set")
+    return prev.value
+
+
+@contextlib.contextmanager
+def option(name, value):
+    """`with _lib.option("SR_PW_NT", 2): ...` -- the switch for the calls inside the block, restored on exit."""
+    prev = set_option(name, value)
+    try:
+        yield
+    finally:
+        set_option(name, prev)
+
+
+def split_mode_name(option_name):
+    """'' / 'bf16' / 'f16' for the split-precision options (anything else: the raw integer as a string)."""
+    v = get_option(option_name)
+    return _SPLIT_NAMES.get(v, str(v))
 
 
 def require_device_f32(name, t, allow_none=False):

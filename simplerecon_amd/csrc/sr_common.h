@@ -13,6 +13,10 @@
 
 #define SR_WAVE 64
 
+// value of a run-time switch (include/simplerecon_hip.h, SR_OPT_*): one relaxed atomic load; the environment is read once, at the
+// first access in the process (sr_options.hip)
+int sr_opt(int id);
+
 static inline int sr_hip_rc(hipError_t e) { return e == hipSuccess ? SR_OK : SR_ERR_HIP_BASE + (int)e; }
 
 static inline size_t sr_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -548,9 +548,9 @@ static SrConvCfg sr_conv_pick(const SrConvParams& p, int B, int stride, int ksiz
 
 static SrConvCfg sr_conv_cfg(const SrConvParams& p, int B, int stride, int ksize) {
   SrConvCfg cfg = sr_conv_pick(p, B, stride, ksize);
-  const char* e = getenv("SR_CONV_TILE");  // ablation override: shape + 10 * nt (nt = 0: keep)
-  if (e && *e) {
-    const int v = atoi(e), shape = v % 10, nt = v / 10;
+  const int v = sr_opt(SR_OPT_CONV_TILE);  // ablation override: shape + 10 * nt (nt = 0: keep); 0 = none
+  if (v > 0) {
+    const int shape = v % 10, nt = v / 10;
     if (shape >= 0 && shape <= 2 && !(stride == 2 && shape == 0)) cfg.shape = shape;
     if (nt == 1 || (nt == 2 && p.Co_pad % 64 == 0)) cfg.nt = nt;
   }
@@ -563,8 +563,7 @@ static SrConvCfg sr_conv_cfg(const SrConvParams& p, int B, int stride, int ksize
 #define SR_CONV_KSPLIT_MAX 8
 static bool sr_conv_splitk_eligible(const float* out, int64_t out_sb, int out_sp, const float* bias, const float* res,
                                     int64_t res_sb, int res_sp, int Cin, int Cout, int ksize, int stride) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("SR_CONV_KSPLIT"); on = e ? atoi(e) : 1; }
+  const int on = sr_opt(SR_OPT_CONV_KSPLIT);
   if (!on || ksize != 1 || stride != 1 || Cout % 4 != 0 || Cin < 4 * SR_CK1) return false;
   auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   if (!al(out) || out_sp % 4 != 0 || out_sb % 4 != 0 || (bias && !al(bias))) return false;
@@ -609,7 +608,11 @@ static int sr_conv2d_dispatch(const float* in, int64_t in_batch_stride, int in_p
     p.ksplit = fit < 2 ? 1 : (fit < SR_CONV_KSPLIT_MAX ? (int)fit : SR_CONV_KSPLIT_MAX);   // upper bound: the launch plans
     p.part = (float*)workspace;
   }
+#ifdef SR_CONV_ABLATION   // (ablation builds only: the product library reads no environment on a launch path)
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
+#else
+  p.debug = 0;
+#endif
   p.vec4 = (((uintptr_t)in & 15) == 0) && (in_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0);
   hipStream_t stream = (hipStream_t)stream_;
   const SrConvCfg cfg = sr_conv_cfg(p, B, stride, ksize);

@@ -418,8 +418,7 @@ extern "C" int sr_dot_volume_sweep(const float* cur, const float* invK_cur, cons
   if (C == 16) {
     // default: footprints of 8x32-pixel tiles staged in LDS (sr_dot_volume_lds.hip); SR_DOT_LDS=0 selects the
     // L1-gather kernels below (ablation), which also take the shapes the staged kernel refuses
-    const char* e = getenv("SR_DOT_LDS");
-    const int use_lds = e ? atoi(e) : 1;
+    const int use_lds = sr_opt(SR_OPT_DOT_LDS);
     if (use_lds) {
       const int rc = sr_launch_dot_volume_lds(p, sr_ws_keys(workspace, B, K, C, h, w), stream);
       if (rc != SR_ERR_UNSUPPORTED) return rc;
@@ -436,8 +435,7 @@ extern "C" int sr_dot_volume_sweep(const float* cur, const float* invK_cur, cons
     case 8: hipLaunchKernelGGL(sr_dot_volume_kernel<8>, grid, block, lds, stream, p); break;
     case 12: hipLaunchKernelGGL(sr_dot_volume_kernel<12>, grid, block, lds, stream, p); break;
     case 16: {
-      static int quad = -1;  // SR_DOT_QUAD=0 selects the generic lane-per-pixel kernel (ablation)
-      if (quad < 0) { const char* e = getenv("SR_DOT_QUAD"); quad = e ? atoi(e) : 1; }
+      const int quad = sr_opt(SR_OPT_DOT_QUAD);  // 0 selects the generic lane-per-pixel kernel (ablation)
       if (quad) hipLaunchKernelGGL(sr_dot_volume_kernel16q, grid, block, lds, stream, p);
       else hipLaunchKernelGGL(sr_dot_volume_kernel<16>, grid, block, lds, stream, p);
       break;

@@ -441,18 +441,13 @@ static void sr_launch_lds_variant(const SrDotParams& p, unsigned long long* keys
                      tiles_x, tiles_y, groups, cull);
 }
 
-static int sr_env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 int sr_launch_dot_volume_lds(const SrDotParams& p, unsigned long long* keys, hipStream_t stream) {
   if (p.w > 65000 || p.h > 65000) return SR_ERR_UNSUPPORTED;
-  // switches (read per call, so a test can flip them inside one process): LDS buffer in texels <-> workgroups per CU
-  // (634: 4, 770: 3), planes per group (2 / 4 / 8), hull culling on / off
-  const int Genv = sr_env_int("SR_DOT_LDS_G", 0);
-  const int cull_env = sr_env_int("SR_DOT_LDS_CULL", 1);
-  const int cap = sr_env_int("SR_DOT_LDS_CAP", 634);
+  // switches (option table): LDS buffer in texels <-> workgroups per CU (634: 4, 770: 3), planes per group (2 / 4 / 8), hull
+  // culling on / off
+  const int Genv = sr_opt(SR_OPT_DOT_LDS_G);
+  const int cull_env = sr_opt(SR_OPT_DOT_LDS_CULL);
+  const int cap = sr_opt(SR_OPT_DOT_LDS_CAP);
   const int tiles_x = (p.w + LT_W - 1) / LT_W, tiles_y = (p.h + LT_H - 1) / LT_H;
   int G = Genv;
   if (G != 2 && G != 4 && G != 8)  // small grids (batch 1): 2-plane groups give twice the workgroups to balance 256 CUs

@@ -101,10 +101,10 @@ bool make_plan_impl(hipblasLtHandle_t g_handle, const Key& key, Plan& plan, cons
   // M = 2400 ... 38400.  Time the candidates once, on the caller's own buffers and stream (the output is simply written
   // several times; C is the residual, never the output).  Skipped inside a stream capture (no synchronisation allowed
   // there) and with SR_GEMM_AUTOTUNE=0.
-  const char* env = getenv("SR_GEMM_AUTOTUNE");
+  const int autotune = sr_opt(SR_OPT_GEMM_AUTOTUNE);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(ta.stream, &cap);
-  if (found > 1 && !(env && atoi(env) == 0) && cap == hipStreamCaptureStatusNone) {
+  if (found > 1 && autotune != 0 && cap == hipStreamCaptureStatusNone) {
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
       if (ta.bias) hipblasLtMatmulDescSetAttribute(plan.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &ta.bias, sizeof(ta.bias));

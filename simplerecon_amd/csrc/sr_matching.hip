@@ -730,7 +730,7 @@ extern "C" int sr_conv3x3_c16_nhwc_fwd(const float* in, int64_t in_batch_stride,
   p.out_slope = leaky_slope;
   int blocks = 3 * sr_cus();
   if (blocks > p.total) blocks = p.total;
-  { const char* e = getenv("SR_T16_XCD"); p.xcd_order = e ? atoi(e) : 1; }   // (ablation; results are identical)
+  p.xcd_order = sr_opt(SR_OPT_T16_XCD);   // (ablation; results are identical)
   const bool norm = in_stats != nullptr, act = in_leaky_slope >= 0.f;
   if (norm && act) hipLaunchKernelGGL((sr_t16_kernel<true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
   else if (norm) hipLaunchKernelGGL((sr_t16_kernel<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p);
@@ -781,12 +781,12 @@ extern "C" int sr_maxblurpool_nhwc_fwd(const float* in, int64_t in_batch_stride,
     return SR_ERR_UNSUPPORTED;
   const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
   int bw = 2;   // output columns per thread.  4 (SR_POOL_BW=4, Wo % 4 == 0) issues 9.6 instead of 12.25 loads per output and is
-  { const char* e = getenv("SR_POOL_BW"); if (e && atoi(e) == 4 && Wo % 4 == 0) bw = 4; }   // SLOWER: 0.70 vs 0.45 ms per 64 images
+  if (sr_opt(SR_OPT_POOL_BW) == 4 && Wo % 4 == 0) bw = 4;   // SLOWER: 0.70 vs 0.45 ms per 64 images
                                                                                             // (half the threads, twice the registers)
   const int64_t total = (int64_t)((Ho + 1) / 2) * ((Wo + bw - 1) / bw) * (C / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   int xcd = ((int64_t)blocks * 256 >= total) && (((int64_t)blocks * B) % 8 == 0);   // no striding, whole eighths
-  { const char* e = getenv("SR_POOL_XCD"); if (e && atoi(e) == 0) xcd = 0; }          // (ablation; results are identical)
+  if (sr_opt(SR_OPT_POOL_XCD) == 0) xcd = 0;          // (ablation; results are identical)
   if (bw == 4)
     hipLaunchKernelGGL((sr_maxblurpool_kernel<4>), dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, in, in_batch_stride,
                        in_pix_stride, out, out_batch_stride, out_pix_stride, H, W, Ho, Wo, C / 4, xcd);

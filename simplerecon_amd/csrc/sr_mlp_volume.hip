@@ -924,14 +924,8 @@ __global__ __launch_bounds__(256, 1) void sr_mlp_volume_split_kernel(SrMlpParams
   }
 }
 
-// SR_MLP_SPLIT (read per call): 0 / unset = fp32 MFMA (the product path), "bf16" = 1, "f16" = 2
-static int sr_mlp_split_mode() {
-  const char* e = getenv("SR_MLP_SPLIT");
-  if (!e || !*e || !strcmp(e, "0") || !strcmp(e, "off") || !strcmp(e, "fp32")) return 0;
-  if (!strcmp(e, "bf16")) return 1;
-  if (!strcmp(e, "f16") || !strcmp(e, "fp16")) return 2;
-  return -1;
-}
+// option SR_OPT_MLP_SPLIT: 0 = fp32 MFMA (the product path), 1 = bf16 pieces, 2 = f16 pieces, -1 = unknown (refused)
+static int sr_mlp_split_mode() { return sr_opt(SR_OPT_MLP_SPLIT); }
 
 // lowest_cost = planes[argmax_d volume] (cost_volume.py:338-342, 374-378); first maximum wins
 __global__ void sr_argmax_planes_kernel(const float* __restrict__ cv, int64_t sb, int64_t sd, int64_t sp,
@@ -996,7 +990,11 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
   p.inv_w = (float)(1.0 / (double)w);
   p.inv_h = (float)(1.0 / (double)h);
   p.slope = leaky_slope;
+#ifdef SR_MLP_ABLATION   // (ablation builds only)
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SR_MLP_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
+#else
+  p.debug = 0;
+#endif
 
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -1020,8 +1018,8 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
   }
   p.vec_store = (cv_sd == 1) && (p.chunk % 4 == 0) && (cv_sp % 4 == 0) && (cv_sb % 4 == 0) &&
                 (((uintptr_t)out_cv & 15) == 0);
-  { const char* e = getenv("SR_MLP_VEC_STORE"); if (e && atoi(e) == 0) p.vec_store = 0; }   // ablation
-  { const char* e = getenv("SR_MLP_XCD"); p.xcd_order = e ? atoi(e) : 1; }
+  if (sr_opt(SR_OPT_MLP_VEC_STORE) == 0) p.vec_store = 0;   // ablation
+  p.xcd_order = sr_opt(SR_OPT_MLP_XCD);
   const long nunits = (long)B * p.tiles * p.chunks;
   const int blocks = (int)((nunits + 3) / 4 < cus ? (nunits + 3) / 4 : cus);
   const size_t w3_bytes = SR_LDS_W3_FLOATS * sizeof(float);

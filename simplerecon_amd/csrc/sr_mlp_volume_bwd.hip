@@ -684,8 +684,7 @@ extern "C" int sr_mlp_volume_bwd(const float* grad_cv, int64_t g_sb, int64_t g_s
   if (B < 0 || K <= 0 || C <= 0 || h <= 0 || w <= 0 || D <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (!dW1 || !db1 || !dW2 || !db2 || !dW3 || !db3) return SR_ERR_INVALID_ARGUMENT;
   const int Cin = C * (K + 1) + 10 * K + 4;
-  static int use_valu = -1;   // SR_MLP_BWD_VALU=1: the r01 VALU kernel (ablation; up to 9 views)
-  if (use_valu < 0) { const char* ev = getenv("SR_MLP_BWD_VALU"); use_valu = ev ? atoi(ev) : 0; }
+  const int use_valu = sr_opt(SR_OPT_MLP_BWD_VALU);   // 1: the r01 VALU kernel (ablation; up to 9 views)
   if (hidden != HID || C != 16 || Cin > (use_valu ? 256 : 416)) return SR_ERR_UNSUPPORTED;   // 16-channel features, <= 15 views
   hipStream_t stream = (hipStream_t)stream_;
   hipError_t e;

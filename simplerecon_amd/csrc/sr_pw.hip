@@ -235,9 +235,7 @@ struct PwPlan { int nt, ks; };
 // Launch plan: the widest channel block (fewest A re-reads) that still makes >= ~1.5 waves per SIMD; below that, split K
 // across the waves of a workgroup.  SR_PW_NT / SR_PW_KS force a plan (tests, sweeps).
 PwPlan pw_plan(int B, int HW, int Cin, int Cout) {
-  int f_nt = 0, f_ks = 0;   // (read per call: tests and sweeps switch plans inside one process)
-  { const char* e = getenv("SR_PW_NT"); f_nt = e ? atoi(e) : 0; }
-  { const char* e = getenv("SR_PW_KS"); f_ks = e ? atoi(e) : 0; }
+  const int f_nt = sr_opt(SR_OPT_PW_NT), f_ks = sr_opt(SR_OPT_PW_KS);   // forced plan (tests, sweeps); 0 = the cost model
   const long mt = (long)B * ((HW + 31) / 32);
   const int n32 = (Cout + 31) / 32;
   const int g8 = (Cin + 7) / 8;

@@ -185,9 +185,7 @@ constexpr int PT_BM[4] = {64, 128, 128, 64}, PT_BN[4] = {128, 160, 64, 64};
 // Tile shape by padding waste over the channel blocks, K split so that the grid makes ~1.5 workgroups per CU while a part
 // keeps >= 4 slabs.  SR_PT_CFG / SR_PT_KS force a plan (tests, sweeps).
 PtPlan pt_plan(int M, int Cin, int Cout, bool can_split) {
-  int f_cfg = -1, f_ks = 0;
-  { const char* e = getenv("SR_PT_CFG"); f_cfg = e ? atoi(e) : -1; }
-  { const char* e = getenv("SR_PT_KS"); f_ks = e ? atoi(e) : 0; }
+  const int f_cfg = sr_opt(SR_OPT_PT_CFG), f_ks = sr_opt(SR_OPT_PT_KS);   // forced plan (tests, sweeps)
   const int slabs = (Cin + PT_KS - 1) / PT_KS;
   const long want = (long)pt_num_cus() * 3 / 2;
   PtPlan best = {0, 1};

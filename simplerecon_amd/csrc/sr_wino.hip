@@ -724,8 +724,7 @@ extern "C" int sr_wino_pack_weights(const float* weight, int Cout, int Cin, floa
 // machine and little padding waste.  SR_CONV_WINO=0 disables, =2 forces it wherever it is applicable.
 extern "C" int sr_conv_prefers_wino(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
   if (ksize != 3 || stride != 1 || B <= 0) return 0;
-  static int mode = -1;
-  if (mode < 0) { const char* e = getenv("SR_CONV_WINO"); mode = e ? atoi(e) : 1; }
+  const int mode = sr_opt(SR_OPT_CONV_WINO);
   if (mode == 0) return 0;
   if (mode == 2) return 1;
   const long regions = (long)((H + 7) / 8) * ((W + 15) / 16);
@@ -749,9 +748,7 @@ struct SrWinoPlan { int nt, ks; };
 static SrWinoPlan sr_wino_plan(int B, int H, int W, int Cin, int Cout, bool allow_split) {
   const int co_pad = ((Cout + 31) / 32) * 32;
   const int slabs = (Cin + 15) / 16;
-  static int forced_nt = -1, forced_ks = -1;
-  if (forced_nt < 0) { const char* e = getenv("SR_WINO_NT"); forced_nt = e ? atoi(e) : 0; }
-  if (forced_ks < 0) { const char* e = getenv("SR_WINO_KSPLIT"); forced_ks = e ? atoi(e) : 0; }
+  const int forced_nt = sr_opt(SR_OPT_WINO_NT), forced_ks = sr_opt(SR_OPT_WINO_KSPLIT);
   const long regions = (long)((H + 2 * WN_TR - 1) / (2 * WN_TR)) * ((W + 2 * WN_TC - 1) / (2 * WN_TC)) * B;
   const long cus = sr_wino_num_cus(), slots = 2 * cus;
   SrWinoPlan best = {co_pad % 64 == 0 ? 2 : 1, 1};
@@ -844,12 +841,11 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
 #else
   p.debug = 0;
 #endif
-  { const char* e = getenv("SR_WINO_XCD"); p.xcd_order = e ? atoi(e) : 1; }
-  p.stagger = -1;
-  { const char* e = getenv("SR_WINO_STAGGER"); if (e) p.stagger = atoi(e); }   // experiment switch, see below
+  p.xcd_order = sr_opt(SR_OPT_WINO_XCD);
+  p.stagger = sr_opt(SR_OPT_WINO_STAGGER);   // experiment switch, see below
   hipStream_t stream = (hipStream_t)stream_;
   int blocks = sr_wino_num_cus() * (nt == 1 ? SR_WINO_NT1_WAVES : SR_WINO_WAVES);
-  { const char* e = getenv("SR_WINO_WG_PER_CU"); if (e && atoi(e) == 1) blocks = sr_wino_num_cus(); }  // ablation
+  if (sr_opt(SR_OPT_WINO_WG_PER_CU) == 1) blocks = sr_wino_num_cus();  // ablation
   if (blocks > p.total) blocks = p.total;
   if (p.stagger < 0) p.stagger = 0;
   // (Measured, r04: an offset of 3 x s_sleep(127) is -14 % / -15 % on 64 -> 64 / 192 -> 64 @ 8x240x320 in an isolated loop over

@@ -21,6 +21,7 @@
 // Because a lane holds all 36 frequencies of (4 consecutive output channels) x (one tile), the output transform
 // Y = A^T M A runs entirely in registers, IN PLACE over the accumulators (no LDS exchange, no barrier): a lane ends up with
 // 16 pixels x 4 channels = 16 float4: bias + residual + activation, 16-byte stores into the consumer's concat slice.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sr_common.h"
@@ -60,7 +61,20 @@ struct SrWino4Params {
   int B, H, W, Cin, Cout, Co_pad, S;
   int regions_x, regions_y, co_blocks, total;
   float slope;
+#ifdef SR_W4_TRACE
+  unsigned long long* trace;   // [blocks][2 groups][W4_TR_N] shader-clock stamps (debug builds only)
+#endif
 };
+#ifdef SR_W4_TRACE
+#define W4_TR_N 96
+#define W4_TR(code)                                                                                              \
+  do {                                                                                                           \
+    if (tid == 0 && tr_n < W4_TR_N && blockIdx.x < 16)                                                            \
+      p.trace[((size_t)blockIdx.x * 2 + grp) * W4_TR_N + tr_n++] = ((unsigned long long)(code) << 56) | (clock64() & 0xffffffffffffffull); \
+  } while (0)
+#else
+#define W4_TR(code) do {} while (0)
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_rsrc(const void* base, int64_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, W4_RSRC_FLAGS);
@@ -189,37 +203,138 @@ __device__ __forceinline__ void w4_epilogue(const SrWino4Params& p, const W4Item
     }
     w4_at(acc[6 * k], acc[6 * k + 1], acc[6 * k + 2], acc[6 * k + 3], acc[6 * k + 4], acc[6 * k + 5], acc[6 * k],
           acc[6 * k + 1], acc[6 * k + 2], acc[6 * k + 3]);
+    float o16[16];   // the row's 4 pixels x 4 channels: ONE activation-code test per row (a per-quad test is 5 scalar branches)
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       w4_f4 y = acc[6 * k + l] + bv;
       if (RES) y = y + rv[k & 1][l];
-      float o4[4] = {y[0], y[1], y[2], y[3]};
-      sr_activate_group(o4, slope);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o16[4 * l + r] = y[r];
+    }
+    sr_activate_group(o16, slope);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
       const unsigned d = (unsigned)((k * p.W + l) * p.out_sp) * 4u;
       const bool ok = FULL ? true : ((oy + k < p.H) & (ox + l < p.W));
-      w4_store(w4_f4{o4[0], o4[1], o4[2], o4[3]}, rs_out, FULL ? o0 + d : w4_sel(ok, o0 + d));
+      w4_store(w4_f4{o16[4 * l], o16[4 * l + 1], o16[4 * l + 2], o16[4 * l + 3]}, rs_out, FULL ? o0 + d : w4_sel(ok, o0 + d));
     }
   }
 }
 
+// V = B^T d B of this thread's (tile, ci) patch: raw -> V, in two halves of the vertical frequencies (18 instead of 36 live
+// temporaries; the 6 x 6 patch is read twice -- LDS reads are not what the phase waits for)
+__device__ __forceinline__ void w4_transform(const float* t_rd, float* t_wr) {
+#pragma unroll
+  for (int half = 0; half < ((SR_W4_ABL & 1) ? 0 : 2); ++half) {
+    float tt[3][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      float d[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) d[r] = t_rd[(r * W4_PS + c) * W4_RS];
+      if (half == 0) {
+        const float a = fmaf(-4.0f, d[2], d[4]), b = fmaf(-4.0f, d[1], d[3]);
+        tt[0][c] = fmaf(-4.25f, d[2], d[0]) + d[4];
+        tt[1][c] = fmaf(0.5f, b, a);
+        tt[2][c] = fmaf(-0.5f, b, a);
+      } else {
+        const float cc = fmaf(-0.25f, d[2], d[4]), e = fmaf(-0.25f, d[1], d[3]);
+        tt[0][c] = fmaf(2.0f, e, cc);
+        tt[1][c] = fmaf(-2.0f, e, cc);
+        tt[2][c] = fmaf(-4.25f, d[3], d[1]) + d[5];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float v[6];
+      w4_bt(tt[i][0], tt[i][1], tt[i][2], tt[i][3], tt[i][4], tt[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) t_wr[((3 * half + i) * 6 + j) * 256] = v[j];
+    }
+  }
+}
+
+// the first W4_PD frequency pairs' weight fragments of a slab (issued a barrier ahead of the MFMA tick that uses them)
+__device__ __forceinline__ void w4_u_prefetch(__amdgpu_buffer_rsrc_t rs_u, unsigned u_voff, unsigned u_slab, unsigned u_fstride,
+                                              w4_f4 (&ua)[W4_NA][2]) {
+  if (SR_W4_ABL & (2 | 32)) return;
+#pragma unroll
+  for (int fp = 0; fp < W4_PD; ++fp) {
+    ua[fp][0] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * fp) * u_fstride);
+    ua[fp][1] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * fp + 1) * u_fstride);
+  }
+}
+
+// 36 frequencies x (16 co x 16 tiles x 16 ci): pairs of frequencies interleaved (dependent MFMAs 64 clk apart); the first
+// W4_PD pairs of weight fragments are already in ua[]
+__device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsigned u_voff, unsigned u_slab, unsigned u_fstride,
+                                             const float* m_rd, w4_f4 (&ua)[W4_NA][2], w4_f4 (&acc)[36], int lane) {
+  if (SR_W4_ABL & 2) return;
+  w4_f4 vb[2][2];
+  if (SR_W4_ABL & 32) {
+#pragma unroll
+    for (int a = 0; a < W4_NA; ++a) ua[a][0] = ua[a][1] = w4_f4{1.0f, 2.0f, 3.0f, (float)u_slab};
+    vb[0][0] = vb[0][1] = vb[1][0] = vb[1][1] = w4_f4{1.0f, 0.5f, 0.25f, (float)lane};
+  } else {
+    vb[0][0] = *reinterpret_cast<const w4_f4*>(m_rd);
+    vb[0][1] = *reinterpret_cast<const w4_f4*>(m_rd + 256);
+  }
+#pragma unroll
+  for (int fp = 0; fp < 18; ++fp) {
+    if (!(SR_W4_ABL & 32) && fp + W4_PD < 18) {
+      ua[(fp + W4_PD) % W4_NA][0] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + W4_PD)) * u_fstride);
+      ua[(fp + W4_PD) % W4_NA][1] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + W4_PD) + 1) * u_fstride);
+    }
+    if (!(SR_W4_ABL & 32) && fp + 1 < 18) {
+      vb[(fp + 1) & 1][0] = *reinterpret_cast<const w4_f4*>(m_rd + (2 * fp + 2) * 256);
+      vb[(fp + 1) & 1][1] = *reinterpret_cast<const w4_f4*>(m_rd + (2 * fp + 3) * 256);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % W4_NA][0][e], vb[fp & 1][0][e], acc[2 * fp], 0, 0, 0);
+      acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % W4_NA][1][e], vb[fp & 1][1][e], acc[2 * fp + 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);   // keep the two accumulators interleaved (left alone hipcc issues 4 dependent MFMAs in a row)
+    }
+  }
+}
+
+__device__ __forceinline__ void w4_finish(const SrWino4Params& p, const W4Item& it, w4_f4 (&acc)[36], int wave, int m_kq,
+                                          int m_j, int tid) {
+  if (SR_W4_ABL & 4) {   // keep the accumulators alive without an epilogue
+    w4_f4 sum = acc[0];
+#pragma unroll
+    for (int f = 1; f < 36; ++f) sum = sum + acc[f];
+    if (sum[0] + sum[1] + sum[2] + sum[3] == 1.2345e33f) p.out[tid] = sum[0];
+    return;
+  }
+  const int cq = it.co0 + 16 * wave + 4 * m_kq;                       // first of this lane's 4 output channels
+  const bool full = (it.oy0 + 16 <= p.H) & (it.ox0 + 16 <= p.W);      // uniform
+  if (p.res != nullptr) {
+    if (full) w4_epilogue<true, true>(p, it, acc, cq, m_j);
+    else w4_epilogue<false, true>(p, it, acc, cq, m_j);
+  } else {
+    if (full) w4_epilogue<true, false>(p, it, acc, cq, m_j);
+    else w4_epilogue<false, false>(p, it, acc, cq, m_j);
+  }
+}
+
+// ---- the first form: two independent 4-wave workgroups per CU, each slab = stage / barrier / T / barrier / M in sequence.
+// Kept as `variant` 1 for A/B measurements; same operations in the same order as the ping-pong kernel below.
 __global__ __launch_bounds__(256, 2) void sr_wino4_kernel(SrWino4Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // transform role: thread (tile, ci)
   const int t_ci = tid & 15, t_tile = tid >> 4;
   const int t_sig = (0x1230 >> (t_tile & 12)) & 3;   // sigma(tile >> 2) = (0, 3, 2, 1)
   const float* t_rd = lds + ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3)) * W4_RS + t_ci;
   float* t_wr = lds + W4_RAW_FLOATS + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
-  // MFMA role: lane (j = tile / output-channel row, kq = K quarter)
   const int m_j = lane & 15, m_kq = lane >> 4;
   const int m_sig = (0x1230 >> (m_j & 12)) & 3;
   const float* m_rd = lds + W4_RAW_FLOATS + m_j * 16 + 4 * (m_kq ^ m_sig);
   const unsigned u_voff = (unsigned)(m_kq * p.Co_pad + 16 * wave + m_j) * 16u;
   const unsigned u_fstride = (SR_W4_ABL & 8) ? 0u : (unsigned)p.S * 4u * (unsigned)p.Co_pad * 16u;   // bytes between two frequencies
-  // staging role: float4 e = tid + 256 j of the patch, pixel pp = e >> 2 (row-major 18 x 18), channel quad q = e & 3
+  const unsigned u_sstride = (SR_W4_ABL & 8) ? 0u : 4u * (unsigned)p.Co_pad * 16u;                   // ... two slabs
   const int st_q = tid & 3, st_pp0 = tid >> 2;
   float* st_wr = lds + st_pp0 * W4_RS + 4 * st_q;
 
@@ -228,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void sr_wino4_kernel(SrWino4Params p) {
   W4Item it = w4_decode(p, work);
   w4_f4 st[W4_STAGE];
   w4_stage(p, it, 0, st_q, st_pp0, st);
-
+  const __amdgpu_buffer_rsrc_t rs_u = w4_rsrc(p.wu, (int64_t)36 * p.S * 4 * p.Co_pad * 16);
   for (;;) {
     const int next_work = work + (int)gridDim.x;
     const bool has_next = next_work < p.total;
@@ -236,12 +351,9 @@ __global__ __launch_bounds__(256, 2) void sr_wino4_kernel(SrWino4Params p) {
     w4_f4 acc[36];
 #pragma unroll
     for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
-    const unsigned u_item = (unsigned)it.co0 * 16u;
-    const __amdgpu_buffer_rsrc_t rs_u = w4_rsrc(p.wu, (int64_t)36 * p.S * 4 * p.Co_pad * 16);
-
+    const unsigned u_item = (SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u;
     for (int s = 0; s < p.S; ++s) {
-      // ---- S: this slab's patch registers -> LDS; then the next slab's (or the next item's first) loads
-      if (!(SR_W4_ABL & 16)) {
+      if (!(SR_W4_ABL & 16)) {   // this slab's patch registers -> LDS; then the next slab's (or the next item's first) loads
 #pragma unroll
         for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(st_wr + j * 64 * W4_RS) = st[j];
         if (tid < 16) *reinterpret_cast<w4_f4*>(st_wr + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
@@ -249,98 +361,145 @@ __global__ __launch_bounds__(256, 2) void sr_wino4_kernel(SrWino4Params p) {
         else if (has_next) w4_stage(p, nxt, 0, st_q, st_pp0, st);
       }
       __syncthreads();   // raw visible; every wave is past the previous slab's V reads
-
-      // ---- T: V = B^T d B for (tile, ci), in two halves of the vertical frequencies (18 instead of 36 live temporaries;
-      // the 6 x 6 patch is read twice -- LDS reads are not what this phase waits for)
-#pragma unroll
-      for (int half = 0; half < ((SR_W4_ABL & 1) ? 0 : 2); ++half) {
-        float t[3][6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          float d[6];
-#pragma unroll
-          for (int r = 0; r < 6; ++r) d[r] = t_rd[(r * W4_PS + c) * W4_RS];
-          if (half == 0) {   // rows 0, 1, 2 of B^T d
-            const float a = fmaf(-4.0f, d[2], d[4]), b = fmaf(-4.0f, d[1], d[3]);
-            t[0][c] = fmaf(-4.25f, d[2], d[0]) + d[4];
-            t[1][c] = fmaf(0.5f, b, a);
-            t[2][c] = fmaf(-0.5f, b, a);
-          } else {           // rows 3, 4, 5
-            const float cc = fmaf(-0.25f, d[2], d[4]), e = fmaf(-0.25f, d[1], d[3]);
-            t[0][c] = fmaf(2.0f, e, cc);
-            t[1][c] = fmaf(-2.0f, e, cc);
-            t[2][c] = fmaf(-4.25f, d[3], d[1]) + d[5];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          float v[6];
-          w4_bt(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
-#pragma unroll
-          for (int j = 0; j < 6; ++j) t_wr[((3 * half + i) * 6 + j) * 256] = v[j];
-        }
-      }
+      w4_transform(t_rd, t_wr);
       __syncthreads();   // V visible (and raw free for the next slab's store)
-
-      // ---- M: 36 frequencies x (16 co x 16 tiles x 16 ci), pairs of frequencies interleaved (dependent MFMAs 64 clk apart)
-      if (!(SR_W4_ABL & 2)) {
-        const unsigned u_slab = (SR_W4_ABL & 8) ? 0u : u_item + (unsigned)s * 4u * (unsigned)p.Co_pad * 16u;
-        w4_f4 ua[W4_NA][2], vb[2][2];
-        if (SR_W4_ABL & 32) {
-#pragma unroll
-          for (int a = 0; a < W4_NA; ++a) ua[a][0] = ua[a][1] = w4_f4{1.0f, 2.0f, 3.0f, (float)s};
-          vb[0][0] = vb[0][1] = vb[1][0] = vb[1][1] = w4_f4{1.0f, 0.5f, 0.25f, (float)lane};
-        }
-#pragma unroll
-        for (int fp = 0; fp < ((SR_W4_ABL & 32) ? 0 : W4_PD); ++fp) {
-          ua[fp][0] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * fp) * u_fstride);
-          ua[fp][1] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * fp + 1) * u_fstride);
-        }
-        if (!(SR_W4_ABL & 32)) {
-          vb[0][0] = *reinterpret_cast<const w4_f4*>(m_rd);
-          vb[0][1] = *reinterpret_cast<const w4_f4*>(m_rd + 256);
-        }
-#pragma unroll
-        for (int fp = 0; fp < 18; ++fp) {
-          if (!(SR_W4_ABL & 32) && fp + W4_PD < 18) {
-            ua[(fp + W4_PD) % W4_NA][0] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + W4_PD)) * u_fstride);
-            ua[(fp + W4_PD) % W4_NA][1] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + W4_PD) + 1) * u_fstride);
-          }
-          if (!(SR_W4_ABL & 32) && fp + 1 < 18) {
-            vb[(fp + 1) & 1][0] = *reinterpret_cast<const w4_f4*>(m_rd + (2 * fp + 2) * 256);
-            vb[(fp + 1) & 1][1] = *reinterpret_cast<const w4_f4*>(m_rd + (2 * fp + 3) * 256);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % W4_NA][0][e], vb[fp & 1][0][e], acc[2 * fp], 0, 0, 0);
-            acc[2 * fp + 1] =
-                __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % W4_NA][1][e], vb[fp & 1][1][e], acc[2 * fp + 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);   // keep the two accumulators interleaved (left alone hipcc issues 4 dependent MFMAs in a row)
-          }
-        }
-      }
+      w4_f4 ua[W4_NA][2];
+      w4_u_prefetch(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, ua);
+      w4_mfma_tick(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, m_rd, ua, acc, lane);
     }
-
-    if (SR_W4_ABL & 4) {   // keep the accumulators alive without an epilogue
-      w4_f4 sum = acc[0];
-#pragma unroll
-      for (int f = 1; f < 36; ++f) sum = sum + acc[f];
-      if (sum[0] + sum[1] + sum[2] + sum[3] == 1.2345e33f) p.out[tid] = sum[0];
-    } else {
-      const int cq = it.co0 + 16 * wave + 4 * m_kq;           // first of this lane's 4 output channels
-      const bool full = (it.oy0 + 16 <= p.H) & (it.ox0 + 16 <= p.W);   // uniform
-      if (p.res != nullptr) {
-        if (full) w4_epilogue<true, true>(p, it, acc, cq, m_j);
-        else w4_epilogue<false, true>(p, it, acc, cq, m_j);
-      } else {
-        if (full) w4_epilogue<true, false>(p, it, acc, cq, m_j);
-        else w4_epilogue<false, false>(p, it, acc, cq, m_j);
-      }
-    }
+    w4_finish(p, it, acc, wave, m_kq, m_j, tid);
     if (!has_next) break;
     work = next_work;
     it = nxt;
   }
+}
+
+// ---- the ping-pong form (default): ONE 8-wave workgroup per CU = two 4-wave groups, each walking its own list of work items
+// with the slab pipeline of sr_wino4_kernel, one workgroup barrier per TICK, and the two groups one tick apart: while group A
+// transforms (LDS + VALU + its epilogue's memory traffic) group B streams MFMAs, then they swap.  Two independent workgroups
+// per CU that start together run their phases IN step (r04 found the same on sr_wino_kernel; r05 ablations on the 4-wave form:
+// MFMA 72 us + transform 19 + operand loads 45 + staging 32 + epilogue 64 = the measured 218 us of a 64 -> 64 layer at
+// 8 x 240 x 320, i.e. nothing overlapped); here the complementary phases are the construction, not an accident.
+//   T tick of a group:  [tail tick: epilogue of the item that just finished]  T(s): raw -> V;  first weight fragments of M(s)
+//   M tick:             M(s): 144 MFMAs per wave;  patch registers of slab s + 1 -> raw;  loads of slab s + 2
+// (raw is read in T ticks and written at the end of M ticks, V is written in T ticks and read in M ticks: the tick barrier
+// orders both).  An item takes 2 S ticks.  Every wave executes the same NUMBER of barriers: group 1 starts one barrier late,
+// whoever finishes first pads.
+__global__ __launch_bounds__(512, 2) void sr_wino4pp_kernel(SrWino4Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  float* lds = lds_all + grp * (W4_RAW_FLOATS + W4_V_FLOATS);
+  const int tid = threadIdx.x & 255;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int t_ci = tid & 15, t_tile = tid >> 4;
+  const int t_sig = (0x1230 >> (t_tile & 12)) & 3;
+  const float* t_rd = lds + ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3)) * W4_RS + t_ci;
+  float* t_wr = lds + W4_RAW_FLOATS + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
+  const int m_j = lane & 15, m_kq = lane >> 4;
+  const int m_sig = (0x1230 >> (m_j & 12)) & 3;
+  const float* m_rd = lds + W4_RAW_FLOATS + m_j * 16 + 4 * (m_kq ^ m_sig);
+  const unsigned u_voff = (unsigned)(m_kq * p.Co_pad + 16 * wave + m_j) * 16u;
+  const unsigned u_fstride = (SR_W4_ABL & 8) ? 0u : (unsigned)p.S * 4u * (unsigned)p.Co_pad * 16u;
+  const unsigned u_sstride = (SR_W4_ABL & 8) ? 0u : 4u * (unsigned)p.Co_pad * 16u;   // bytes between two slabs
+  const int st_q = tid & 3, st_pp0 = tid >> 2;
+  float* st_wr = lds + st_pp0 * W4_RS + 4 * st_q;
+
+  // this group's items: slot, slot + stride, ...; barriers: grp + 1 + 2 S per item, padded to the longer group's count
+  const int stride = 2 * (int)gridDim.x;
+  const int slot = 2 * (int)blockIdx.x + grp;
+  const int n_mine = slot < p.total ? (p.total - slot + stride - 1) / stride : 0;
+  const int n_a = (p.total - 2 * (int)blockIdx.x + stride - 1) / stride;   // group 0 (the grid never exceeds ceil(total / 2))
+  const int n_b = 2 * (int)blockIdx.x + 1 < p.total ? (p.total - 2 * (int)blockIdx.x - 1 + stride - 1) / stride : 0;
+  const int bars_a = 1 + 2 * p.S * n_a, bars_b = n_b > 0 ? 2 + 2 * p.S * n_b : 0;
+  const int bars_all = bars_a > bars_b ? bars_a : bars_b;
+  int bars = 0;   // barriers this wave has executed
+#ifdef SR_W4_TRACE
+  int tr_n = 0;
+#endif
+
+  if (n_mine > 0) {
+    int work = slot;
+    W4Item it = w4_decode(p, work);
+    w4_f4 st[W4_STAGE];
+    w4_f4 acc[36];
+#pragma unroll
+    for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    w4_f4 ua[W4_NA][2];
+    const __amdgpu_buffer_rsrc_t rs_u = w4_rsrc(p.wu, (int64_t)36 * p.S * 4 * p.Co_pad * 16);
+    if (grp == 1) { __syncthreads(); ++bars; }   // one tick late
+    // first patch: slab 0 -> raw (this group's own buffer, nobody else reads it: no barrier needed before its own T ... but the
+    // writers are 4 waves and the readers other threads of the group: the tick barrier below comes AFTER T, so synchronise the
+    // group here through a workgroup barrier that the other group matches with one of its own ticks)
+    w4_stage(p, it, 0, st_q, st_pp0, st);
+    if (!(SR_W4_ABL & 16)) {
+#pragma unroll
+      for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(st_wr + j * 64 * W4_RS) = st[j];
+      if (tid < 16) *reinterpret_cast<w4_f4*>(st_wr + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
+    }
+    {
+      const bool more = p.S > 1 || n_mine > 1;
+      if (!(SR_W4_ABL & 16) && more) {
+        if (p.S > 1) w4_stage(p, it, 1, st_q, st_pp0, st);
+        else w4_stage(p, w4_decode(p, work + stride), 0, st_q, st_pp0, st);
+      }
+    }
+    __syncthreads(); ++bars;   // raw(slab 0) visible to the group
+    w4_transform(t_rd, t_wr);
+    w4_u_prefetch(rs_u, u_voff, (SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u, u_fstride, ua);
+    __syncthreads(); ++bars;   // ---- end of the first T tick
+
+    for (int done = 0; done < n_mine; ++done) {
+      const bool has_next = done + 1 < n_mine;
+      const W4Item nxt = w4_decode(p, has_next ? work + stride : work);
+      const unsigned u_item = (SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u;
+      for (int s = 0; s < p.S; ++s) {
+        // ---- M tick: MFMAs of slab s; then the patch in st[] (slab s + 1 / the next item's slab 0) -> raw and the loads of
+        // the patch after that
+        W4_TR(1);
+        w4_mfma_tick(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, m_rd, ua, acc, lane);
+        W4_TR(2);
+        const bool last = s + 1 == p.S;
+        if (!(SR_W4_ABL & 16) && (!last || has_next)) {
+#pragma unroll
+          for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(st_wr + j * 64 * W4_RS) = st[j];
+          if (tid < 16) *reinterpret_cast<w4_f4*>(st_wr + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
+          if (s + 2 < p.S) w4_stage(p, it, s + 2, st_q, st_pp0, st);
+          else if (!last && has_next) w4_stage(p, nxt, 0, st_q, st_pp0, st);                  // s + 2 == S: the next item's slab 0
+          else if (last && has_next) {                                                         // the next item's slab 1 / its successor's slab 0
+            if (p.S > 1) w4_stage(p, nxt, 1, st_q, st_pp0, st);
+            else if (done + 2 < n_mine) w4_stage(p, w4_decode(p, work + 2 * stride), 0, st_q, st_pp0, st);
+          }
+        }
+        W4_TR(3);
+        __syncthreads(); ++bars;
+        if (!last) {
+          // ---- T tick of slab s + 1
+          W4_TR(4);
+          w4_transform(t_rd, t_wr);
+          w4_u_prefetch(rs_u, u_voff, u_item + (unsigned)(s + 1) * u_sstride, u_fstride, ua);
+          W4_TR(5);
+          __syncthreads(); ++bars;
+        }
+      }
+      // ---- tail tick: this item's epilogue, then T of the next item's slab 0
+      W4_TR(6);
+      w4_finish(p, it, acc, wave, m_kq, m_j, tid);
+      W4_TR(7);
+#pragma unroll
+      for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (has_next) {
+        w4_transform(t_rd, t_wr);
+        w4_u_prefetch(rs_u, u_voff, (SR_W4_ABL & 8) ? 0u : (unsigned)nxt.co0 * 16u, u_fstride, ua);
+        W4_TR(8);
+        __syncthreads(); ++bars;
+      }
+      work += stride;
+      it = nxt;
+    }
+  }
+  for (; bars < bars_all; ++bars) __syncthreads();   // (the other group is still working)
 }
 
 // U = G g G^T per (co, ci) for the points (0, 1/2, -1/2, 2, -2, inf), in double, rounded once; stored in MFMA A-fragment
@@ -417,10 +576,9 @@ extern "C" int sr_conv_prefers_wino4(int B, int H, int W, int Cin, int Cout, int
   return (util >= 0.9 && co_util >= 0.99 && Cin >= 16 && items >= 3 * slots && fill >= 0.85) ? 1 : 0;
 }
 
-extern "C" int sr_conv3x3_wino4_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u,
-                                         const float* bias, const float* residual, int64_t res_batch_stride,
-                                         int res_pix_stride, float* out, int64_t out_batch_stride, int out_pix_stride, int B,
-                                         int H, int W, int Cin, int Cout, float leaky_slope, void* stream_) {
+static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u, const float* bias,
+                  const float* residual, int64_t res_batch_stride, int res_pix_stride, float* out, int64_t out_batch_stride,
+                  int out_pix_stride, int B, int H, int W, int Cin, int Cout, float leaky_slope, int variant, void* stream_) {
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SR_ERR_INVALID_ARGUMENT;
   if (B == 0) return SR_OK;
   if (!in || !packed_u || !out) return SR_ERR_INVALID_ARGUMENT;
@@ -449,10 +607,71 @@ extern "C" int sr_conv3x3_wino4_nhwc_fwd(const float* in, int64_t in_batch_strid
   if (total >= lim) return SR_ERR_UNSUPPORTED;
   p.total = (int)total;
   p.slope = leaky_slope;
-  int blocks = 2 * w4_num_cus();
-  if (blocks > p.total) blocks = p.total;
-  hipError_t e = hipFuncSetAttribute((const void*)sr_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
+  if (variant != 2) {   // two independent 4-wave workgroups per CU
+    int blocks = 2 * w4_num_cus();
+    if (blocks > p.total) blocks = p.total;
+    hipError_t e = hipFuncSetAttribute((const void*)sr_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
+    if (e != hipSuccess) return sr_hip_rc(e);
+    hipLaunchKernelGGL(sr_wino4_kernel, dim3(blocks), dim3(256), W4_LDS_BYTES, (hipStream_t)stream_, p);
+    return sr_hip_rc(hipGetLastError());
+  }
+  int blocks = w4_num_cus();
+  if (blocks > (p.total + 1) / 2) blocks = (p.total + 1) / 2;
+#ifdef SR_W4_TRACE
+  static unsigned long long* trace_buf = nullptr;
+  static int launches = 0;
+  const size_t trace_n = (size_t)16 * 2 * W4_TR_N;
+  if (!trace_buf) (void)hipMalloc((void**)&trace_buf, trace_n * 8);
+  (void)hipMemsetAsync(trace_buf, 0, trace_n * 8, (hipStream_t)stream_);
+  p.trace = trace_buf;
+#endif
+  hipError_t e = hipFuncSetAttribute((const void*)sr_wino4pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_LDS_BYTES);
   if (e != hipSuccess) return sr_hip_rc(e);
-  hipLaunchKernelGGL(sr_wino4_kernel, dim3(blocks), dim3(256), W4_LDS_BYTES, (hipStream_t)stream_, p);
+  hipLaunchKernelGGL(sr_wino4pp_kernel, dim3(blocks), dim3(512), 2 * W4_LDS_BYTES, (hipStream_t)stream_, p);
+#ifdef SR_W4_TRACE
+  {
+    const char* at = getenv("SR_W4_TRACE_LAUNCH");
+    if (++launches == (at ? atoi(at) : 10)) {
+      (void)hipStreamSynchronize((hipStream_t)stream_);
+      unsigned long long* host = (unsigned long long*)malloc(trace_n * 8);
+      (void)hipMemcpy(host, trace_buf, trace_n * 8, hipMemcpyDeviceToHost);
+      for (int b = 0; b < 16 && b < blocks; b += 5)
+        for (int g = 0; g < 2; ++g) {
+          fprintf(stderr, "W4TRACE block %d group %d:", b, g);
+          unsigned long long t0 = host[((size_t)b * 2 + 0) * W4_TR_N] & 0xffffffffffffffull, prev = 0;
+          for (int i = 0; i < W4_TR_N; ++i) {
+            const unsigned long long v = host[((size_t)b * 2 + g) * W4_TR_N + i];
+            if (!v) break;
+            const unsigned long long t = (v & 0xffffffffffffffull) - t0;
+            fprintf(stderr, " %d@%llu(+%llu)", (int)(v >> 56), t, t - prev);
+            prev = t;
+          }
+          fprintf(stderr, "\n");
+        }
+      free(host);
+    }
+  }
+#endif
   return sr_hip_rc(hipGetLastError());
+}
+
+extern "C" int sr_conv3x3_wino4_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u,
+                                         const float* bias, const float* residual, int64_t res_batch_stride,
+                                         int res_pix_stride, float* out, int64_t out_batch_stride, int out_pix_stride, int B,
+                                         int H, int W, int Cin, int Cout, float leaky_slope, void* stream_) {
+  return w4_run(in, in_batch_stride, in_pix_stride, packed_u, bias, residual, res_batch_stride, res_pix_stride, out,
+                out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, leaky_slope, 0, stream_);
+}
+
+// `variant` 0: the default form (= sr_conv3x3_wino4_nhwc_fwd), 1: two independent 4-wave workgroups per CU, 2: one 8-wave
+// ping-pong workgroup per CU.  All forms compute every output with the same operations in the same order: bit-identical
+// results (tests/test_gpu_wino4.py).
+extern "C" int sr_conv3x3_wino4_variant_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride,
+                                                 const float* packed_u, const float* bias, const float* residual,
+                                                 int64_t res_batch_stride, int res_pix_stride, float* out,
+                                                 int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
+                                                 int Cout, float leaky_slope, int variant, void* stream_) {
+  if (variant < 0 || variant > 2) return SR_ERR_INVALID_ARGUMENT;
+  return w4_run(in, in_batch_stride, in_pix_stride, packed_u, bias, residual, res_batch_stride, res_pix_stride, out,
+                out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, leaky_slope, variant, stream_);
 }

@@ -424,13 +424,7 @@ __global__ __launch_bounds__(256, NT == 1 ? SR_WS_NT1_WGS : 2) void sr_wino_spli
 
 // ------------------------------------------------------------------ host side (called from sr_wino.hip) -------------
 
-int sr_wino_split_mode() {
-  const char* e = getenv("SR_WINO_SPLIT");
-  if (!e || !*e || !strcmp(e, "0") || !strcmp(e, "off") || !strcmp(e, "fp32")) return 0;
-  if (!strcmp(e, "bf16")) return 1;
-  if (!strcmp(e, "f16") || !strcmp(e, "fp16")) return 2;
-  return -1;
-}
+int sr_wino_split_mode() { return sr_opt(SR_OPT_WINO_SPLIT); }
 
 int sr_wino_split_pack(const float* weight, int Cout, int Cin, float* packed, int mode, hipStream_t stream) {
   const int G = ((Cin + 15) / 16) * 2, Co_pad = ((Cout + 31) / 32) * 32;

@@ -3,10 +3,15 @@
 `split_precision("f16")` turns on the two fenced split-precision kernels for the calls made inside
 the block: the metadata-MLP sweep's layers 1-2 and the Winograd 3x3 convolutions then multiply on the 16-bit matrix pipe --
 every fp32 operand as two 16-bit pieces, three exact products, fp32 accumulate.  Tensors, parameters and results stay fp32.
-The library reads the switches per call (environment `SR_MLP_SPLIT`, `SR_WINO_SPLIT`), so the block must enclose the
-forward calls themselves; packed weights are re-packed when the mode changes (`ops.packed_wino_weight`'s cache key)."""
+The modes are entries of the library's option table (`SR_MLP_SPLIT`, `SR_WINO_SPLIT`: include/simplerecon_hip.h), set
+through `_lib.set_option` -- the process environment is neither read nor written (r04 mutated os.environ, which the library
+re-read with getenv() on every launch: a data race against launches on other threads, and inherited by child processes).
+The table is process-wide: launches from OTHER threads inside the block run split as well, and a HIP graph captured inside
+the block keeps the split kernels after it.  The block must enclose the forward calls themselves; packed weights are
+re-packed when the mode changes (`ops.packed_wino_weight`'s cache key)."""
 import contextlib
-import os
+
+from . import _lib
 
 _MODES = ("f16", "bf16")
 
@@ -19,14 +24,11 @@ def split_precision(mode="f16", sweep=True, convs=True):
     if mode not in _MODES:
         raise ValueError(f"split_precision mode must be one of {_MODES}, got {mode!r}")
     names = [n for n, on in (("SR_MLP_SPLIT", sweep), ("SR_WINO_SPLIT", convs)) if on]
-    saved = {n: os.environ.get(n) for n in names}
+    saved = {}
     try:
         for n in names:
-            os.environ[n] = mode
+            saved[n] = _lib.set_option(n, mode)
         yield
     finally:
         for n, v in saved.items():
-            if v is None:
-                os.environ.pop(n, None)
-            else:
-                os.environ[n] = v
+            _lib.set_option(n, v)

@@ -258,9 +258,9 @@ _PACKED_WINO = weakref.WeakKeyDictionary()  # nn.Conv2d -> (weight version, data
 
 
 def wino_split_mode():
-    """'' (off: fp32 MFMA, the product path), 'bf16' or 'f16': the fenced split-precision Winograd variant, read per call."""
-    v = os.environ.get("SR_WINO_SPLIT", "")
-    return "" if v in ("", "0", "off", "fp32") else v
+    """'' (off: fp32 MFMA, the product path), 'bf16' or 'f16': the fenced split-precision Winograd variant -- the library's
+    option SR_WINO_SPLIT (one atomic load; set with _lib.set_option / experimental.split_precision)."""
+    return _lib.split_mode_name("SR_WINO_SPLIT")
 
 
 def packed_wino_weight(conv: nn.Conv2d, bn=None):
@@ -288,6 +288,9 @@ _PACKED_WINO4 = weakref.WeakKeyDictionary()  # nn.Conv2d -> (state key, F(4x4, 3
 # (sr_conv_prefers_wino4: the full-resolution layers at batch 8), "0" = none, "2" = every layer it applies to (tests).
 # Read once, handed to the library as an argument.
 WINO4_MODE = int(os.environ.get("SR_CONV_WINO4", "1"))
+# kernel form: 0 = the library's default, 1 = two independent 4-wave workgroups per CU, 2 = the 8-wave ping-pong workgroup
+# (bit-identical results; A/B measurements)
+WINO4_VARIANT = int(os.environ.get("SR_WINO4_VARIANT", "0"))
 
 
 def packed_wino4_weight(conv: nn.Conv2d, bn=None):
@@ -460,9 +463,10 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 if prof is not None:
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ev0.record()
-                rc = lib.sr_conv3x3_wino4_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp4), _lib.ptr(bias4), _lib.ptr(residual), rsb,
-                                                   rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co,
-                                                   C.c_float(_act_code(leaky, act)), _lib.stream_ptr(x.device))
+                rc = lib.sr_conv3x3_wino4_variant_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp4), _lib.ptr(bias4),
+                                                           _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co,
+                                                           C.c_float(_act_code(leaky, act)), WINO4_VARIANT,
+                                                           _lib.stream_ptr(x.device))
                 if prof is not None and rc == 0:
                     ev1.record()
                     regions = ((h + 15) // 16) * ((w + 15) // 16)   # multiplies issued: 36 per 4x4 tile and (ci, co) pair, padded

@@ -112,3 +112,37 @@ def test_depth_model_default_construction_is_all_native():
     with pytest.raises(HipLibraryError), torch.inference_mode():
         model.forward_tensors(torch.zeros(1, 3, 96, 128), torch.zeros(1, 2, 3, 96, 128), torch.eye(4).expand(1, 2, 4, 4),
                               torch.eye(4).expand(1, 2, 4, 4), torch.eye(4).expand(1, 2, 4, 4), torch.eye(4)[None])
+
+
+def test_option_table_is_explicit_and_seeded_once_from_the_environment():
+    """include/simplerecon_hip.h, SR_OPT_*: every run-time switch is an entry of one table -- named like the environment
+    variable that seeds it at the first access, read / set through the C ABI afterwards (host-only code: runs without a GPU).
+    Changing the environment later has no effect."""
+    import ctypes as C
+    import os
+    from simplerecon_amd import _lib
+    lib = _lib.lib()
+    n = lib.sr_option_count()
+    names = [lib.sr_option_name(i).decode() for i in range(n)]
+    assert len(set(names)) == n and all(nm.startswith("SR_") for nm in names)
+    assert {"SR_MLP_SPLIT", "SR_WINO_SPLIT", "SR_WINO_XCD", "SR_PW_NT", "SR_DOT_LDS"} <= set(names)
+    assert lib.sr_option_id(b"SR_NO_SUCH_SWITCH") == -1 and lib.sr_option_name(n) is None
+    for i, nm in enumerate(names):
+        assert lib.sr_option_id(nm.encode()) == i
+    d = C.c_int(0)
+    assert lib.sr_option_default(lib.sr_option_id(b"SR_WINO_XCD"), C.byref(d)) == 0 and d.value == 1
+    before = _lib.get_option("SR_PW_NT")
+    os.environ["SR_PW_NT"] = "4"          # too late: the table was seeded at the first access
+    try:
+        assert _lib.get_option("SR_PW_NT") == before
+        with _lib.option("SR_PW_NT", 2):
+            assert _lib.get_option("SR_PW_NT") == 2
+            with _lib.option("SR_PW_NT", 1):
+                assert _lib.get_option("SR_PW_NT") == 1
+            assert _lib.get_option("SR_PW_NT") == 2
+        assert _lib.get_option("SR_PW_NT") == before
+    finally:
+        del os.environ["SR_PW_NT"]
+    assert _lib.set_option("SR_MLP_SPLIT", "int8") in (0, 1, 2, -1) and _lib.get_option("SR_MLP_SPLIT") == -1
+    _lib.set_option("SR_MLP_SPLIT", 0)
+    assert lib.sr_option_set(n, 0, None) == 1 and lib.sr_option_get(-1, C.byref(d)) == 1   # SR_ERR_INVALID_ARGUMENT

@@ -157,7 +157,7 @@ def test_conv_random_shapes_and_options():
                                    (1, 384, 384, 15, 20, True, 0.2), (8, 64, 64, 120, 160, True, 0.2), (4, 32, 64, 37, 53, True, 0.0),
                                    (2, 128, 128, 64, 96, False, 0.2), (1, 64, 128, 8, 16, True, None), (5, 80, 64, 24, 40, True, 0.2),
                                    (3, 48, 32, 17, 29, True, 0.2), (8, 64, 64, 240, 320, True, 0.2), (2, 16, 64, 33, 47, True, 0.2)])
-def test_winograd_pipeline_cases_and_work_order(shape, monkeypatch):
+def test_winograd_pipeline_cases_and_work_order(shape, monkeypatch, sr_option):
     """The software-pipelined slab loop of sr_wino_kernel (next slab stored mid-slab, barrier after step 5, transform of
     its first channel group under the last MFMA steps; next REGION's first slab chained in when the slab count is even)
     over its structural cases: one slab (16 channels), odd and even slab counts (2, 3, 4, 5, 8, 12, 24), many regions
@@ -170,10 +170,10 @@ def test_winograd_pipeline_cases_and_work_order(shape, monkeypatch):
     x = torch.randn((B, ci, h, w), generator=g).to(DEV)
     res = torch.randn((B, co, h, w), generator=g).to(DEV) if extras else None
     conv = conv.to(DEV)
-    monkeypatch.setenv("SR_CONV_WINO", "2")
+    sr_option("SR_CONV_WINO", 2)
     outs = []
     for mode in ("0", "1", "1"):
-        monkeypatch.setenv("SR_WINO_XCD", mode)
+        sr_option("SR_WINO_XCD", int(mode))
         with torch.inference_mode():
             outs.append(ops.conv2d(x, conv, residual=res, leaky=leaky).clone())
     torch.cuda.synchronize()
@@ -237,15 +237,15 @@ PW_SHAPES = [  # (B, Cin, Cout, h, w, act, residual, gate)
 
 @pytest.mark.parametrize("shape", PW_SHAPES)
 @pytest.mark.parametrize("plan", [None, (0, 1), (0, 4), (1, 1), (1, 2), (2, 1), (3, 2), (3, 8)])
-def test_pointwise_gemm_tiled_kernel(shape, plan, monkeypatch):
+def test_pointwise_gemm_tiled_kernel(shape, plan, monkeypatch, sr_option):
     """sr_pw_conv_tiled_nhwc_fwd (csrc/sr_pw_tiled.hip): the LDS-tiled form of the same operator on batch-dense maps --
     every tile configuration (64x128, 128x160, 128x64, 64x64) and K split (partials added in index order), gate per image
     with pixel tiles that straddle images, ragged M / N / K tails, channel-slice operands -- against ATen in float64."""
     B, ci, co, h, w, act, with_res, with_gate = shape
     monkeypatch.setattr(ops, "PW_TILED", "1")
     if plan is not None:
-        monkeypatch.setenv("SR_PT_CFG", str(plan[0]))
-        monkeypatch.setenv("SR_PT_KS", str(plan[1]))
+        sr_option("SR_PT_CFG", plan[0])
+        sr_option("SR_PT_KS", plan[1])
         if plan[1] > 1 and ((ci + 31) // 32 // plan[1] < 4 or co % 4):
             pytest.skip("K too short (or Cout not in float4 quads) for this split")
     ops._SHAPE_QUERIES.clear()
@@ -285,15 +285,15 @@ def test_pointwise_gemm_tiled_kernel(shape, plan, monkeypatch):
 
 @pytest.mark.parametrize("shape", PW_SHAPES)
 @pytest.mark.parametrize("plan", [None, (1, 1), (2, 2), (2, 4), (4, 1)])
-def test_pointwise_gemm_kernel(shape, plan, monkeypatch):
+def test_pointwise_gemm_kernel(shape, plan, monkeypatch, sr_option):
     """sr_pw_conv_nhwc_fwd (csrc/sr_pw.hip): the 1x1 convolution as a hand-written fp32-MFMA GEMM -- bias, BatchNorm fold,
     residual before the activation, SiLU / ReLU / LeakyReLU, the squeeze-excite gate on the input, channel-slice inputs
     and outputs, every launch plan (channel tiles per wave, K split 1 / 2 / 4) -- against ATen in float64; deterministic."""
     B, ci, co, h, w, act, with_res, with_gate = shape
     monkeypatch.setattr(ops, "PW_TILED", "0")
     if plan is not None:
-        monkeypatch.setenv("SR_PW_NT", str(plan[0]))
-        monkeypatch.setenv("SR_PW_KS", str(plan[1]))
+        sr_option("SR_PW_NT", plan[0])
+        sr_option("SR_PW_KS", plan[1])
         if plan[1] > 1 and (ci + 7) // 8 // plan[1] < 8:
             pytest.skip("K too short for this split")
     g = torch.Generator().manual_seed(ci * 5 + co)

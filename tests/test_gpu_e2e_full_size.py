@@ -161,20 +161,20 @@ def test_batch_1_at_benchmarked_shape_matches_oracle_chain(case):
 
 
 @pytest.mark.parametrize("split", ["bf16", "f16"])
-def test_batch_1_with_split_precision_mlp_sweep(case, split, monkeypatch):
+def test_batch_1_with_split_precision_mlp_sweep(case, split, monkeypatch, sr_option):
     """The fenced split-precision sweep (SR_MLP_SPLIT) through the SAME end-to-end check at the SAME
     tolerances -- including the element-wise bounds on depth_pred_s0 -- as the fp32-MFMA sweep."""
-    monkeypatch.setenv("SR_MLP_SPLIT", split)
+    sr_option("SR_MLP_SPLIT", split)
     out = case.run_hip(slice(0, 1))
     case.check(out, 0, 0, f"batch 1, frame 0, SR_MLP_SPLIT={split}")
 
 
 @pytest.mark.parametrize("split", ["bf16", "f16"])
-def test_batch_1_with_split_precision_sweep_and_convs(case, split, monkeypatch):
+def test_batch_1_with_split_precision_sweep_and_convs(case, split, monkeypatch, sr_option):
     """Both fenced split-precision kernels at once (SR_MLP_SPLIT + SR_WINO_SPLIT): every Winograd 3x3
     convolution of both encoders, the CVEncoder and the decoder multiplies 16-bit pieces.  Same check, same tolerances."""
-    monkeypatch.setenv("SR_MLP_SPLIT", split)
-    monkeypatch.setenv("SR_WINO_SPLIT", split)
+    sr_option("SR_MLP_SPLIT", split)
+    sr_option("SR_WINO_SPLIT", split)
     out = case.run_hip(slice(0, 1))
     # f16 pieces: the UNCHANGED bounds (measured p99 7.3e-6 / max 1.2e-5: at least as close to the oracle as the fp32 kernels).
     # bf16 pieces in ~45 consecutive convolutions do NOT meet the element-wise bounds (measured p99 5.3e-5 / max 9.2e-5, 7 x the

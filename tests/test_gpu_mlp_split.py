@@ -16,13 +16,13 @@ MODES = ["bf16", "f16"]
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", [n for n, c in gc.VOLUME_CASES.items() if c["model"] == "hero" and c["K"] <= 7])
-def test_split_sweep_matches_oracle_and_golden(name, mode, monkeypatch):
+def test_split_sweep_matches_oracle_and_golden(name, mode, monkeypatch, sr_option):
     case = gc.VOLUME_CASES[name]
     inp = gc.volume_inputs(case)
     gold = gc.load_golden("volume", name)
     mgr = _manager(case)
     ref = _run(mgr, inp)[0]                      # fp32-MFMA kernel
-    monkeypatch.setenv("SR_MLP_SPLIT", mode)
+    sr_option("SR_MLP_SPLIT", mode)
     vol, lowest, planes, mask = _run(mgr, inp)
     planes_np = planes.cpu().numpy() if "depth_planes_bdhw" in inp else planes[:, :, 0, 0].cpu().numpy()
     cv_o, low_o, mask_o = _oracle(mgr, inp, planes_np)
@@ -46,14 +46,14 @@ def test_split_sweep_matches_oracle_and_golden(name, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_split_sweep_cfg3_batch8(mode, monkeypatch):
+def test_split_sweep_cfg3_batch8(mode, monkeypatch, sr_option):
     """BASELINE.json configs[2] at the benchmarked batch, channels-last volume, all frames on a plane subset."""
     B = 8
     case = dict(B=B, K=7, C=16, D=64, h=120, w=160, seed=58)
     inp = synthetic.cost_volume_inputs(B, 7, 16, 120, 160, seed=case["seed"])
     mgr = _manager(case)
     mgr.volume_memory_format = torch.channels_last
-    monkeypatch.setenv("SR_MLP_SPLIT", mode)
+    sr_option("SR_MLP_SPLIT", mode)
     vol, lowest, planes, mask = _run(mgr, inp)
     planes_np = planes[:, :, 0, 0].cpu().numpy()
     sub = [0, 31, 63]
@@ -65,32 +65,32 @@ def test_split_sweep_cfg3_batch8(mode, monkeypatch):
     assert torch.equal(vol, again), "the split sweep is deterministic"
 
 
-def test_split_sweep_refuses_what_it_does_not_cover(monkeypatch):
+def test_split_sweep_refuses_what_it_does_not_cover(monkeypatch, sr_option):
     """More than 7 source views (the split weights no longer fit the LDS) and unknown modes fail loudly."""
     from simplerecon_amd._lib import HipLibraryError
     case = dict(B=1, K=9, C=16, D=5, h=12, w=20, seed=79)
     inp = synthetic.cost_volume_inputs(1, 9, 16, 12, 20, seed=79)
     mgr = _manager(case)
-    monkeypatch.setenv("SR_MLP_SPLIT", "bf16")
+    sr_option("SR_MLP_SPLIT", "bf16")
     with pytest.raises(HipLibraryError):
         _run(mgr, inp)
     case = gc.VOLUME_CASES["hero_small"]
-    monkeypatch.setenv("SR_MLP_SPLIT", "int8")
+    sr_option("SR_MLP_SPLIT", "int8")
     with pytest.raises(HipLibraryError):
         _run(_manager(case), gc.volume_inputs(case))
 
 
-def test_f16_pieces_fail_loudly_outside_fp16_range(monkeypatch):
+def test_f16_pieces_fail_loudly_outside_fp16_range(monkeypatch, sr_option):
     """Matching features beyond fp16's range: the f16 variant returns non-finite costs (never a silently saturated value);
     the bf16 variant, with fp32's exponent range, still matches the oracle."""
     case = gc.VOLUME_CASES["hero_small"]
     inp = gc.volume_inputs(case)
     inp = dict(inp, cur_feats=inp["cur_feats"] * 3e5, src_feats=inp["src_feats"] * 3e5)
     mgr = _manager(case)
-    monkeypatch.setenv("SR_MLP_SPLIT", "f16")
+    sr_option("SR_MLP_SPLIT", "f16")
     vol = _run(mgr, inp)[0]
     assert not bool(torch.isfinite(vol).all())
-    monkeypatch.setenv("SR_MLP_SPLIT", "bf16")
+    sr_option("SR_MLP_SPLIT", "bf16")
     vol, lowest, planes, mask = _run(mgr, inp)
     planes_np = planes.cpu().numpy() if "depth_planes_bdhw" in inp else planes[:, :, 0, 0].cpu().numpy()
     cv_o, _, _ = _oracle(mgr, inp, planes_np)

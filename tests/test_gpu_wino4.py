@@ -23,10 +23,11 @@ def _run(kind, x, conv, res, leaky, out=None):
     rsb, rsp = ops._strides(res) if res is not None else (0, 0)
     slope = C.c_float(ops._act_code(leaky, None))
     with _lib.on_device(x.device):
-        if kind == "w4":
+        if kind in ("w4", "w4_pp"):   # two independent 4-wave workgroups per CU (product) / the 8-wave ping-pong workgroup
             wp, bias = ops.packed_wino4_weight(conv)
-            rc = lib.sr_conv3x3_wino4_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(res), rsb, rsp,
-                                               _lib.ptr(out), osb, osp, b, h, w, ci, co, slope, _lib.stream_ptr(x.device))
+            rc = lib.sr_conv3x3_wino4_variant_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(res), rsb,
+                                                       rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, slope,
+                                                       1 if kind == "w4" else 2, _lib.stream_ptr(x.device))
         elif kind == "w2":
             wp, bias = ops.packed_wino_weight(conv)
             rc = lib.sr_conv3x3_wino_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(res), rsb, rsp,
@@ -49,7 +50,8 @@ def _ref64(x, conv, res, leaky):
 
 # (B, Cin, H, W, Cout, residual, bias): interior + border regions, ragged sizes, channel tails in Cin (not a multiple of 16)
 # and Cout (not a multiple of 64 / 16), several items per workgroup, one region smaller than a tile
-SHAPES = [(1, 16, 16, 16, 64, False, True), (2, 64, 48, 64, 64, True, True), (1, 24, 35, 53, 64, True, False),
+SHAPES = [(1, 16, 16, 16, 64, False, True), (1, 16, 16, 32, 64, True, True), (1, 16, 48, 16, 64, False, True),
+          (1, 32, 33, 17, 64, True, True), (2, 16, 16, 16, 128, True, True), (5, 48, 16, 16, 64, True, True), (2, 64, 48, 64, 64, True, True), (1, 24, 35, 53, 64, True, False),
           (1, 64, 20, 18, 24, False, True), (2, 192, 32, 48, 64, True, True), (1, 128, 50, 70, 128, True, True),
           (1, 36, 9, 7, 12, True, True), (3, 64, 240, 320, 64, True, True), (1, 112, 17, 33, 72, False, False)]
 
@@ -63,6 +65,7 @@ def test_wino4_matches_fp64_and_the_other_kernels(shape):
     res = torch.randn(b, co, h, w, device=DEV).contiguous(memory_format=torch.channels_last) if with_res else None
     with torch.inference_mode():
         y4 = _run("w4", x, conv, res, 0.2)
+        y4b = _run("w4_pp", x, conv, res, 0.2)
         y2 = _run("w2", x, conv, res, 0.2)
         yd = _run("direct", x, conv, res, 0.2)
         ref = _ref64(x, conv, res, 0.2)
@@ -74,6 +77,7 @@ def test_wino4_matches_fp64_and_the_other_kernels(shape):
     print(f"{shape}: rel-to-range error F(4x4) {e4:.2e}  F(2x2) {e2:.2e}  direct {ed:.2e}")
     assert e4 < 2e-5, f"F(4x4) error {e4} (F(2x2) {e2}, direct {ed})"
     assert torch.isfinite(y4).all()
+    assert torch.equal(y4, y4b), "the two kernel forms run the same operations in the same order"
 
 
 def test_wino4_writes_into_a_concat_slice_and_reads_from_one():
@@ -101,6 +105,27 @@ def test_wino4_is_deterministic_and_batch_independent():
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert torch.equal(a[2:3], one)   # per-pixel arithmetic does not depend on the batch
+
+
+@pytest.mark.parametrize("act", [None, 0.0, 0.2, "silu"])
+def test_wino4_activation_codes(act):
+    torch.manual_seed(8)
+    conv = torch.nn.Conv2d(32, 64, 3, padding=1).to(DEV)
+    x = torch.randn(2, 32, 40, 24, device=DEV).contiguous(memory_format=torch.channels_last)
+    lib = _lib.lib()
+    wp, bias = ops.packed_wino4_weight(conv)
+    out = ops.empty_nhwc(2, 64, 40, 24, DEV)
+    isb, isp = ops._strides(x)
+    osb, osp = ops._strides(out)
+    code = ops._act_code(None, "silu") if act == "silu" else ops._act_code(act, None)
+    with torch.inference_mode():
+        rc = lib.sr_conv3x3_wino4_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), None, 0, 0, _lib.ptr(out), osb,
+                                           osp, 2, 40, 24, 32, 64, C.c_float(code), _lib.stream_ptr(x.device))
+        _lib.check(rc, "sr_conv3x3_wino4_nhwc_fwd")
+        y = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        ref = torch.nn.functional.silu(y) if act == "silu" else y if act is None else torch.nn.functional.leaky_relu(y, act)
+    torch.cuda.synchronize()
+    assert (out.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
 
 
 def test_wino4_non_finite_inputs_do_not_leak_across_channel_padding():

@@ -45,9 +45,11 @@ def stub(monkeypatch):
                 return b"stub_kernel"
             return 4096 if res is ctypes.c_size_t else 0
 
+    real = _lib.lib()   # (the option table is host-only code: those calls go to the real library, GPU or not)
+
     class Lib:
         def __getattr__(self, name):
-            return Fn(name)
+            return getattr(real, name) if name.startswith("sr_option_") else Fn(name)
 
     from simplerecon_amd import ops
     monkeypatch.setattr(ops, "_SHAPE_QUERIES", {})   # per-shape answers of the (stubbed) library are cached per process
@@ -206,7 +208,7 @@ def test_per_shape_library_answers_are_asked_once(stub):
     assert ops._shape_query(lib, "sr_conv_prefers_wino", 2, 8, 16, 16, 32, 3, 1) == 1 and len(stub) == n + 1
 
 
-def test_split_precision_switch_repacks_the_winograd_weight(stub, monkeypatch):
+def test_split_precision_switch_repacks_the_winograd_weight(stub, monkeypatch, sr_option):
     """SR_WINO_SPLIT (the fenced split-precision Winograd variant) changes what a packed weight CONTAINS (16-bit pieces in the
     fp32 layout's buffer): the cache must re-pack when the switch changes and hit otherwise; off-values mean the fp32 path."""
     from torch import nn
@@ -216,23 +218,22 @@ def test_split_precision_switch_repacks_the_winograd_weight(stub, monkeypatch):
     monkeypatch.setattr(ops, "_packed_here", lambda *a, **k: None)
     conv = nn.Conv2d(16, 32, 3, padding=1)
     for off in ("", "0", "off", "fp32"):
-        monkeypatch.setenv("SR_WINO_SPLIT", off)
+        sr_option("SR_WINO_SPLIT", off)
         assert ops.wino_split_mode() == ""
-    monkeypatch.delenv("SR_WINO_SPLIT")
     ops.packed_wino_weight(conv)
     n = stub.count("sr_wino_pack_weights")
     ops.packed_wino_weight(conv)
     assert stub.count("sr_wino_pack_weights") == n            # cache hit
-    monkeypatch.setenv("SR_WINO_SPLIT", "f16")
+    sr_option("SR_WINO_SPLIT", "f16")
     assert ops.wino_split_mode() == "f16"
     ops.packed_wino_weight(conv)
     assert stub.count("sr_wino_pack_weights") == n + 1        # re-packed as 16-bit pieces
     ops.packed_wino_weight(conv)
     assert stub.count("sr_wino_pack_weights") == n + 1
-    monkeypatch.setenv("SR_WINO_SPLIT", "bf16")
+    sr_option("SR_WINO_SPLIT", "bf16")
     ops.packed_wino_weight(conv)
     assert stub.count("sr_wino_pack_weights") == n + 2
-    monkeypatch.setenv("SR_WINO_SPLIT", "0")
+    sr_option("SR_WINO_SPLIT", "0")
     ops.packed_wino_weight(conv)
     assert stub.count("sr_wino_pack_weights") == n + 3        # and back to fp32 fragments
 
@@ -246,16 +247,20 @@ def test_fenced_workloads_label_their_arithmetic():
         assert name in bw.WORKLOADS
 
 
-def test_split_precision_context_manager_sets_and_restores_the_switches(monkeypatch):
+def test_split_precision_context_manager_sets_and_restores_the_switches(sr_option):
+    """The context manager drives the library's option table (no os.environ mutation: ADVICE r04) and nests."""
     from simplerecon_amd import experimental, ops
-    monkeypatch.delenv("SR_MLP_SPLIT", raising=False)
-    monkeypatch.setenv("SR_WINO_SPLIT", "bf16")
+    env_before = dict(os.environ)
+    sr_option("SR_MLP_SPLIT", 0)
+    sr_option("SR_WINO_SPLIT", "bf16")
+    mlp = lambda: _lib.split_mode_name("SR_MLP_SPLIT")
     with experimental.split_precision("f16"):
-        assert os.environ["SR_MLP_SPLIT"] == "f16" and ops.wino_split_mode() == "f16"
+        assert mlp() == "f16" and ops.wino_split_mode() == "f16"
         with experimental.split_precision("bf16", convs=False):
-            assert os.environ["SR_MLP_SPLIT"] == "bf16" and ops.wino_split_mode() == "f16"
-        assert os.environ["SR_MLP_SPLIT"] == "f16"
-    assert "SR_MLP_SPLIT" not in os.environ and ops.wino_split_mode() == "bf16"
+            assert mlp() == "bf16" and ops.wino_split_mode() == "f16"
+        assert mlp() == "f16"
+    assert mlp() == "" and ops.wino_split_mode() == "bf16"
+    assert dict(os.environ) == env_before
     with pytest.raises(ValueError):
         with experimental.split_precision("int8"):
             pass
