@@ -10,7 +10,7 @@ import torch
 
 import bench_workloads as bw
 import oracle
-from simplerecon_amd import synthetic
+from simplerecon_amd import _lib, synthetic
 from simplerecon_amd.cost_volume import FeatureVolumeManager
 
 DEV = "cuda:0"

@@ -21,7 +21,7 @@ for (B, ci, H, W, co) in shapes:
     line = f"{str((B, ci, H, W, co)):26s}"
     with torch.inference_mode():
         ref = _ref64(x[:1], conv, res[:1], 0.2)
-        for kind in ("w2", "w4", "w4_pp"):
+        for kind in ("w2", "w4", "w4_ws"):
             f = lambda: _run(kind, x, conv, res, 0.2, out=out)
             for _ in range(3): f()
             torch.cuda.synchronize()

@@ -192,6 +192,9 @@ SPLIT_MODES = {"": 0, "0": 0, "off": 0, "fp32": 0, "bf16": 1, "f16": 2, "fp16": 
 _SPLIT_NAMES = {0: "", 1: "bf16", 2: "f16"}
 
 
+OPTION_LISTENERS = []   # callables (name, value) run after every set_option: caches of plan queries hang themselves in here
+
+
 def _option_id(name):
     oid = lib().sr_option_id(name.encode())
     if oid < 0:
@@ -212,6 +215,8 @@ def set_option(name, value):
         value = SPLIT_MODES.get(value, -1)
     prev = C.c_int(0)
     check(lib().sr_option_set(_option_id(name), int(value), C.byref(prev)), "sr_option_set")
+    for fn in OPTION_LISTENERS:
+        fn(name, int(value))
     return prev.value
 
 

@@ -136,17 +136,28 @@ def grad_wanted(*tensors_or_modules):
     return False
 
 
+# Every registration of a submodule anywhere in the process (add_module / attribute assignment: SyncBatchNorm conversion,
+# BatchNorm fusion, a swapped block) bumps this counter through torch's global registration hook; cached layer lists carry the
+# value they were gathered under.
+_TREE_EPOCH = [0]
+
+
+def _bump_tree_epoch(module, name, submodule):
+    _TREE_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_module_registration_hook(_bump_tree_epoch)
+
+
 def any_batchnorm_training(module):
-    """True if a BatchNorm2d layer of `module` is in training mode (batch statistics cannot be folded into the conv
-    weights).  The layer list is gathered once per module object -- walking `modules()` costs ~1 ms per forward on the
-    EfficientNetV2-S pyramid."""
+    """True if a batch-norm layer of `module` (BatchNorm2d, SyncBatchNorm, ... -- any `_BatchNorm`) is in training mode (batch
+    statistics cannot be folded into the conv weights).  The layer list is gathered once per module TREE: walking `modules()`
+    costs ~1 ms per forward on the EfficientNetV2-S pyramid, so the list is cached together with the process-wide submodule
+    registration count it was gathered under -- replacing a layer anywhere (also deep in the tree, which r04's key of
+    (training, number of direct children) missed) invalidates it.  The layers' own `training` flags are read on every call."""
     rec = module.__dict__.get("_sr_bn_layers")
-    # the cached list is valid for one module tree and one train / eval state: a flip of module.training (model.train() /
-    # .eval() walk the CURRENT tree) or a different number of registered submodules rebuilds it, so layers swapped in
-    # later (SyncBatchNorm conversion, BatchNorm fusion) are seen
-    key = (module.training, len(module._modules))
-    if rec is None or rec[0] != key:
-        rec = (key, [m for m in module.modules() if isinstance(m, nn.BatchNorm2d)])
+    if rec is None or rec[0] != _TREE_EPOCH[0]:
+        rec = (_TREE_EPOCH[0], [m for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)])
         module.__dict__["_sr_bn_layers"] = rec
     for m in rec[1]:
         if m.training:

@@ -823,8 +823,11 @@ static int sr_wino_run(const float* in, int64_t in_batch_stride, int in_pix_stri
   if (split < 0) return SR_ERR_INVALID_ARGUMENT;
   if (split && (io || !vout)) return SR_ERR_UNSUPPORTED;   // split precision: fp32 tensors, the vector instantiation only
   const int64_t lim = (int64_t)1 << 31;          // per-image byte offsets are 32-bit (buffer addressing)
-  if (vout && (((int64_t)(H * W - 1) * in_pix_stride + Cin) * 4 >= lim || ((int64_t)(H * W - 1) * out_pix_stride + Cout) * 4 >= lim ||
-               (residual && ((int64_t)(H * W - 1) * res_pix_stride + Cout) * 4 >= lim)))
+  // (the input-side limit applies to the vector STAGING too -- sr_wino_kernel<NT, true, false> --, not only to the vector
+  // epilogue: its buffer descriptors carry 32-bit byte offsets just the same.  Callers fall back to sr_conv2d_nhwc_fwd.)
+  if (p.vec4 && ((int64_t)((int64_t)H * W - 1) * in_pix_stride + Cin) * 4 >= lim) return SR_ERR_UNSUPPORTED;
+  if (vout && (((int64_t)((int64_t)H * W - 1) * out_pix_stride + Cout) * 4 >= lim ||
+               (residual && ((int64_t)((int64_t)H * W - 1) * res_pix_stride + Cout) * 4 >= lim)))
     return SR_ERR_UNSUPPORTED;
   const bool can_split = !io && vout && workspace && (((uintptr_t)workspace & 15) == 0);   // (partials are fp32: fp32 I/O only)
   SrWinoPlan plan = sr_wino_plan(B, H, W, Cin, Cout, can_split);

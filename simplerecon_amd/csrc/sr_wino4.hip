@@ -502,6 +502,122 @@ __global__ __launch_bounds__(512, 2) void sr_wino4pp_kernel(SrWino4Params p) {
   for (; bars < bars_all; ++bars) __syncthreads();   // (the other group is still working)
 }
 
+// ---- the wave-specialised form (variant 3): ONE 8-wave workgroup per CU; waves 0-3 only stream MFMAs (and run the epilogue),
+// waves 4-7 only stage and transform.  scripts/micro/mfma_overlap.hip (profiles/r02_mfma_valu_overlap.txt): a wave that issues
+// nothing but MFMAs keeps its full rate next to a VALU wave on the same SIMD (64.3 vs 64.5 clk per 32x32x2 MFMA) while the
+// VALU wave still issues every 13 clk; the same VALU instructions INSIDE the MFMA wave cost 5-6.5 clk of matrix-pipe time each.
+// So the roles are split by wave: per TICK (one workgroup barrier) the transform waves produce V[k & 1] of slab k -- raw[k & 1]
+// -> registers -> V, then the patch of slab k + 1 -> raw[(k + 1) & 1] and the loads of slab k + 2 -- while the MFMA waves
+// consume V[(k - 1) & 1]; the slab sequence runs across work items without a bubble, the item's epilogue rides behind the MFMAs
+// of its last slab.  raw and V are double-buffered (125.6 KB of LDS), so one barrier per tick orders everything.
+// The transform here is the single-pass form (36 temporaries: these waves hold no accumulators).
+__device__ __forceinline__ void w4_transform36(const float* t_rd, float* t_wr) {
+  if (SR_W4_ABL & 1) return;
+  float t[6][6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float d[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) d[r] = t_rd[(r * W4_PS + c) * W4_RS];
+    w4_bt(d[0], d[1], d[2], d[3], d[4], d[5], t[0][c], t[1][c], t[2][c], t[3][c], t[4][c], t[5][c]);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float v[6];
+    w4_bt(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) t_wr[(i * 6 + j) * 256] = v[j];
+  }
+}
+
+constexpr int W4_WS_RAW2 = 2 * W4_RAW_FLOATS;                       // V buffers start behind the two raw buffers
+constexpr int W4_WS_LDS_BYTES = (2 * W4_RAW_FLOATS + 2 * W4_V_FLOATS) * 4;   // 125 568
+
+__global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int role_t = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // 0: MFMA waves, 1: transform waves
+  const int tid = threadIdx.x & 255;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // this workgroup's items: blockIdx.x, + gridDim.x, ...; K = n S slabs in a row
+  const int n_items = ((int)p.total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int K = n_items * p.S;
+
+  if (role_t) {
+    // ================= transform waves
+    const int t_ci = tid & 15, t_tile = tid >> 4;
+    const int t_sig = (0x1230 >> (t_tile & 12)) & 3;
+    const int t_rd_off = ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3)) * W4_RS + t_ci;
+    const int t_wr_off = W4_WS_RAW2 + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
+    const int st_q = tid & 3, st_pp0 = tid >> 2;
+    const int st_wr_off = st_pp0 * W4_RS + 4 * st_q;
+    w4_f4 st[W4_STAGE];
+    // load cursor: the patch that st[] is loaded with next
+    int ld_work = blockIdx.x, ld_s = 0;
+    W4Item ld_it = w4_decode(p, ld_work);
+    auto advance = [&]() {
+      if (++ld_s == p.S) { ld_s = 0; ld_work += (int)gridDim.x; if (ld_work < p.total) ld_it = w4_decode(p, ld_work); }
+    };
+    // prologue: patch 0 -> raw[0]; patch 1 in flight
+    if (!(SR_W4_ABL & 16)) {
+      w4_stage(p, ld_it, ld_s, st_q, st_pp0, st);
+      advance();
+#pragma unroll
+      for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(lds + st_wr_off + j * 64 * W4_RS) = st[j];
+      if (tid < 16) *reinterpret_cast<w4_f4*>(lds + st_wr_off + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
+      if (K > 1) { w4_stage(p, ld_it, ld_s, st_q, st_pp0, st); advance(); }
+    }
+    __syncthreads();
+    for (int k = 0; k <= K; ++k) {
+      if (k < K) {
+        const int par = k & 1;
+        w4_transform36(lds + par * W4_RAW_FLOATS + t_rd_off, lds + par * W4_V_FLOATS + t_wr_off);
+        if (!(SR_W4_ABL & 16) && k + 1 < K) {
+          float* wr = lds + (par ^ 1) * W4_RAW_FLOATS + st_wr_off;
+#pragma unroll
+          for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(wr + j * 64 * W4_RS) = st[j];
+          if (tid < 16) *reinterpret_cast<w4_f4*>(wr + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
+          if (k + 2 < K) { w4_stage(p, ld_it, ld_s, st_q, st_pp0, st); advance(); }
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // ================= MFMA waves
+    const int m_j = lane & 15, m_kq = lane >> 4;
+    const int m_sig = (0x1230 >> (m_j & 12)) & 3;
+    const int m_rd_off = W4_WS_RAW2 + m_j * 16 + 4 * (m_kq ^ m_sig);
+    const unsigned u_voff = (unsigned)(m_kq * p.Co_pad + 16 * wave + m_j) * 16u;
+    const unsigned u_fstride = (SR_W4_ABL & 8) ? 0u : (unsigned)p.S * 4u * (unsigned)p.Co_pad * 16u;
+    const unsigned u_sstride = (SR_W4_ABL & 8) ? 0u : 4u * (unsigned)p.Co_pad * 16u;
+    const __amdgpu_buffer_rsrc_t rs_u = w4_rsrc(p.wu, (int64_t)36 * p.S * 4 * p.Co_pad * 16);
+    w4_f4 acc[36];
+#pragma unroll
+    for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    w4_f4 ua[W4_NA][2];
+    int work = blockIdx.x, s = 0;
+    W4Item it = w4_decode(p, work);
+    __syncthreads();
+    for (int k = 0; k <= K; ++k) {
+      if (k >= 1) {
+        const unsigned u_item = (SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u;
+        w4_mfma_tick(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, lds + ((k - 1) & 1) * W4_V_FLOATS + m_rd_off, ua, acc,
+                     lane);
+        if (++s == p.S) {
+          w4_finish(p, it, acc, wave, m_kq, m_j, tid);
+#pragma unroll
+          for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+          s = 0;
+          work += (int)gridDim.x;
+          if (work < p.total) it = w4_decode(p, work);
+        }
+      }
+      if (k < K) w4_u_prefetch(rs_u, u_voff, ((SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u) + (unsigned)s * u_sstride, u_fstride, ua);
+      __syncthreads();
+    }
+  }
+}
+
 // U = G g G^T per (co, ci) for the points (0, 1/2, -1/2, 2, -2, inf), in double, rounded once; stored in MFMA A-fragment
 // order: element (f, s, kq, co, e) = U_f[co][16 s + 4 kq + e], f = 6 i + j (i vertical, j horizontal frequency).
 __global__ void sr_wino4_pack_kernel(const float* __restrict__ w, float* __restrict__ wu, int Co, int Ci, int S, int Co_pad) {
@@ -607,6 +723,14 @@ static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, c
   if (total >= lim) return SR_ERR_UNSUPPORTED;
   p.total = (int)total;
   p.slope = leaky_slope;
+  if (variant == 3) {   // wave-specialised: 4 MFMA waves + 4 transform waves, one workgroup per CU
+    int blocks = w4_num_cus();
+    if (blocks > p.total) blocks = p.total;
+    hipError_t e = hipFuncSetAttribute((const void*)sr_wino4ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_WS_LDS_BYTES);
+    if (e != hipSuccess) return sr_hip_rc(e);
+    hipLaunchKernelGGL(sr_wino4ws_kernel, dim3(blocks), dim3(512), W4_WS_LDS_BYTES, (hipStream_t)stream_, p);
+    return sr_hip_rc(hipGetLastError());
+  }
   if (variant != 2) {   // two independent 4-wave workgroups per CU
     int blocks = 2 * w4_num_cus();
     if (blocks > p.total) blocks = p.total;
@@ -671,7 +795,7 @@ extern "C" int sr_conv3x3_wino4_variant_nhwc_fwd(const float* in, int64_t in_bat
                                                  int64_t res_batch_stride, int res_pix_stride, float* out,
                                                  int64_t out_batch_stride, int out_pix_stride, int B, int H, int W, int Cin,
                                                  int Cout, float leaky_slope, int variant, void* stream_) {
-  if (variant < 0 || variant > 2) return SR_ERR_INVALID_ARGUMENT;
+  if (variant < 0 || variant > 3) return SR_ERR_INVALID_ARGUMENT;
   return w4_run(in, in_batch_stride, in_pix_stride, packed_u, bias, residual, res_batch_stride, res_pix_stride, out,
                 out_batch_stride, out_pix_stride, B, H, W, Cin, Cout, leaky_slope, variant, stream_);
 }

@@ -317,6 +317,14 @@ def packed_wino4_weight(conv: nn.Conv2d, bn=None):
 _SHAPE_QUERIES = {}
 
 
+def _drop_shape_queries(*_):
+    _SHAPE_QUERIES.clear()
+
+
+# launch plans depend on the forcing switches (SR_PT_*, SR_PW_*, SR_CONV_WINO ...): any option change drops the cached answers
+_lib.OPTION_LISTENERS.append(_drop_shape_queries)
+
+
 def _shape_query(lib, name, *shape):
     key = (name, shape)
     v = _SHAPE_QUERIES.get(key)
@@ -331,8 +339,11 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
     eval-mode BatchNorm2d folded into weight and bias.  `leaky` = LeakyReLU slope, or act="silu".  tf_same=True
     replaces the module's symmetric padding by TensorFlow-"SAME" padding (tf_same_pads).  library_gemm=True lets a 1x1
     conv over a dense map run as a hipBLASLt GEMM (faster on the MBConv shapes; its algorithm choice depends on the number
-    of pixels, so results are no longer bitwise independent of the batch size -- callers that promise that keep the
-    default; only with SR_CONV1X1_GEMM=lib since r04).  `gate` ([B, Cin], 1x1 / stride-1 convs only): the input is scaled
+    of pixels; only with SR_CONV1X1_GEMM=lib since r04).  Batch-size invariance: every kernel on the default path is run-to-run
+    deterministic; 3x3 results are also bitwise independent of the batch size UNLESS the launch plan splits K (the split-K
+    factor of the Winograd / direct / pointwise plans is chosen from the total number of work items, B included) -- a 1x1 /
+    stride-1 convolution with Cin >= 128 on a few pixel tiles may give B = 1 and B = 8 different low-order bits
+    (tests/test_gpu_determinism.py pins both statements).  `gate` ([B, Cin], 1x1 / stride-1 convs only): the input is scaled
     per image and input channel while it is loaded (the squeeze-excite gate of an MBConv block).  Returns a channels-last view."""
     _lib.refuse_autograd(x, conv.weight)
     x = as_nhwc(x, "conv input")
@@ -404,10 +415,17 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 ev1.record()
                 a_, b_ = C.c_int(0), C.c_int(0)
                 if tiled:
-                    lib.sr_pw_conv_tiled_plan(m, ci, co, int(ws is not None), C.byref(a_), C.byref(b_))
-                    bm, bn = ((64, 128), (128, 160), (128, 64), (64, 64))[a_.value]
-                    executed = 2.0 * (-(-m // bm) * bm) * (-(-co // bn) * bn) * (-(-ci // 32) * 32)
-                    name = f"sr_pw_tiled_kernel<{bm}x{bn}, ks {b_.value}, {gflag}>"
+                    # the plan the LAUNCHER took: it splits K only with a usable workspace AND 16-byte aligned out / residual /
+                    # bias rows (sr_pw_conv_tiled_nhwc_fwd's `can_split`), so ask with the same answer
+                    al16 = lambda t, sp_: t is None or (t.data_ptr() % 16 == 0 and sp_ % 4 == 0)
+                    can_split = ws is not None and ws.data_ptr() % 16 == 0 and co % 4 == 0 and al16(out, osp) and \
+                        al16(residual, rsp) and (bias is None or bias.data_ptr() % 16 == 0)
+                    lib.sr_pw_conv_tiled_plan(m, ci, co, int(can_split), C.byref(a_), C.byref(b_))
+                    if b_.value > 1 and nbytes < b_.value * m * co * 4:
+                        lib.sr_pw_conv_tiled_plan(m, ci, co, 0, C.byref(a_), C.byref(b_))
+                    tile_m, tile_n = ((64, 128), (128, 160), (128, 64), (64, 64))[a_.value]
+                    executed = 2.0 * (-(-m // tile_m) * tile_m) * (-(-co // tile_n) * tile_n) * (-(-ci // 32) * 32)
+                    name = f"sr_pw_tiled_kernel<{tile_m}x{tile_n}, ks {b_.value}, {gflag}>"
                 else:
                     lib.sr_pw_conv_plan(b, h * w, ci, co, C.byref(a_), C.byref(b_))
                     mt = b * ((h * w + 31) // 32)
@@ -415,8 +433,11 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                     name = f"sr_pw_kernel<{a_.value}, {b_.value}, {gflag}>"
                 prof.append((name, 2.0 * b * h * w * co * ci, ev0, ev1, (b, ci, h, w, co, k, s, ho, wo, residual is not None),
                              executed))
-        _lib.check(rc, "sr_pw_conv_tiled_nhwc_fwd" if tiled else "sr_pw_conv_nhwc_fwd")
-        return out
+        if rc != 2 or gate is not None:   # SR_ERR_UNSUPPORTED (a per-image byte range past 2^31): the implicit-GEMM kernel below,
+            _lib.check(rc, "sr_pw_conv_tiled_nhwc_fwd" if tiled else "sr_pw_conv_nhwc_fwd")   # whose addressing is 64-bit
+            return out
+        if prof is not None:
+            prof.pop()
     if gate is not None:
         raise _lib.HipLibraryError("a gated 1x1 convolution needs Cin % 4 == 0 and 16-byte aligned input rows")
     if k == 1 and s == 1 and (w % 32 != 0 or h % 4 != 0) and (isp, isb) == (ci, h * w * ci) \
@@ -523,6 +544,17 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 executed = 2.0 * b * regions * 32 * 16 * ((ci + 15) // 16 * 16) * ((co + 31) // 32 * 32)
             prof.append((name, 2.0 * b * ho * wo * co * ci * k * k, ev0, ev1,
                          (b, ci, h, w, co, k, s, ho, wo, residual is not None), executed))
+    if use_wino and rc == 2 and not wino_split_mode():
+        # SR_ERR_UNSUPPORTED from the Winograd entry point (a per-image byte range past 2^31: its buffer descriptors carry 32-bit
+        # offsets): the implicit-GEMM kernel serves the shape with 64-bit addressing, as it did before r04
+        if prof is not None:
+            prof.pop()
+        wp, bias = packed_weight(conv, bn)
+        with _lib.on_device(x.device):
+            rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb, rsp,
+                                        _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope, _lib.stream_ptr(x.device))
+        _lib.check(rc, "sr_conv2d_nhwc_fwd")
+        return out
     _lib.check(rc, "sr_conv3x3_wino_nhwc_fwd" if use_wino else "sr_conv2d_nhwc_fwd")
     return out
 

@@ -23,11 +23,11 @@ def _run(kind, x, conv, res, leaky, out=None):
     rsb, rsp = ops._strides(res) if res is not None else (0, 0)
     slope = C.c_float(ops._act_code(leaky, None))
     with _lib.on_device(x.device):
-        if kind in ("w4", "w4_pp"):   # two independent 4-wave workgroups per CU (product) / the 8-wave ping-pong workgroup
+        if kind in ("w4", "w4_pp", "w4_ws"):   # two 4-wave workgroups per CU / 8-wave ping-pong / wave-specialised 8-wave
             wp, bias = ops.packed_wino4_weight(conv)
             rc = lib.sr_conv3x3_wino4_variant_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(res), rsb,
                                                        rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, slope,
-                                                       1 if kind == "w4" else 2, _lib.stream_ptr(x.device))
+                                                       {"w4": 1, "w4_pp": 2, "w4_ws": 3}[kind], _lib.stream_ptr(x.device))
         elif kind == "w2":
             wp, bias = ops.packed_wino_weight(conv)
             rc = lib.sr_conv3x3_wino_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(res), rsb, rsp,
@@ -66,6 +66,7 @@ def test_wino4_matches_fp64_and_the_other_kernels(shape):
     with torch.inference_mode():
         y4 = _run("w4", x, conv, res, 0.2)
         y4b = _run("w4_pp", x, conv, res, 0.2)
+        y4c = _run("w4_ws", x, conv, res, 0.2)
         y2 = _run("w2", x, conv, res, 0.2)
         yd = _run("direct", x, conv, res, 0.2)
         ref = _ref64(x, conv, res, 0.2)
@@ -77,7 +78,7 @@ def test_wino4_matches_fp64_and_the_other_kernels(shape):
     print(f"{shape}: rel-to-range error F(4x4) {e4:.2e}  F(2x2) {e2:.2e}  direct {ed:.2e}")
     assert e4 < 2e-5, f"F(4x4) error {e4} (F(2x2) {e2}, direct {ed})"
     assert torch.isfinite(y4).all()
-    assert torch.equal(y4, y4b), "the two kernel forms run the same operations in the same order"
+    assert torch.equal(y4, y4b) and torch.equal(y4, y4c), "the kernel forms run the same operations in the same order"
 
 
 def test_wino4_writes_into_a_concat_slice_and_reads_from_one():

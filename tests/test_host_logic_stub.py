@@ -264,3 +264,22 @@ def test_split_precision_context_manager_sets_and_restores_the_switches(sr_optio
     with pytest.raises(ValueError):
         with experimental.split_precision("int8"):
             pass
+
+
+def test_batchnorm_layer_cache_sees_replacements_deep_in_the_tree():
+    """the cached list of batch-norm layers behind `any_batchnorm_training` must be rebuilt when a layer is
+    swapped ANYWHERE in the tree (SyncBatchNorm conversion, fusion), and must recognise every `_BatchNorm` flavour."""
+    from torch import nn
+    from simplerecon_amd import autograd_ops as A
+    m = nn.Sequential(nn.Sequential(nn.Conv2d(3, 3, 1), nn.BatchNorm2d(3)), nn.ReLU()).eval()
+    assert not A.any_batchnorm_training(m)
+    m[0][1] = nn.BatchNorm2d(3)                      # a fresh layer (training mode) two levels down
+    assert A.any_batchnorm_training(m)
+    m.eval()
+    assert not A.any_batchnorm_training(m)
+    m[0][1] = nn.SyncBatchNorm(3)                    # not an nn.BatchNorm2d, still batch statistics
+    assert A.any_batchnorm_training(m)
+    m[0][1].eval()
+    assert not A.any_batchnorm_training(m)
+    m[0][1].train()                                  # a flag flipped on the leaf only
+    assert A.any_batchnorm_training(m)
