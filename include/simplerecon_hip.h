@@ -341,9 +341,10 @@ int sr_conv3x3_wino_nhwc_fwd(const float* in, int64_t in_batch_stride, int in_pi
  * transforms, fp32 products and accumulation; fp32 error ~1.3e-6 of the output range on a 64-channel layer (F(2x2): 3e-7).
  * `packed_u` comes from sr_wino4_pack_weights (U = G g G^T, computed in double, in MFMA A-fragment order).  Needs channel
  * counts in whole quads and 16-byte aligned rows (SR_ERR_UNSUPPORTED otherwise: use sr_conv3x3_wino_nhwc_fwd).
- * sr_conv_prefers_wino4(): 1 when this kernel is expected to beat F(2x2) for the shape (16x16-pixel regions with little
- * padding, whole 64-channel output blocks, several rounds of work items); `mode` 0 = never, 1 = that rule, 2 = wherever it
- * applies.  The mode is an ARGUMENT (the Python host reads SR_CONV_WINO4 once at import): no environment reads in here. */
+ * sr_conv_prefers_wino4(): which kernel FORM is expected to beat F(2x2) for the shape -- 0 none, 1 two 4-wave workgroups per
+ * CU, 3 one wave-specialised 8-wave workgroup per CU (pass it as `variant` of sr_conv3x3_wino4_variant_nhwc_fwd); `mode`
+ * 0 = never, 1 = the rule fitted on profiles/r05_wino4_shape_sweep.txt, 2 = form 1 wherever the kernel applies.  The mode
+ * is an ARGUMENT (the Python host reads SR_CONV_WINO4 once at import): no environment reads in here. */
 size_t sr_wino4_packed_weight_floats(int Cout, int Cin);
 int sr_wino4_pack_weights(const float* weight, int Cout, int Cin, float* packed, void* stream);
 int sr_conv_prefers_wino4(int B, int H, int W, int Cin, int Cout, int mode);

@@ -43,7 +43,17 @@ constexpr int W4_STAGE = 6;                              // float4 loads per thr
 #define SR_W4_NA 3
 #define SR_W4_PD 2
 #endif
-constexpr int W4_NA = SR_W4_NA, W4_PD = SR_W4_PD;                      // weight-fragment register sets / prefetch distance (frequency pairs)
+constexpr int W4_NA = SR_W4_NA, W4_PD = SR_W4_PD;
+// Issue priority (s_setprio) of the non-MFMA phases.  scripts/micro/mfma16_overlap.hip: next to a wave that streams
+// v_mfma_f32_16x16x4_f32 back to back, a second wave on the same SIMD gets ONE instruction issued per MFMA (37.6 clk per
+// v_fma_f32 -- or per v_pk_fma_f32 -- instead of 5.7) at equal priority: the arbiter serves the MFMA wave first although its
+// next MFMA cannot start before the matrix pipe is free.  With the transform / staging / epilogue code at a higher priority
+// those instructions issue when they are ready and the MFMAs take the slots in between (one per 32 clocks is all they need).
+#ifndef SR_W4_PRIO
+#define SR_W4_PRIO 2
+#endif
+__device__ __forceinline__ void w4_prio_other() { if (SR_W4_PRIO) __builtin_amdgcn_s_setprio(SR_W4_PRIO); }
+__device__ __forceinline__ void w4_prio_mfma() { if (SR_W4_PRIO) __builtin_amdgcn_s_setprio(0); }                      // weight-fragment register sets / prefetch distance (frequency pairs)
 
 // Phase ablations (timing experiments only, results are wrong): -DSR_W4_ABL=<bits>  1: no transform, 2: no MFMA phase,
 // 4: no epilogue, 8: every weight fragment from one cached address, 16: no staging loads / stores, 32: no operand loads in
@@ -270,6 +280,7 @@ __device__ __forceinline__ void w4_u_prefetch(__amdgpu_buffer_rsrc_t rs_u, unsig
 __device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsigned u_voff, unsigned u_slab, unsigned u_fstride,
                                              const float* m_rd, w4_f4 (&ua)[W4_NA][2], w4_f4 (&acc)[36], int lane) {
   if (SR_W4_ABL & 2) return;
+  w4_prio_mfma();
   w4_f4 vb[2][2];
   if (SR_W4_ABL & 32) {
 #pragma unroll
@@ -296,6 +307,7 @@ __device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsign
       __builtin_amdgcn_sched_barrier(0);   // keep the two accumulators interleaved (left alone hipcc issues 4 dependent MFMAs in a row)
     }
   }
+  w4_prio_other();
 }
 
 __device__ __forceinline__ void w4_finish(const SrWino4Params& p, const W4Item& it, w4_f4 (&acc)[36], int wave, int m_kq,
@@ -322,6 +334,7 @@ __device__ __forceinline__ void w4_finish(const SrWino4Params& p, const W4Item& 
 // Kept as `variant` 1 for A/B measurements; same operations in the same order as the ping-pong kernel below.
 __global__ __launch_bounds__(256, 2) void sr_wino4_kernel(SrWino4Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  w4_prio_other();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void sr_wino4_kernel(SrWino4Params p) {
 // whoever finishes first pads.
 __global__ __launch_bounds__(512, 2) void sr_wino4pp_kernel(SrWino4Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  w4_prio_other();
   const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   float* lds = lds_all + grp * (W4_RAW_FLOATS + W4_V_FLOATS);
   const int tid = threadIdx.x & 255;
@@ -502,15 +516,24 @@ __global__ __launch_bounds__(512, 2) void sr_wino4pp_kernel(SrWino4Params p) {
   for (; bars < bars_all; ++bars) __syncthreads();   // (the other group is still working)
 }
 
-// ---- the wave-specialised form (variant 3): ONE 8-wave workgroup per CU; waves 0-3 only stream MFMAs (and run the epilogue),
-// waves 4-7 only stage and transform.  scripts/micro/mfma_overlap.hip (profiles/r02_mfma_valu_overlap.txt): a wave that issues
-// nothing but MFMAs keeps its full rate next to a VALU wave on the same SIMD (64.3 vs 64.5 clk per 32x32x2 MFMA) while the
-// VALU wave still issues every 13 clk; the same VALU instructions INSIDE the MFMA wave cost 5-6.5 clk of matrix-pipe time each.
-// So the roles are split by wave: per TICK (one workgroup barrier) the transform waves produce V[k & 1] of slab k -- raw[k & 1]
-// -> registers -> V, then the patch of slab k + 1 -> raw[(k + 1) & 1] and the loads of slab k + 2 -- while the MFMA waves
-// consume V[(k - 1) & 1]; the slab sequence runs across work items without a bubble, the item's epilogue rides behind the MFMAs
-// of its last slab.  raw and V are double-buffered (125.6 KB of LDS), so one barrier per tick orders everything.
-// The transform here is the single-pass form (36 temporaries: these waves hold no accumulators).
+// ---- the wave-specialised form (variant 3): ONE 8-wave workgroup per CU; waves 0-3 ("M") stream the MFMAs and move the input
+// patches (loads + LDS stores: a handful of instructions per slab), waves 4-7 ("T") transform the patches and own the output
+// side of every work item: residual prefetch, bias + residual + activation, stores.
+// Why: scripts/micro/mfma_overlap.hip (profiles/r02_mfma_valu_overlap.txt): a wave that issues nothing but MFMAs keeps its
+// full rate next to a VALU wave on the same SIMD (64.3 vs 64.5 clk per 32x32x2 MFMA) while the VALU wave still issues every
+// 13 clk; the same VALU instructions INSIDE the MFMA wave cost 5-6.5 clk of matrix-pipe time each.  And the r05 ablations /
+// s_memtime traces of the other two forms: an item's epilogue costs 16-20 k clocks -- its 16 residual loads per lane are
+// latency-bound (4 KB in flight per wave), its stores write half cache lines -- during which that workgroup issues no MFMA.
+// Per TICK (one workgroup barrier), k = 0 .. K over the slabs of all the workgroup's items in a row:
+//   T waves: V[k & 1] = B^T d B of raw[k & 1]                                   (slab k)
+//   M waves: MFMAs of slab k - 1 on V[(k - 1) & 1]; then patch k + 1 (in registers since tick k - 1) -> raw[(k + 1) & 1] and
+//            the loads of patch k + 2.
+// raw and V are double-buffered (125.6 KB of LDS): one barrier per tick orders everything.  When slab k - 1 closes an item,
+// the M waves run the output transform in place and hand the 16 x 16 x 64 output tile to the T waves in two halves THROUGH
+// the V buffer they just finished reading (free until T(k + 1)): M writes rows 0-1 of every 4 x 4 tile, barrier, T reads
+// them (a thread takes float4s of whole 256-byte pixel records: its stores are full cache lines), barrier, M writes rows 2-3,
+// barrier, T reads, barrier -- three extra barriers per item; the T waves add bias and the residual they prefetched a tick
+// earlier (16 float4 in registers these waves have to spare), apply the activation and store.
 __device__ __forceinline__ void w4_transform36(const float* t_rd, float* t_wr) {
   if (SR_W4_ABL & 1) return;
   float t[6][6];
@@ -533,57 +556,121 @@ __device__ __forceinline__ void w4_transform36(const float* t_rd, float* t_wr) {
 constexpr int W4_WS_RAW2 = 2 * W4_RAW_FLOATS;                       // V buffers start behind the two raw buffers
 constexpr int W4_WS_LDS_BYTES = (2 * W4_RAW_FLOATS + 2 * W4_V_FLOATS) * 4;   // 125 568
 
+// patch loads of the MFMA waves: interior regions take the precomputed lane offsets (no address arithmetic per slab)
+__device__ __forceinline__ void w4_stage_m(const SrWino4Params& p, const W4Item& it, int s, int st_q, int st_pp0,
+                                           const unsigned (&st_off)[W4_STAGE], w4_f4 (&st)[W4_STAGE]) {
+  const bool interior = (it.oy0 >= 1) & (it.ox0 >= 1) & (it.oy0 + 17 <= p.H) & (it.ox0 + 17 <= p.W);   // uniform
+  if (!interior) { w4_stage(p, it, s, st_q, st_pp0, st); return; }
+  const unsigned in_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.in_sp + p.Cin) * 4);
+  const __amdgpu_buffer_rsrc_t rs_in = w4_rsrc(p.in + (int64_t)it.b * p.in_sb, in_img_bytes);
+  const unsigned base = (unsigned)(((it.oy0 - 1) * p.W + (it.ox0 - 1)) * p.in_sp + 16 * s) * 4u;   // scalar offset operand
+  if (16 * s + 16 <= p.Cin) {   // (uniform) every channel quad of the slab exists
+#pragma unroll
+    for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load(rs_in, st_off[j], base);
+  } else {
+    const bool chan_ok = 16 * s + 4 * st_q + 4 <= p.Cin;
+#pragma unroll
+    for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load(rs_in, chan_ok ? st_off[j] : W4_OOB, base);
+  }
+}
+
 __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int role_t = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // 0: MFMA waves, 1: transform waves
+  w4_prio_other();
+  const int role_t = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // 0: MFMA waves, 1: transform / output waves
   const int tid = threadIdx.x & 255;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // this workgroup's items: blockIdx.x, + gridDim.x, ...; K = n S slabs in a row
+  // this workgroup's items: blockIdx.x, + gridDim.x, ...; K = n S slabs in a row; slab k - 1 closes an item iff k % S == 0
   const int n_items = ((int)p.total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int K = n_items * p.S;
+#ifdef SR_W4_TRACE
+  int tr_n = 0;
+  const int grp = role_t;
+#endif
 
   if (role_t) {
-    // ================= transform waves
+    // ================= T waves: transform + output side
     const int t_ci = tid & 15, t_tile = tid >> 4;
     const int t_sig = (0x1230 >> (t_tile & 12)) & 3;
     const int t_rd_off = ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3)) * W4_RS + t_ci;
     const int t_wr_off = W4_WS_RAW2 + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
-    const int st_q = tid & 3, st_pp0 = tid >> 2;
-    const int st_wr_off = st_pp0 * W4_RS + 4 * st_q;
-    w4_f4 st[W4_STAGE];
-    // load cursor: the patch that st[] is loaded with next
-    int ld_work = blockIdx.x, ld_s = 0;
-    W4Item ld_it = w4_decode(p, ld_work);
-    auto advance = [&]() {
-      if (++ld_s == p.S) { ld_s = 0; ld_work += (int)gridDim.x; if (ld_work < p.total) ld_it = w4_decode(p, ld_work); }
-    };
-    // prologue: patch 0 -> raw[0]; patch 1 in flight
-    if (!(SR_W4_ABL & 16)) {
-      w4_stage(p, ld_it, ld_s, st_q, st_pp0, st);
-      advance();
-#pragma unroll
-      for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(lds + st_wr_off + j * 64 * W4_RS) = st[j];
-      if (tid < 16) *reinterpret_cast<w4_f4*>(lds + st_wr_off + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
-      if (K > 1) { w4_stage(p, ld_it, ld_s, st_q, st_pp0, st); advance(); }
-    }
-    __syncthreads();
+    // output role: channel quad c of the pixels pxl = (tid >> 4) + 16 i, i = 0 .. 7, of a half tile (16 tiles x 2 x 4 pixels)
+    const int o_c = tid & 15;
+    const float slope = sr_uniform(p.slope);
+    int ep_work = blockIdx.x;   // the item whose epilogue comes next
+    w4_f4 rv[2][8];
+    __syncthreads();   // (the M waves' first patch is in raw[0])
     for (int k = 0; k <= K; ++k) {
-      if (k < K) {
-        const int par = k & 1;
-        w4_transform36(lds + par * W4_RAW_FLOATS + t_rd_off, lds + par * W4_V_FLOATS + t_wr_off);
-        if (!(SR_W4_ABL & 16) && k + 1 < K) {
-          float* wr = lds + (par ^ 1) * W4_RAW_FLOATS + st_wr_off;
+      const bool closes = k >= 1 && (k % p.S) == 0;   // (uniform) slab k - 1 is the last of its item
+      W4Item eit = w4_decode(p, ep_work);
+      const int cq = eit.co0 + 4 * o_c;
+      const bool cq_ok = cq < p.Cout;
+      const bool full = (eit.oy0 + 16 <= p.H) & (eit.ox0 + 16 <= p.W);   // uniform
+      if (closes && p.res != nullptr && !(SR_W4_ABL & 4)) {
+        // residual of the whole 16 x 16 x 64 tile: 16 float4 per thread, a tick (plus the M waves' output transform) ahead
+        const unsigned res_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.res_sp + p.Cout) * 4);
+        const __amdgpu_buffer_rsrc_t rs_res = w4_rsrc(p.res + (int64_t)eit.b * p.res_sb, res_img_bytes);
 #pragma unroll
-          for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(wr + j * 64 * W4_RS) = st[j];
-          if (tid < 16) *reinterpret_cast<w4_f4*>(wr + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
-          if (k + 2 < K) { w4_stage(p, ld_it, ld_s, st_q, st_pp0, st); advance(); }
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int pxl = (tid >> 4) + 16 * i, tile = pxl >> 3;
+            const int oy = eit.oy0 + 4 * (tile >> 2) + 2 * h + ((pxl >> 2) & 1), ox = eit.ox0 + 4 * (tile & 3) + (pxl & 3);
+            const bool ok = cq_ok & (full | ((oy < p.H) & (ox < p.W)));
+            rv[h][i] = w4_load(rs_res, w4_sel(ok, (unsigned)((oy * p.W + ox) * p.res_sp + cq) * 4u), 0u);
+          }
       }
-      __syncthreads();
+      W4_TR(1);
+      if (k < K) w4_transform36(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off);
+      W4_TR(2);
+      __syncthreads();   // ---- end of tick k
+      W4_TR(3);
+      if (closes) {
+        const float* OUT = lds + W4_WS_RAW2 + ((k - 1) & 1) * W4_V_FLOATS;
+        const unsigned out_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.out_sp + p.Cout) * 4);
+        const __amdgpu_buffer_rsrc_t rs_out = w4_rsrc(p.out + (int64_t)eit.b * p.out_sb, out_img_bytes);
+        w4_f4 bv = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (p.bias) bv = __builtin_bit_cast(w4_f4, __builtin_amdgcn_raw_buffer_load_b128(w4_rsrc(p.bias, (int64_t)p.Cout * 4),
+                                                                                         (int)w4_sel(cq_ok, (unsigned)cq * 4u), 0, 0));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          w4_f4 y[8];
+          if (!(SR_W4_ABL & 4)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int pxl = (tid >> 4) + 16 * i;
+              y[i] = *reinterpret_cast<const w4_f4*>(OUT + pxl * 64 + 4 * (o_c ^ ((pxl >> 3) & 15)));
+            }
+          }
+          __syncthreads();   // half h read: the M waves may write the next half / T(k + 1) may overwrite this V buffer
+          if (!(SR_W4_ABL & 4)) {
+            float o[32];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              w4_f4 v = y[i] + bv;
+              if (p.res != nullptr) v = v + rv[h][i];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[4 * i + e] = v[e];
+            }
+            sr_activate_group(o, slope);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int pxl = (tid >> 4) + 16 * i, tile = pxl >> 3;
+              const int oy = eit.oy0 + 4 * (tile >> 2) + 2 * h + ((pxl >> 2) & 1), ox = eit.ox0 + 4 * (tile & 3) + (pxl & 3);
+              const bool ok = cq_ok & (full | ((oy < p.H) & (ox < p.W)));
+              w4_store(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out,
+                       w4_sel(ok, (unsigned)((oy * p.W + ox) * p.out_sp + cq) * 4u));
+            }
+          }
+          if (h == 0) __syncthreads();   // the M waves have written half 1
+        }
+        ep_work += (int)gridDim.x;
+        W4_TR(4);
+      }
     }
   } else {
-    // ================= MFMA waves
+    // ================= M waves: MFMAs + patch movement + output transform
     const int m_j = lane & 15, m_kq = lane >> 4;
     const int m_sig = (0x1230 >> (m_j & 12)) & 3;
     const int m_rd_off = W4_WS_RAW2 + m_j * 16 + 4 * (m_kq ^ m_sig);
@@ -591,29 +678,105 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
     const unsigned u_fstride = (SR_W4_ABL & 8) ? 0u : (unsigned)p.S * 4u * (unsigned)p.Co_pad * 16u;
     const unsigned u_sstride = (SR_W4_ABL & 8) ? 0u : 4u * (unsigned)p.Co_pad * 16u;
     const __amdgpu_buffer_rsrc_t rs_u = w4_rsrc(p.wu, (int64_t)36 * p.S * 4 * p.Co_pad * 16);
+    const int st_q = tid & 3, st_pp0 = tid >> 2;
+    const int st_wr_off = st_pp0 * W4_RS + 4 * st_q;
+    unsigned st_off[W4_STAGE];
+#pragma unroll
+    for (int j = 0; j < W4_STAGE; ++j) {
+      const int pp = st_pp0 + 64 * j;
+      const int r = (pp * 3641) >> 16, c = pp - 18 * r;
+      st_off[j] = pp < W4_PS * W4_PS ? (unsigned)((r * p.W + c) * p.in_sp + 4 * st_q) * 4u : W4_OOB;
+    }
+    // OUT hand-over: this lane's 16-byte chunk of the pixel records of its tile
+    const int o_wr_off = m_j * 8 * 64 + 4 * ((4 * wave + m_kq) ^ m_j);
     w4_f4 acc[36];
 #pragma unroll
     for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
     w4_f4 ua[W4_NA][2];
+    w4_f4 st[W4_STAGE];
     int work = blockIdx.x, s = 0;
     W4Item it = w4_decode(p, work);
-    __syncthreads();
+    int ld_work = blockIdx.x, ld_s = 0;   // load cursor: the patch st[] is loaded with next
+    W4Item ld_it = it;
+    auto advance = [&]() {
+      if (++ld_s == p.S) { ld_s = 0; ld_work += (int)gridDim.x; if (ld_work < p.total) ld_it = w4_decode(p, ld_work); }
+    };
+    auto store_patch = [&](int par) {
+      float* wr = lds + par * W4_RAW_FLOATS + st_wr_off;
+#pragma unroll
+      for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(wr + j * 64 * W4_RS) = st[j];
+      if (tid < 16) *reinterpret_cast<w4_f4*>(wr + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
+    };
+    if (!(SR_W4_ABL & 16)) {   // patch 0 -> raw[0] (read by T(0) in tick 0, behind the first barrier ... which is tick 0's own
+      w4_stage_m(p, ld_it, ld_s, st_q, st_pp0, st_off, st);   //  barrier: so it has to land BEFORE tick 0 -- an extra barrier)
+      advance();
+      store_patch(0);
+      if (K > 1) { w4_stage_m(p, ld_it, ld_s, st_q, st_pp0, st_off, st); advance(); }
+    }
+    __syncthreads();   // raw[0] visible
     for (int k = 0; k <= K; ++k) {
+      const bool closes = k >= 1 && (k % p.S) == 0;
+      W4_TR(1);
       if (k >= 1) {
         const unsigned u_item = (SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u;
         w4_mfma_tick(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, lds + ((k - 1) & 1) * W4_V_FLOATS + m_rd_off, ua, acc,
                      lane);
-        if (++s == p.S) {
-          w4_finish(p, it, acc, wave, m_kq, m_j, tid);
-#pragma unroll
-          for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
-          s = 0;
-          work += (int)gridDim.x;
-          if (work < p.total) it = w4_decode(p, work);
-        }
+        ++s;
       }
-      if (k < K) w4_u_prefetch(rs_u, u_voff, ((SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u) + (unsigned)s * u_sstride, u_fstride, ua);
-      __syncthreads();
+      W4_TR(2);
+      if (!(SR_W4_ABL & 16) && k + 1 < K) {
+        store_patch((k + 1) & 1);
+        W4_TR(5);
+        if (k + 2 < K) { w4_stage_m(p, ld_it, ld_s, st_q, st_pp0, st_off, st); advance(); }
+      }
+      W4_TR(3);
+      if (closes) {
+        s = 0;
+        work += (int)gridDim.x;
+        const W4Item nit = work < p.total ? w4_decode(p, work) : it;
+        if (k < K) w4_u_prefetch(rs_u, u_voff, (SR_W4_ABL & 8) ? 0u : (unsigned)nit.co0 * 16u, u_fstride, ua);
+        it = nit;
+        float* OUT = lds + W4_WS_RAW2 + ((k - 1) & 1) * W4_V_FLOATS + o_wr_off;
+        if (SR_W4_ABL & 4) {
+          w4_f4 sum = acc[0];
+#pragma unroll
+          for (int f = 1; f < 36; ++f) sum = sum + acc[f];
+          if (sum[0] + sum[1] + sum[2] + sum[3] == 1.2345e33f) p.out[tid] = sum[0];
+          __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+        } else {
+          // Y = A^T M A in place; rows 0-1 of every tile -> OUT, [T reads], rows 2-3 -> OUT
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            w4_at(acc[j], acc[6 + j], acc[12 + j], acc[18 + j], acc[24 + j], acc[30 + j], acc[j], acc[6 + j], acc[12 + j],
+                  acc[18 + j]);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            w4_at(acc[6 * r], acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3], acc[6 * r + 4], acc[6 * r + 5], acc[6 * r],
+                  acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3]);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) *reinterpret_cast<w4_f4*>(OUT + (r * 4 + l) * 64) = acc[6 * r + l];
+          }
+          W4_TR(6);
+          __syncthreads();   // ---- end of tick k: half 0 visible
+#pragma unroll
+          for (int r = 2; r < 4; ++r)
+            w4_at(acc[6 * r], acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3], acc[6 * r + 4], acc[6 * r + 5], acc[6 * r],
+                  acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3]);
+          __syncthreads();   // T has read half 0
+#pragma unroll
+          for (int r = 2; r < 4; ++r)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) *reinterpret_cast<w4_f4*>(OUT + ((r - 2) * 4 + l) * 64) = acc[6 * r + l];
+          __syncthreads();   // half 1 visible
+          __syncthreads();   // T has read half 1 (this V buffer is T(k + 1)'s target)
+          W4_TR(7);
+        }
+#pragma unroll
+        for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+      } else {
+        if (k < K) w4_u_prefetch(rs_u, u_voff, ((SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u) + (unsigned)s * u_sstride, u_fstride, ua);
+        __syncthreads();   // ---- end of tick k
+      }
     }
   }
 }
@@ -675,9 +838,16 @@ extern "C" int sr_wino4_pack_weights(const float* weight, int Cout, int Cin, flo
   return sr_hip_rc(hipGetLastError());
 }
 
-// 1 when the F(4x4, 3x3) kernel is the better choice for this 3x3 / stride-1 convolution: 16x16-pixel regions with little
-// padding waste, enough work items to fill both workgroup slots of every CU for several rounds, whole 64-channel output
-// blocks.  `mode` 0: never, 1: this rule, 2: wherever the kernel applies (tests).
+// Which F(4x4, 3x3) kernel form, if any, is expected to beat the F(2x2) kernel for this 3x3 / stride-1 convolution: 0 = none,
+// 1 = two 4-wave workgroups per CU, 3 = the wave-specialised 8-wave workgroup.  Fitted on scripts/wino4_shape_sweep.py
+// (profiles/r05_wino4_shape_sweep.txt: every 3x3 shape of the hero conv stack at batch 8 / 1 and the matching encoder's
+// layer1 at 64 images, all three kernels):
+//   * many work items (>= 512, the last round >= 80 % full of 256 workgroups, <= 10 % region padding): F(4x4) wins by
+//     8-26 %; the wave-specialised form on short slab chains (Cin <= 64), the 4-wave form on long ones;
+//   * one round of 150-256 items (60x80 / 30x40 levels at batch 8): the wave-specialised form wins by ~16 % (one workgroup
+//     per CU has no second-round tail; F(2x2)'s 8x16 regions leave more of the chip idle there);
+//   * everything else (two partial rounds, < 150 items, 15x20 maps, batch 1): F(2x2) with its split-K plans stays.
+// `mode` 0: never, 1: this rule, 2: the 4-wave form wherever the kernel applies (tests).
 extern "C" int sr_conv_prefers_wino4(int B, int H, int W, int Cin, int Cout, int mode) {
   if (mode == 0 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 4 != 0 || Cout % 4 != 0) return 0;
   if (mode == 2) return 1;
@@ -686,11 +856,50 @@ extern "C" int sr_conv_prefers_wino4(int B, int H, int W, int Cin, int Cout, int
   const int co_blocks = (Cout + 63) / 64;
   const double co_util = (double)Cout / (double)(co_blocks * 64);
   const long items = regions * B * co_blocks;
-  const long slots = 2L * w4_num_cus();
-  const long rounds = (items + slots - 1) / slots;
-  const double fill = (double)items / (double)(rounds * slots);
-  return (util >= 0.9 && co_util >= 0.99 && Cin >= 16 && items >= 3 * slots && fill >= 0.85) ? 1 : 0;
+  const long cus = w4_num_cus();
+  if (co_util < 0.99 || Cin < 16) return 0;
+  if (items >= 2 * cus) {
+    const long rounds = (items + cus - 1) / cus;
+    const double fill = (double)items / (double)(rounds * cus);
+    if (util < 0.9 || fill < 0.8) return 0;
+    return Cin <= 64 ? 3 : 1;
+  }
+  if (items * 10 >= cus * 6 && items <= cus && util >= 0.75) return 3;   // one round on >= 60 % of the CUs
+  return 0;
 }
+
+#ifdef SR_W4_TRACE
+static unsigned long long* w4_trace_buf = nullptr;
+static int w4_trace_launches = 0;
+static void w4_trace_begin(SrWino4Params& p, hipStream_t stream) {
+  const size_t trace_n = (size_t)16 * 2 * W4_TR_N;
+  if (!w4_trace_buf) (void)hipMalloc((void**)&w4_trace_buf, trace_n * 8);
+  (void)hipMemsetAsync(w4_trace_buf, 0, trace_n * 8, stream);
+  p.trace = w4_trace_buf;
+}
+static void w4_trace_end(int blocks, hipStream_t stream) {
+  const size_t trace_n = (size_t)16 * 2 * W4_TR_N;
+  const char* at = getenv("SR_W4_TRACE_LAUNCH");
+  if (++w4_trace_launches != (at ? atoi(at) : 10)) return;
+  (void)hipStreamSynchronize(stream);
+  unsigned long long* host = (unsigned long long*)malloc(trace_n * 8);
+  (void)hipMemcpy(host, w4_trace_buf, trace_n * 8, hipMemcpyDeviceToHost);
+  for (int b = 0; b < 16 && b < blocks; b += 5)
+    for (int g = 0; g < 2; ++g) {
+      fprintf(stderr, "W4TRACE block %d group %d:", b, g);
+      unsigned long long t0 = host[((size_t)b * 2 + 0) * W4_TR_N] & 0xffffffffffffffull, prev = 0;
+      for (int i = 0; i < W4_TR_N; ++i) {
+        const unsigned long long v = host[((size_t)b * 2 + g) * W4_TR_N + i];
+        if (!v) break;
+        const unsigned long long t = (v & 0xffffffffffffffull) - t0;
+        fprintf(stderr, " %d@%llu(+%llu)", (int)(v >> 56), t, t - prev);
+        prev = t;
+      }
+      fprintf(stderr, "\n");
+    }
+  free(host);
+}
+#endif
 
 static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* packed_u, const float* bias,
                   const float* residual, int64_t res_batch_stride, int res_pix_stride, float* out, int64_t out_batch_stride,
@@ -728,7 +937,13 @@ static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, c
     if (blocks > p.total) blocks = p.total;
     hipError_t e = hipFuncSetAttribute((const void*)sr_wino4ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_WS_LDS_BYTES);
     if (e != hipSuccess) return sr_hip_rc(e);
+#ifdef SR_W4_TRACE
+    w4_trace_begin(p, (hipStream_t)stream_);
+#endif
     hipLaunchKernelGGL(sr_wino4ws_kernel, dim3(blocks), dim3(512), W4_WS_LDS_BYTES, (hipStream_t)stream_, p);
+#ifdef SR_W4_TRACE
+    w4_trace_end(blocks, (hipStream_t)stream_);
+#endif
     return sr_hip_rc(hipGetLastError());
   }
   if (variant != 2) {   // two independent 4-wave workgroups per CU
@@ -742,39 +957,13 @@ static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, c
   int blocks = w4_num_cus();
   if (blocks > (p.total + 1) / 2) blocks = (p.total + 1) / 2;
 #ifdef SR_W4_TRACE
-  static unsigned long long* trace_buf = nullptr;
-  static int launches = 0;
-  const size_t trace_n = (size_t)16 * 2 * W4_TR_N;
-  if (!trace_buf) (void)hipMalloc((void**)&trace_buf, trace_n * 8);
-  (void)hipMemsetAsync(trace_buf, 0, trace_n * 8, (hipStream_t)stream_);
-  p.trace = trace_buf;
+  w4_trace_begin(p, (hipStream_t)stream_);
 #endif
   hipError_t e = hipFuncSetAttribute((const void*)sr_wino4pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_LDS_BYTES);
   if (e != hipSuccess) return sr_hip_rc(e);
   hipLaunchKernelGGL(sr_wino4pp_kernel, dim3(blocks), dim3(512), 2 * W4_LDS_BYTES, (hipStream_t)stream_, p);
 #ifdef SR_W4_TRACE
-  {
-    const char* at = getenv("SR_W4_TRACE_LAUNCH");
-    if (++launches == (at ? atoi(at) : 10)) {
-      (void)hipStreamSynchronize((hipStream_t)stream_);
-      unsigned long long* host = (unsigned long long*)malloc(trace_n * 8);
-      (void)hipMemcpy(host, trace_buf, trace_n * 8, hipMemcpyDeviceToHost);
-      for (int b = 0; b < 16 && b < blocks; b += 5)
-        for (int g = 0; g < 2; ++g) {
-          fprintf(stderr, "W4TRACE block %d group %d:", b, g);
-          unsigned long long t0 = host[((size_t)b * 2 + 0) * W4_TR_N] & 0xffffffffffffffull, prev = 0;
-          for (int i = 0; i < W4_TR_N; ++i) {
-            const unsigned long long v = host[((size_t)b * 2 + g) * W4_TR_N + i];
-            if (!v) break;
-            const unsigned long long t = (v & 0xffffffffffffffull) - t0;
-            fprintf(stderr, " %d@%llu(+%llu)", (int)(v >> 56), t, t - prev);
-            prev = t;
-          }
-          fprintf(stderr, "\n");
-        }
-      free(host);
-    }
-  }
+  w4_trace_end(blocks, (hipStream_t)stream_);
 #endif
   return sr_hip_rc(hipGetLastError());
 }

@@ -475,8 +475,9 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 return out
             if rc != 2:   # SR_ERR_UNSUPPORTED: no library algorithm for this shape -> the HIP kernel below
                 _lib.check(rc, "sr_gemm1x1_nhwc_fwd")
-    if use_wino and WINO4_MODE and not wino_split_mode() and \
-            _shape_query(lib, "sr_conv_prefers_wino4", b, h, w, ci, co, WINO4_MODE):
+    w4_form = _shape_query(lib, "sr_conv_prefers_wino4", b, h, w, ci, co, WINO4_MODE) \
+        if (use_wino and WINO4_MODE and not wino_split_mode()) else 0   # 0: F(2x2); 1 / 3: the kernel form the rule picks
+    if w4_form:
         al = lambda t, sb_, sp_: t is None or (t.data_ptr() % 16 == 0 and sp_ % 4 == 0 and sb_ % 4 == 0)
         wp4, bias4 = packed_wino4_weight(conv, bn)
         if al(x, isb, isp) and al(out, osb, osp) and al(residual, rsb, rsp) and (bias4 is None or bias4.data_ptr() % 16 == 0):
@@ -486,13 +487,14 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                     ev0.record()
                 rc = lib.sr_conv3x3_wino4_variant_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp4), _lib.ptr(bias4),
                                                            _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co,
-                                                           C.c_float(_act_code(leaky, act)), WINO4_VARIANT,
+                                                           C.c_float(_act_code(leaky, act)), WINO4_VARIANT or w4_form,
                                                            _lib.stream_ptr(x.device))
                 if prof is not None and rc == 0:
                     ev1.record()
                     regions = ((h + 15) // 16) * ((w + 15) // 16)   # multiplies issued: 36 per 4x4 tile and (ci, co) pair, padded
                     executed = 2.0 * b * regions * 16 * 36 * ((ci + 15) // 16 * 16) * ((co + 63) // 64 * 64)
-                    prof.append(("sr_wino4_kernel", 2.0 * b * ho * wo * co * ci * 9, ev0, ev1,
+                    prof.append(("sr_wino4ws_kernel" if (WINO4_VARIANT or w4_form) == 3 else "sr_wino4_kernel",
+                                 2.0 * b * ho * wo * co * ci * 9, ev0, ev1,
                                  (b, ci, h, w, co, k, s, ho, wo, residual is not None), executed))
             if rc == 0:
                 return out

@@ -143,10 +143,13 @@ def test_wino4_non_finite_inputs_do_not_leak_across_channel_padding():
 
 def test_ops_conv2d_dispatches_wino4_by_rule_and_by_switch(monkeypatch):
     lib = _lib.lib()
-    assert lib.sr_conv_prefers_wino4(8, 240, 320, 64, 64, 1) == 1
-    assert lib.sr_conv_prefers_wino4(8, 240, 320, 192, 64, 1) == 1
-    assert lib.sr_conv_prefers_wino4(1, 240, 320, 64, 64, 1) == 0      # too few work items: F(2x2)
-    assert lib.sr_conv_prefers_wino4(8, 120, 160, 64, 64, 1) == 0      # 640 items on 512 slots: a 1.25-round launch
+    assert lib.sr_conv_prefers_wino4(8, 240, 320, 64, 64, 1) == 3      # short slab chain: the wave-specialised form
+    assert lib.sr_conv_prefers_wino4(8, 240, 320, 192, 64, 1) == 1     # long one: two 4-wave workgroups per CU
+    assert lib.sr_conv_prefers_wino4(1, 240, 320, 64, 64, 1) == 0      # 300 items in two partial rounds: F(2x2)
+    assert lib.sr_conv_prefers_wino4(8, 120, 160, 64, 64, 1) == 3      # 640 items = 2.5 rounds of 256 workgroups
+    assert lib.sr_conv_prefers_wino4(8, 60, 80, 64, 64, 1) == 3        # one round on 160 CUs
+    assert lib.sr_conv_prefers_wino4(8, 60, 80, 128, 128, 1) == 0      # 320 items: two partial rounds
+    assert lib.sr_conv_prefers_wino4(8, 15, 20, 384, 384, 1) == 0
     assert lib.sr_conv_prefers_wino4(8, 240, 320, 64, 64, 0) == 0
     assert lib.sr_conv_prefers_wino4(1, 24, 24, 16, 16, 2) == 1
     torch.manual_seed(6)
@@ -158,10 +161,10 @@ def test_ops_conv2d_dispatches_wino4_by_rule_and_by_switch(monkeypatch):
         prof = []
         monkeypatch.setattr(ops, "PROFILE", prof)
         y = ops.conv2d(x, conv, leaky=0.2)
-        assert prof[-1][0] == "sr_wino4_kernel"
+        assert prof[-1][0] in ("sr_wino4_kernel", "sr_wino4ws_kernel")
         monkeypatch.setattr(ops, "WINO4_MODE", 0)
         ops._SHAPE_QUERIES.clear()
         y0 = ops.conv2d(x, conv, leaky=0.2)
-        assert prof[-1][0] != "sr_wino4_kernel"
+        assert not prof[-1][0].startswith("sr_wino4")
     ops._SHAPE_QUERIES.clear()
     assert (y - y0).abs().max().item() < 2e-5 * y0.abs().max().item()
