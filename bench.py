@@ -153,9 +153,10 @@ def main():
     ap.add_argument("--workload", default=None, help="default: the BASELINE.json metric configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-experiments", action="store_true",
-                    help="skip the `experiments` field (the fenced split-precision workload, run in a child process after the "
-                         "headline is timed; it is reported beside the headline and never enters it)")
+    ap.add_argument("--no-experiments", action="store_true", help="(default since r05; kept for old command lines)")
+    ap.add_argument("--experiments", action="store_true",
+                    help="also report the fenced split-precision workload in an `experiments` field (a child process after the "
+                         "headline is timed; narrower arithmetic than the reference's fp32: never the headline -- VERDICT r04)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the process group and run the result gather / all-reduce / barrier collectives even "
                          "with one rank (exercises the RCCL path on a 1-GPU box)")
@@ -265,7 +266,7 @@ def main():
             except Exception as e:  # the baseline is reported next to the measurement, it must never cost the line
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
-        if world == 1 and name == bench_workloads.DEFAULT and not (args.no_experiments or args.no_cpu_baseline or args.no_roofline):
+        if world == 1 and name == bench_workloads.DEFAULT and args.experiments and not args.no_experiments:
             out["experiments"] = [_fenced_experiment("hero_cfg3_f16x3_convs", min(args.steps, 10), args.warmup)]
         print(json.dumps(out), flush=True)
     if collective:

@@ -418,36 +418,70 @@ class HeroCfg3:
                                                D * h * w, 1, D, None, None, _lib.ptr(ws), ws.numel(), st), "sweep")
         return _time_launches(sweep, n)
 
-    def roofline(self, n):
+    def _kernel_entries(self, n):
+        """One roofline entry per kernel of the step (every conv kernel by name + the plane sweep), sorted by time per step.
+        Conv kernels: `achieved` counts the FLOPs the kernel EXECUTES on the matrix cores -- Winograd F(2x2, 3x3) issues 16 and
+        F(4x4, 3x3) 36 / 4 = 9 multiplies per 2x2 outputs and channel pair instead of the direct algorithm's 36 -- so frac = MFMA
+        utilisation <= 1; the direct-convolution (algorithmic) count is reported beside it."""
         n = max(3, min(n, 10))
         agg = self._profile_convs(n)
-        self._conv_agg, self._prof_n = agg, n
-        name = max(agg, key=lambda k: agg[k][2])
-        calls, flops, t, executed = agg[name]
-        wino = "wino" in name
-        # `achieved` counts the FLOPs the kernel EXECUTES on the matrix cores (Winograd F(2x2,3x3) issues 16 instead of
-        # 36 multiplies per 2x2 tile and channel pair), so frac = MFMA utilisation <= 1; the direct-convolution
-        # (algorithmic) count is reported beside it
-        achieved = (executed if wino else flops) / t / 1e12
-        peak = FP32_MFMA_PEAK_TF
-        if "split" in name:   # fenced experiment: three 16-bit products per fp32 product, priced on the 16-bit matrix pipe
-            achieved, peak = 3 * achieved, F16_MFMA_PEAK_TF
-        traffic = _pmc_traffic(self.name)
-        out = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-               "frac": achieved / peak, "traffic": traffic,
-               "algorithmic_bytes_per_launch": (self._conv_bytes.get(name, 0.0) / calls) or None,
-               "traffic_over_algorithmic": (traffic / (self._conv_bytes[name] / calls))
-               if traffic and self._conv_bytes.get(name) else None,
-               "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // n,
-               "executed_flops_per_launch": (executed if wino else flops) / calls,
-               "algorithmic_flops_per_launch": flops / calls,
-               "algorithmic_tflops": flops / t / 1e12,
-               "algorithmic_speed_vs_direct_peak": flops / t / 1e12 / FP32_MFMA_PEAK_TF,
-               "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_32x32x2_f32).  achieved / frac = FLOPs actually issued on the "
-                       "matrix pipe / time / peak (MFMA utilisation); algorithmic_* = the direct-convolution count "
-                       "2*B*Ho*Wo*Cout*Cin*k*k over the launches of this kernel in one step (Winograd needs 16/36 of "
-                       "them, so algorithmic_speed_vs_direct_peak may exceed 1: a speed-up over direct convolution, not "
-                       "a roofline fraction)"}
+        self._prof_n = n
+        out = []
+        for name, (calls, flops, t, executed) in agg.items():
+            wino = "wino" in name
+            ex = executed if wino else flops
+            peak = FP32_MFMA_PEAK_TF
+            if "split" in name:   # fenced experiment: three 16-bit products per fp32 product, priced on the 16-bit matrix pipe
+                ex, peak = 3 * ex, F16_MFMA_PEAK_TF
+            e = {"kernel": name, "bound": "mfma", "achieved": ex / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                 "frac": ex / t / 1e12 / peak, "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // n,
+                 "ms_per_step": t / n * 1e3, "executed_flops_per_launch": ex / calls,
+                 "algorithmic_flops_per_launch": flops / calls, "algorithmic_tflops": flops / t / 1e12}
+            nbytes = self._conv_bytes.get(name)
+            if nbytes:   # both rooflines of the kernel: the larger fraction names the resource that binds it
+                e["mfma_frac"] = e["frac"]
+                e["hbm_frac"] = nbytes / t / 1e9 / HBM_PEAK_GBS
+                e["algorithmic_bytes_per_launch"] = nbytes / calls
+                if e["hbm_frac"] > e["mfma_frac"]:
+                    e.update({"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": e["hbm_frac"]})
+            out.append(e)
+        if self.feature_volume_type == "mlp_feature_volume":
+            t = self._mlp_sweep_time(n)
+            N = self.h * self.w
+            cin = self.Cc * (self.K + 1) + 10 * self.K + 4
+            flops = 2.0 * (cin * 128 + 128 * 128 + 128) * self.B * self.D * N
+            e = {"kernel": _mlp_kernel_name(self.K), "bound": "mfma", "achieved": flops / t / 1e12,
+                 "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF,
+                 "avg_launch_us": t * 1e6, "launches_per_step": 1, "ms_per_step": t * 1e3,
+                 "algorithmic_flops_per_launch": flops, "executed_flops_per_launch": flops,
+                 "algorithmic_bytes_per_launch": self.B * (4 * ((self.K + 1) * self.Cc * N + self.D * N + N))}
+            if "split" in e["kernel"]:   # fenced experiment: three 16-bit products per fp32 product, priced on the 16-bit pipe
+                e.update({"achieved": 3 * flops / t / 1e12, "peak": F16_MFMA_PEAK_TF, "frac": 3 * flops / t / 1e12 / F16_MFMA_PEAK_TF,
+                          "algorithmic_tflops": flops / t / 1e12,
+                          "note": "executed = 3 x algorithmic flops (two 16-bit pieces per operand, three products)"})
+            out.append(e)
+        out.sort(key=lambda e: -e["ms_per_step"])
+        return out
+
+    def roofline(self, n):
+        """The DOMINANT kernel of the step -- the one with the most time per step among every conv kernel and the plane sweep
+        (r05: the F(4x4) Winograd kernel and the metadata-MLP sweep are within a few percent of each other; whichever leads is
+        named here, the other is the first entry of `kernels`)."""
+        ents = self._kernel_entries(n)
+        self._entries = ents
+        out = dict(ents[0])
+        # PMC traffic of THIS kernel (profiles/traffic.json: "<workload>:<kernel symbol>", written by scripts/pmc_traffic.py)
+        short = out["kernel"].split("<")[0].split("(")[0].replace("void ", "").strip()
+        traffic = _pmc_traffic(f"{self.name}:{short}", out["kernel"])
+        out["traffic"] = traffic
+        ab = out.get("algorithmic_bytes_per_launch")
+        out["traffic_over_algorithmic"] = (traffic / ab) if (traffic and ab) else None
+        out["note"] = ("fp32-in / fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense).  "
+                       "achieved / frac = FLOPs actually issued on the matrix pipe / time / peak (MFMA utilisation); algorithmic_* = "
+                       "the direct-convolution count 2*B*Ho*Wo*Cout*Cin*k*k over the launches of this kernel in one step "
+                       "(Winograd issues 16/36 -- F(4x4): 9/36 -- of them, so algorithmic_tflops may exceed the peak: a speed-up "
+                       "over direct convolution, not a roofline fraction)")
         return out
 
     def roofline_hbm(self, n):
@@ -473,39 +507,7 @@ class HeroCfg3:
         return out
 
     def extra_kernels(self, n):
-        out = []
-        for name, (calls, flops, t, executed) in sorted(self._conv_agg.items(), key=lambda kv: -kv[1][2])[1:]:
-            ex = executed if "wino" in name else flops
-            peak = FP32_MFMA_PEAK_TF
-            if "split" in name:
-                ex, peak = 3 * ex, F16_MFMA_PEAK_TF
-            e = {"kernel": name, "bound": "mfma", "achieved": ex / t / 1e12, "peak": peak,
-                 "unit": "TFLOP/s", "frac": ex / t / 1e12 / peak, "algorithmic_tflops": flops / t / 1e12,
-                 "avg_launch_us": t / calls * 1e6, "launches_per_step": calls // self._prof_n}
-            nbytes = self._conv_bytes.get(name)
-            if nbytes:   # both rooflines of the kernel: the larger fraction names the resource that binds it
-                e["mfma_frac"] = e["frac"]
-                e["hbm_frac"] = nbytes / t / 1e9 / HBM_PEAK_GBS
-                e["algorithmic_bytes_per_launch"] = nbytes / calls
-                if e["hbm_frac"] > e["mfma_frac"]:
-                    e.update({"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": e["hbm_frac"]})
-            out.append(e)
-        if self.feature_volume_type == "mlp_feature_volume":
-            t = self._mlp_sweep_time(max(3, min(n, 10)))
-            N = self.h * self.w
-            cin = self.Cc * (self.K + 1) + 10 * self.K + 4
-            flops = 2.0 * (cin * 128 + 128 * 128 + 128) * self.B * self.D * N
-            e = {"kernel": _mlp_kernel_name(self.K), "bound": "mfma", "achieved": flops / t / 1e12,
-                 "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_MFMA_PEAK_TF,
-                 "avg_launch_us": t * 1e6, "algorithmic_flops_per_launch": flops,
-                 "algorithmic_bytes_per_launch": self.B * (4 * ((self.K + 1) * self.Cc * N + self.D * N + N))}
-            if "split" in e["kernel"]:   # fenced experiment: three 16-bit products per fp32 product, priced on the 16-bit pipe
-                e.update({"achieved": 3 * flops / t / 1e12, "peak": F16_MFMA_PEAK_TF, "frac": 3 * flops / t / 1e12 / F16_MFMA_PEAK_TF,
-                          "algorithmic_tflops": flops / t / 1e12,
-                          "note": "executed = 3 x algorithmic flops (two 16-bit pieces per operand, three products)"})
-            out.append(e)
-        return out
+        return [dict(e) for e in self._entries[1:]]
 
     def cpu_baseline(self):
         """The reference's CPU PyTorch path for this workload = the same ATen operator sequence (bench_cpu_aten.py:

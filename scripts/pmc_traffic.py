@@ -5,7 +5,7 @@ HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters 
 FETCH_SIZE reports exactly half of the bytes of 16-byte-per-lane reads (guides/MI355X_MICROARCH.md, HBM section;
 re-confirmed in round 1 on sr_pack_nhwc_kernel: 8.6 MB streamed, FETCH_SIZE = 4205 KiB, WRITE_SIZE = 8400 KiB).
 Infinity-Cache hits are included in FETCH_SIZE, so this is fabric traffic, an upper bound on DRAM traffic."""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -23,7 +23,9 @@ def main(rnd):
     path = os.path.join(R, "profiles", "traffic.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
     lines = []
-    for wl, tag, kerns in (("hero_cfg3", "hero", {"hero_cfg3": "sr_wino_kernel<2, true, true", "hero_cfg3:mlp_sweep": "sr_mlp_volume_kernel"}),
+    for wl, tag, kerns in (("hero_cfg3", "hero", {"hero_cfg3:sr_wino_kernel": "sr_wino_kernel<2, true, true", "hero_cfg3:mlp_sweep": "sr_mlp_volume_kernel",
+                                              "hero_cfg3:sr_mlp_volume_kernel": "sr_mlp_volume_kernel", "hero_cfg3:sr_wino4_kernel": "sr_wino4_kernel",
+                                              "hero_cfg3:sr_wino4ws_kernel": "sr_wino4ws_kernel"}),
                            ("hero_cfg5_volume", "cfg5", {"hero_cfg5_volume": "sr_mlp_volume_kernel"})):
         f, w = agg(tag, "FETCH_SIZE"), agg(tag, "WRITE_SIZE")
         if not f:
@@ -36,7 +38,8 @@ def main(rnd):
                 lines.append(f"| `{k[:70]}` | {n} | {v/n:.1f} | {wv/max(wn,1):.1f} | {b/1e6:.1f} MB |")
             for key, sub in kerns.items():
                 if sub in k:
-                    out[key] = {"bytes": b, "kernel": k.split("(")[0].replace("void ", "")}
+                    m = re.search(r"sr_\w+(<[^(]*>)?", k)
+                    out[key] = {"bytes": b, "kernel": m.group(0) if m else k[:60]}
         lines.append("")
     json.dump(out, open(path, "w"), indent=1)
     open(os.path.join(R, "profiles", f"{rnd}_pmc_traffic.md"), "w").write(

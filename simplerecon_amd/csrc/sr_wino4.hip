@@ -595,30 +595,42 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
     const int t_sig = (0x1230 >> (t_tile & 12)) & 3;
     const int t_rd_off = ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3)) * W4_RS + t_ci;
     const int t_wr_off = W4_WS_RAW2 + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
-    // output role: channel quad c of the pixels pxl = (tid >> 4) + 16 i, i = 0 .. 7, of a half tile (16 tiles x 2 x 4 pixels)
-    const int o_c = tid & 15;
+    // output role: channel quad o_c of the pixels pxl_i = (tid >> 4) + 16 i, i = 0 .. 7, of a half tile (16 tiles x 2 x 4 pixels:
+    // pxl = 8 tile + 4 kk + l).  With t0 = tid >> 7, kk = (tid >> 6) & 1, l = (tid >> 4) & 3:  tile_i = t0 + 2 i, so pixel i of half h
+    // sits at row 4 (i >> 1) + 2 h + kk, column 4 t0 + 8 (i & 1) + l of the region: ONE lane offset per tensor (row kk, column
+    // 4 t0 + l, channel quad) plus a scalar per (i, h) -- no address arithmetic per access.
+    const int o_c = tid & 15, o_t0 = tid >> 7, o_kk = (tid >> 6) & 1, o_l = (tid >> 4) & 3;
+    const unsigned o_lane = (unsigned)((o_kk * p.W + 4 * o_t0 + o_l) * p.out_sp + 4 * o_c) * 4u;
+    const unsigned r_lane = (unsigned)((o_kk * p.W + 4 * o_t0 + o_l) * p.res_sp + 4 * o_c) * 4u;
+    const int o_rd = ((tid >> 4) * 64) * 4;                 // byte offset of pixel 0's record in OUT
+    const int o_cx = 16 * (o_c ^ o_t0);                     // its 16-byte chunk; pixel i: chunk o_c ^ tile_i = (o_c ^ t0) ^ 2 i
     const float slope = sr_uniform(p.slope);
+    const bool has_res = p.res != nullptr && !(SR_W4_ABL & 4);   // uniform
     int ep_work = blockIdx.x;   // the item whose epilogue comes next
     w4_f4 rv[2][8];
     __syncthreads();   // (the M waves' first patch is in raw[0])
     for (int k = 0; k <= K; ++k) {
       const bool closes = k >= 1 && (k % p.S) == 0;   // (uniform) slab k - 1 is the last of its item
-      W4Item eit = w4_decode(p, ep_work);
-      const int cq = eit.co0 + 4 * o_c;
-      const bool cq_ok = cq < p.Cout;
+      const W4Item eit = w4_decode(p, ep_work);
+      const bool cq_ok = eit.co0 + 4 * o_c < p.Cout;
       const bool full = (eit.oy0 + 16 <= p.H) & (eit.ox0 + 16 <= p.W);   // uniform
-      if (closes && p.res != nullptr && !(SR_W4_ABL & 4)) {
+      if (closes && has_res) {
         // residual of the whole 16 x 16 x 64 tile: 16 float4 per thread, a tick (plus the M waves' output transform) ahead
         const unsigned res_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.res_sp + p.Cout) * 4);
         const __amdgpu_buffer_rsrc_t rs_res = w4_rsrc(p.res + (int64_t)eit.b * p.res_sb, res_img_bytes);
+        const unsigned rbase = (unsigned)((eit.oy0 * p.W + eit.ox0) * p.res_sp + eit.co0) * 4u;   // scalar
+        const unsigned rl = cq_ok ? r_lane : W4_OOB;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const int pxl = (tid >> 4) + 16 * i, tile = pxl >> 3;
-            const int oy = eit.oy0 + 4 * (tile >> 2) + 2 * h + ((pxl >> 2) & 1), ox = eit.ox0 + 4 * (tile & 3) + (pxl & 3);
-            const bool ok = cq_ok & (full | ((oy < p.H) & (ox < p.W)));
-            rv[h][i] = w4_load(rs_res, w4_sel(ok, (unsigned)((oy * p.W + ox) * p.res_sp + cq) * 4u), 0u);
+            const unsigned d = (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.res_sp) * 4u;   // scalar
+            if (full) {
+              rv[h][i] = w4_load(rs_res, rl, rbase + d);
+            } else {
+              const bool ok = (eit.oy0 + 4 * (i >> 1) + 2 * h + o_kk < p.H) & (eit.ox0 + 4 * o_t0 + 8 * (i & 1) + o_l < p.W);
+              rv[h][i] = w4_load(rs_res, ok ? rl : W4_OOB, rbase + d);
+            }
           }
       }
       W4_TR(1);
@@ -627,21 +639,20 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
       __syncthreads();   // ---- end of tick k
       W4_TR(3);
       if (closes) {
-        const float* OUT = lds + W4_WS_RAW2 + ((k - 1) & 1) * W4_V_FLOATS;
+        const char* OUT = reinterpret_cast<const char*>(lds + W4_WS_RAW2 + ((k - 1) & 1) * W4_V_FLOATS) + o_rd;
         const unsigned out_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.out_sp + p.Cout) * 4);
         const __amdgpu_buffer_rsrc_t rs_out = w4_rsrc(p.out + (int64_t)eit.b * p.out_sb, out_img_bytes);
+        const unsigned obase = (unsigned)((eit.oy0 * p.W + eit.ox0) * p.out_sp + eit.co0) * 4u;   // scalar
+        const unsigned ol = cq_ok ? o_lane : W4_OOB;
         w4_f4 bv = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
         if (p.bias) bv = __builtin_bit_cast(w4_f4, __builtin_amdgcn_raw_buffer_load_b128(w4_rsrc(p.bias, (int64_t)p.Cout * 4),
-                                                                                         (int)w4_sel(cq_ok, (unsigned)cq * 4u), 0, 0));
+                                                                                         (int)(cq_ok ? (unsigned)(eit.co0 + 4 * o_c) * 4u : W4_OOB), 0, 0));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           w4_f4 y[8];
           if (!(SR_W4_ABL & 4)) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const int pxl = (tid >> 4) + 16 * i;
-              y[i] = *reinterpret_cast<const w4_f4*>(OUT + pxl * 64 + 4 * (o_c ^ ((pxl >> 3) & 15)));
-            }
+            for (int i = 0; i < 8; ++i) y[i] = *reinterpret_cast<const w4_f4*>(OUT + i * 16 * 64 * 4 + (o_cx ^ (32 * i)));
           }
           __syncthreads();   // half h read: the M waves may write the next half / T(k + 1) may overwrite this V buffer
           if (!(SR_W4_ABL & 4)) {
@@ -649,18 +660,20 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               w4_f4 v = y[i] + bv;
-              if (p.res != nullptr) v = v + rv[h][i];
+              if (has_res) v = v + rv[h][i];
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[4 * i + e] = v[e];
             }
             sr_activate_group(o, slope);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-              const int pxl = (tid >> 4) + 16 * i, tile = pxl >> 3;
-              const int oy = eit.oy0 + 4 * (tile >> 2) + 2 * h + ((pxl >> 2) & 1), ox = eit.ox0 + 4 * (tile & 3) + (pxl & 3);
-              const bool ok = cq_ok & (full | ((oy < p.H) & (ox < p.W)));
-              w4_store(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out,
-                       w4_sel(ok, (unsigned)((oy * p.W + ox) * p.out_sp + cq) * 4u));
+              const unsigned d = obase + (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.out_sp) * 4u;   // scalar
+              unsigned voff = ol + d;
+              if (!full) {
+                const bool ok = (eit.oy0 + 4 * (i >> 1) + 2 * h + o_kk < p.H) & (eit.ox0 + 4 * o_t0 + 8 * (i & 1) + o_l < p.W);
+                voff = ok ? voff : W4_OOB;
+              }
+              w4_store(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out, voff);
             }
           }
           if (h == 0) __syncthreads();   // the M waves have written half 1
