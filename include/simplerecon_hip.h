@@ -575,6 +575,21 @@ int sr_rgb_stem3x3s2_fwd(const float* image, int64_t sb, int64_t sc, int64_t sy,
                          const float* bias, float* out, int64_t out_batch_stride, int out_pix_stride, int B, int H, int W,
                          int Cout, int pad_top, int pad_left, int Ho, int Wo, float act_code, void* stream);
 
+/* The front half of a stride-1 MBConv block in ONE launch (csrc/sr_mbconv_fused.hip, r05): 1x1 expansion (BatchNorm folded,
+ * SiLU) -> depthwise 3x3 / pad 1 (BatchNorm folded, SiLU) -> squeeze-excite average pool -> squeeze-excite gates
+ * sigmoid(W2 silu(W1 mean + b1) + b2) -- timm's InvertedResidual up to the projection (reference
+ * experiment_modules/depth_model.py:110-116 builds the encoder from timm), which stays sr_pw_conv_nhwc_fwd with `gate`.
+ * `w_expand` [mid][Cin], `w_dw9c` [9][mid] tap-major, `w_reduce` [rd][mid], `w_excite` [mid][rd]; `out` [B][H*W][mid]
+ * channels-last view, `pool` [B][mid] (channel sums, by-product), `gate` [B][mid]; `counters`: B zeroed 32-bit words that the
+ * call leaves zeroed (one arrival counter per image: the last workgroup of an image computes its gates).  Deterministic.
+ * sr_mbconv_fused_supported(): Cin in {128, 160, 256}, mid % 16 == 0, rd <= 64, H*W*64 bytes within the LDS budget. */
+int sr_mbconv_fused_supported(int H, int W, int Cin, int mid, int rd);
+int sr_mbconv_expand_dw_se_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* w_expand,
+                               const float* b_expand, const float* w_dw9c, const float* b_dw, const float* w_reduce,
+                               const float* b_reduce, const float* w_excite, const float* b_excite, float* out,
+                               int64_t out_batch_stride, int out_pix_stride, float* pool, float* gate, unsigned* counters,
+                               int B, int H, int W, int Cin, int mid, int rd, void* stream);
+
 /* The squeeze-excite gates alone, gate[b][c] = sigmoid(W2 silu(W1 mean_b + b1) + b2)[c], from sr_dwconv3x3_nhwc_fwd's partial
  * sums (timm SqueezeExcite of the MBConv blocks, reference depth_model.py:110-116) for a consumer that applies them itself:
  * sr_pw_conv_nhwc_fwd(gate = ...) scales the projection's input while loading it.  `hidden`: scratch [B][rd]. */

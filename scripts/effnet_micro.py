@@ -48,4 +48,9 @@ with torch.inference_mode():
             t4 = timed(lambda: ops.scale_channels_(d, g))
             t5 = timed(lambda: ops.conv2d(d, blk.conv_pwl, bn=blk.bn3, residual=y))
             print(f"   block1: pw {t1*1e3:.0f} us  dw {t2*1e3:.0f} us  se {t3*1e3:.0f} us  scale {t4*1e3:.0f} us  pwl {t5*1e3:.0f} us")
+            if ops.mbconv_fused_supported(y, blk.conv_pw, blk.conv_dw, blk.se):
+                t6 = timed(lambda: ops.mbconv_expand_dw_se(y, blk.conv_pw, blk.bn1, blk.conv_dw, blk.bn2, blk.se))
+                dd, gg = ops.mbconv_expand_dw_se(y, blk.conv_pw, blk.bn1, blk.conv_dw, blk.bn2, blk.se)
+                t7 = timed(lambda: ops.conv2d(dd, blk.conv_pwl, bn=blk.bn3, residual=y, gate=gg))
+                print(f"   block1 fused: expansion+depthwise+gates {t6*1e3:.0f} us  gated projection {t7*1e3:.0f} us")
     print(f"whole encoder {timed(lambda: enc(img)):8.3f} ms for {B} images (stages sum {tot:.3f})")

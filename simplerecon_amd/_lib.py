@@ -38,6 +38,9 @@ SIGNATURES = {
                                _p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
     "sr_gemm1x1_workspace_bytes": (_sz, []),
     "sr_gemm1x1_nhwc_fwd": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "sr_mbconv_fused_supported": (_i, [_i, _i, _i, _i, _i]),
+    "sr_mbconv_expand_dw_se_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _i, _i, _i, _i, _i,
+                                        _i, _p]),
     "sr_rgb_stem3x3s2_fwd": (_i, [_p, _i64, _i64, _i64, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "sr_se_gate2_fwd": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "sr_conv3x3_wino_io_nhwc_fwd": (_i, [_p, _i64, _i, _p, _p, _p, _i64, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
@@ -202,10 +205,21 @@ def _option_id(name):
     return oid
 
 
+_OPTION_MIRROR = {}   # name -> value as last read / set THROUGH this module: what the launch paths consult (no ctypes call
+                      # per launch).  A host that drives sr_option_set() by other means calls refresh_options() afterwards.
+
+
 def get_option(name):
-    v = C.c_int(0)
-    check(lib().sr_option_get(_option_id(name), C.byref(v)), "sr_option_get")
-    return v.value
+    v = _OPTION_MIRROR.get(name)
+    if v is None:
+        c = C.c_int(0)
+        check(lib().sr_option_get(_option_id(name), C.byref(c)), "sr_option_get")
+        v = _OPTION_MIRROR[name] = c.value
+    return v
+
+
+def refresh_options():
+    _OPTION_MIRROR.clear()
 
 
 def set_option(name, value):
@@ -215,6 +229,7 @@ def set_option(name, value):
         value = SPLIT_MODES.get(value, -1)
     prev = C.c_int(0)
     check(lib().sr_option_set(_option_id(name), int(value), C.byref(prev)), "sr_option_set")
+    _OPTION_MIRROR[name] = int(value)
     for fn in OPTION_LISTENERS:
         fn(name, int(value))
     return prev.value

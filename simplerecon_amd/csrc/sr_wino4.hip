@@ -553,6 +553,43 @@ __device__ __forceinline__ void w4_transform36(const float* t_rd, float* t_wr) {
   }
 }
 
+// The same transform on channel PAIRS with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: two IEEE fmas per
+// instruction, component-wise the very operations of w4_bt -- bit-identical): a thread takes (tile, 2 channels), reads 8-byte
+// pairs from the patch and writes 8-byte pairs of V.  128 work items per slab = lanes 0-31 of each of the four T waves: half
+// the VALU and LDS instructions per wave of the one-channel form.  (MFMA and VALU instructions of the two waves of a SIMD do
+// not overlap -- scripts/micro/mfma16_overlap.hip --, so the T waves' instruction count is matrix-pipe time.)
+typedef float w4_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ w4_f2 w4_fma2(float a, w4_f2 b, w4_f2 c) { return __builtin_elementwise_fma(w4_f2{a, a}, b, c); }
+__device__ __forceinline__ void w4_bt2(w4_f2 d0, w4_f2 d1, w4_f2 d2, w4_f2 d3, w4_f2 d4, w4_f2 d5, w4_f2& t0, w4_f2& t1, w4_f2& t2,
+                                       w4_f2& t3, w4_f2& t4, w4_f2& t5) {
+  const w4_f2 a = w4_fma2(-4.0f, d2, d4), b = w4_fma2(-4.0f, d1, d3);
+  const w4_f2 c = w4_fma2(-0.25f, d2, d4), e = w4_fma2(-0.25f, d1, d3);
+  t0 = w4_fma2(-4.25f, d2, d0) + d4;
+  t1 = w4_fma2(0.5f, b, a);
+  t2 = w4_fma2(-0.5f, b, a);
+  t3 = w4_fma2(2.0f, e, c);
+  t4 = w4_fma2(-2.0f, e, c);
+  t5 = w4_fma2(-4.25f, d3, d1) + d5;
+}
+__device__ __forceinline__ void w4_transform36_pk(const float* t_rd, float* t_wr) {
+  if (SR_W4_ABL & 1) return;
+  w4_f2 t[6][6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    w4_f2 d[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const w4_f2*>(t_rd + (r * W4_PS + c) * W4_RS);
+    w4_bt2(d[0], d[1], d[2], d[3], d[4], d[5], t[0][c], t[1][c], t[2][c], t[3][c], t[4][c], t[5][c]);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    w4_f2 v[6];
+    w4_bt2(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<w4_f2*>(t_wr + (i * 6 + j) * 256) = v[j];
+  }
+}
+
 constexpr int W4_WS_RAW2 = 2 * W4_RAW_FLOATS;                       // V buffers start behind the two raw buffers
 constexpr int W4_WS_LDS_BYTES = (2 * W4_RAW_FLOATS + 2 * W4_V_FLOATS) * 4;   // 125 568
 
@@ -591,7 +628,10 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
 
   if (role_t) {
     // ================= T waves: transform + output side
-    const int t_ci = tid & 15, t_tile = tid >> 4;
+    // transform role: work item (tile, channel pair) = 32 * wave + lane for lanes 0-31 of every T wave
+    const bool t_on = lane < 32;
+    const int t_item = 32 * wave + (lane & 31);
+    const int t_ci = 2 * (t_item & 7), t_tile = t_item >> 3;
     const int t_sig = (0x1230 >> (t_tile & 12)) & 3;
     const int t_rd_off = ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3)) * W4_RS + t_ci;
     const int t_wr_off = W4_WS_RAW2 + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
@@ -634,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
           }
       }
       W4_TR(1);
-      if (k < K) w4_transform36(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off);
+      if (k < K && t_on) w4_transform36_pk(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off);
       W4_TR(2);
       __syncthreads();   // ---- end of tick k
       W4_TR(3);

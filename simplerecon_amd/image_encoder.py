@@ -35,6 +35,10 @@ def _tf_pads(x, conv):
 
 BN_EPS = 1e-3          # tf_* models
 FUSE_SE_GATE = os.environ.get("SR_SE_GATE_FUSED", "1") != "0"   # 0: separate in-place scaling pass (r03)
+# 1: expansion -> depthwise -> squeeze-excite gates in ONE launch (csrc/sr_mbconv_fused.hip, r05).  OFF by default: measured
+# 47 / 80-90 / 93 us per block (stages 3 / 4 / 5, batch 8) against 52 / 78 / 53 us for the launch-per-operator path -- its
+# 16-channel slices re-read the block input 32-96 times from L2 and write half cache lines
+FUSE_MBCONV = os.environ.get("SR_MBCONV_FUSED", "0") == "1"
 STEM_CHANNELS = 24
 # (block type, repeats, stride, expansion, output channels, squeeze-excite ratio w.r.t. the block input)
 STAGES = (("cn", 2, 1, 1, 24, 0.0), ("er", 4, 2, 4, 48, 0.0), ("er", 4, 2, 4, 64, 0.0),
@@ -108,6 +112,10 @@ class InvertedResidual(nn.Module):
         self.has_skip = stride == 1 and cin == cout
 
     def forward(self, x):
+        if FUSE_MBCONV and ops.USE_PW_1X1 and FUSE_SE_GATE and ops.mbconv_fused_supported(x, self.conv_pw, self.conv_dw, self.se):
+            # r05: expansion -> depthwise -> squeeze-excite gates in ONE launch (csrc/sr_mbconv_fused.hip), then the projection
+            d, gate = ops.mbconv_expand_dw_se(x, self.conv_pw, self.bn1, self.conv_dw, self.bn2, self.se)
+            return ops.conv2d(d, self.conv_pwl, bn=self.bn3, residual=x if self.has_skip else None, gate=gate)
         t = ops.conv2d(x, self.conv_pw, bn=self.bn1, act="silu", library_gemm=True)
         d, pool = ops.dwconv3x3(t, self.conv_dw, bn=self.bn2, act="silu", tf_same=True, want_pool=True)
         if ops.USE_PW_1X1 and FUSE_SE_GATE:

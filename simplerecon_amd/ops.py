@@ -982,6 +982,50 @@ def se_gates(pool_partial, pixels, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2
     return gate
 
 
+_MBX_COUNTERS = {}   # device -> zeroed int32 arrival counters of sr_mbconv_expand_dw_se_fwd (the call leaves them zeroed)
+
+
+def mbconv_fused_supported(x, conv_pw: nn.Conv2d, conv_dw: nn.Conv2d, se):
+    """True when the one-launch front half (csrc/sr_mbconv_fused.hip) serves this MBConv block on this input."""
+    if conv_dw.stride != (1, 1) or tuple(conv_dw.padding) != (1, 1) or conv_pw.kernel_size != (1, 1):
+        return False
+    return bool(_shape_query(_lib.lib(), "sr_mbconv_fused_supported", x.shape[2], x.shape[3], conv_pw.in_channels,
+                             conv_pw.out_channels, se.conv_reduce.out_channels))
+
+
+def mbconv_expand_dw_se(x, conv_pw: nn.Conv2d, bn1, conv_dw: nn.Conv2d, bn2, se):
+    """MBConv front half in one launch: silu(bn1(conv_pw(x))) -> silu(bn2(conv_dw(.))) -> squeeze-excite gates.  Returns
+    (the depthwise output as a channels-last view, gates [B, mid]); the projection applies the gates (conv2d(..., gate=))."""
+    _lib.refuse_autograd(x, conv_pw.weight)
+    x = as_nhwc(x, "MBConv input")
+    b, ci, h, w = x.shape
+    mid, rd = conv_pw.out_channels, se.conv_reduce.out_channels
+    w_exp, b_exp = gemm_weight(conv_pw, bn1)
+    w9c, b_dw = packed_dw_weight(conv_dw, bn2)
+    w1, w2 = se.conv_reduce.weight.detach(), se.conv_expand.weight.detach()
+    if not (w1.is_contiguous() and w2.is_contiguous()):
+        w1, w2 = w1.contiguous(), w2.contiguous()
+    b1 = se.conv_reduce.bias.detach() if se.conv_reduce.bias is not None else None
+    b2 = se.conv_expand.bias.detach() if se.conv_expand.bias is not None else None
+    out = empty_nhwc(b, mid, h, w, x.device)
+    pool = torch.empty((b, mid), dtype=torch.float32, device=x.device)
+    gate = torch.empty((b, mid), dtype=torch.float32, device=x.device)
+    if b == 0:
+        return out, gate
+    cnt = _MBX_COUNTERS.get(x.device)
+    if cnt is None or cnt.numel() < b:
+        cnt = _MBX_COUNTERS[x.device] = torch.zeros(max(b, 64), dtype=torch.int32, device=x.device)
+    isb, isp = _strides(x)
+    osb, osp = _strides(out)
+    with _lib.on_device(x.device):
+        rc = _lib.lib().sr_mbconv_expand_dw_se_fwd(_lib.ptr(x), isb, isp, _lib.ptr(w_exp), _lib.ptr(b_exp), _lib.ptr(w9c),
+                                                   _lib.ptr(b_dw), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
+                                                   _lib.ptr(out), osb, osp, _lib.ptr(pool), _lib.ptr(gate), _lib.ptr(cnt), b, h, w,
+                                                   ci, mid, rd, _lib.stream_ptr(x.device))
+    _lib.check(rc, "sr_mbconv_expand_dw_se_fwd")
+    return out, gate
+
+
 def se_scale_(x, pool_partial, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2d, want_gate=False):
     """x *= squeeze-excite gate, in place on a channels-last view (se_gate + scale_channels_ in two short launches)."""
     _lib.require_device_f32("pool partial sums", pool_partial)

@@ -10,6 +10,7 @@ from torch import nn
 import oracle
 from parity import assert_close
 from simplerecon_amd import _lib, ops, synthetic
+from simplerecon_amd import image_encoder
 from simplerecon_amd.image_encoder import EfficientNetV2SFeatures
 
 pytestmark = pytest.mark.gpu
@@ -90,6 +91,46 @@ def test_dwconv_se_scale(shape, stride):
     assert_close(d, ref * g[:, :, None, None], what="gated depthwise output")
     assert_close(gate1, g, tol=1e-5, what="squeeze-excite gate (two-launch path)")
     assert_close(d1, ref * g[:, :, None, None], what="gated depthwise output (two-launch path)")
+
+
+@pytest.mark.parametrize("shape,mid", [((8, 128, 30, 40), 512), ((2, 160, 30, 40), 960), ((8, 256, 15, 20), 1536),
+                                       ((1, 128, 7, 9), 512), ((3, 160, 16, 20), 960)])
+def test_mbconv_front_half_in_one_launch(shape, mid):
+    """sr_mbconv_expand_dw_se_fwd (csrc/sr_mbconv_fused.hip, r05): 1x1 expansion + BN + SiLU -> depthwise 3x3 + BN + SiLU ->
+    squeeze-excite pool -> gates in ONE launch, against the oracle's restatement of the same operators and against the r04
+    launch-per-operator path; deterministic, and the arrival counters come back zeroed (the call can be repeated)."""
+    b, ci, h, w = shape
+    rng = np.random.default_rng(sum(shape) + mid)
+    x = rng.standard_normal(shape, dtype=np.float32)
+    pw = synthetic.seeded_fill_(nn.Conv2d(ci, mid, 1, bias=False), seed=ci).to(DEV)
+    bn1 = _bn(mid, seed=1).to(DEV)
+    dw = synthetic.seeded_fill_(nn.Conv2d(mid, mid, 3, padding=1, groups=mid, bias=False), seed=mid).to(DEV)
+    bn2 = _bn(mid, seed=2).to(DEV)
+    se = image_encoder.SqueezeExcite(mid, ci // 4)
+    synthetic.seeded_fill_(se, seed=7)
+    se = se.to(DEV)
+    xt = torch.from_numpy(x).to(DEV)
+    assert ops.mbconv_fused_supported(xt, pw, dw, se)
+    with torch.inference_mode():
+        d, gate = ops.mbconv_expand_dw_se(xt, pw, bn1, dw, bn2, se)
+        d2, gate2 = ops.mbconv_expand_dw_se(xt, pw, bn1, dw, bn2, se)
+        t = ops.conv2d(xt, pw, bn=bn1, act="silu")
+        d_ref, pool = ops.dwconv3x3(t, dw, bn=bn2, act="silu", tf_same=True, want_pool=True)
+        gate_ref = ops.se_gates(pool, h * w, se.conv_reduce, se.conv_expand)
+    torch.cuda.synchronize()
+    assert torch.equal(d, d2) and torch.equal(gate, gate2)
+    assert int(ops._MBX_COUNTERS[xt.device].abs().sum()) == 0
+    sd1 = {k_: _np(v) for k_, v in bn1.state_dict().items()}
+    sd2 = {k_: _np(v) for k_, v in bn2.state_dict().items()}
+    e = oracle.silu(oracle.batchnorm_eval(oracle.conv2d(x, _np(pw.weight), None), sd1, "", eps=1e-3))
+    ref = oracle.silu(oracle.batchnorm_eval(oracle.dwconv3x3_same(e, _np(dw.weight), 1), sd2, "", eps=1e-3))
+    assert_close(d, ref, what=f"fused expansion + depthwise {shape} -> {mid}")
+    assert_close(d, d_ref, tol=1e-5, what="fused vs launch-per-operator path")
+    mean = ref.mean(axis=(2, 3))
+    hid = oracle.silu(mean @ _np(se.conv_reduce.weight)[:, :, 0, 0].T + _np(se.conv_reduce.bias))
+    g = 1.0 / (1.0 + np.exp(-(hid @ _np(se.conv_expand.weight)[:, :, 0, 0].T + _np(se.conv_expand.bias))))
+    assert_close(gate, g, tol=1e-5, what="squeeze-excite gates")
+    assert_close(gate, gate_ref, tol=1e-5, what="gates vs the two-launch path")
 
 
 @pytest.mark.parametrize("shape,cout,res", [((8, 1536, 15, 20), 256, True), ((1, 1536, 15, 20), 256, False),
