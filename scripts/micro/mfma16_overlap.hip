@@ -29,6 +29,10 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, int roleLo,
   if (role == 1) {
     for (int it = 0; it < itA; ++it) {
       if (MF == 16) { REP16(c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c1, 0, 0, 0);) }
+      else if (MF == 165) { REP16(c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c0, 0, 0, 0); asm volatile("s_nop 6");
+                                  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c1, 0, 0, 0); asm volatile("s_nop 6");) }
+      else if (MF == 166) { REP16(c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c0, 0, 0, 0); asm volatile("s_nop 4");
+                                  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c1, 0, 0, 0); asm volatile("s_nop 4");) }
       else if (MF == 164) { REP4(REP4(c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c1, 0, 0, 0);
                                       c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c3, 0, 0, 0);)
                                  REP4(c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(seed, seed, c1, 0, 0, 0);
@@ -88,7 +92,7 @@ static void run(const char* kname, unsigned long long* d) {
   const double mf = MF == 164 ? 128.0 : 32.0;
   for (int prio = 0; prio < 2; ++prio) {
     hipLaunchKernelGGL((k<KIND, MF>), dim3(256), dim3(512), 0, 0, d, 1, 2, itA * 8, itB, 1.0f, prio);
-    snprintf(buf, sizeof buf, "[%s] next to a %s stream%s", kname, MF == 16 ? "16x16x4 (2 acc)" : MF == 164 ? "16x16x4 (4 acc)" : "32x32x2 (2 acc)",
+    snprintf(buf, sizeof buf, "[%s] next to a %s stream%s", kname, MF == 16 ? "16x16x4 (2 acc)" : MF == 164 ? "16x16x4 (4 acc)" : MF == 165 ? "16x16x4 + s_nop 6" : MF == 166 ? "16x16x4 + s_nop 4" : "32x32x2 (2 acc)",
              prio ? ", s_setprio 3" : ""); report(buf, d, itA * 8 * mf, nB);
   }
 }
@@ -98,7 +102,7 @@ int main() {
   hipMalloc(&d, 8 * 256 * 8);
   hipLaunchKernelGGL((k<0, 16>), dim3(256), dim3(512), 0, 0, d, 1, 0, 64, 0, 1.0f, 0); report("16x16x4 MFMA stream alone", d, 64 * 32.0, 0);
   hipLaunchKernelGGL((k<0, 32>), dim3(256), dim3(512), 0, 0, d, 1, 0, 64, 0, 1.0f, 0); report("32x32x2 MFMA stream alone", d, 64 * 32.0, 0);
-  run<0, 16>("v_fma_f32", d); run<0, 164>("v_fma_f32", d); run<0, 32>("v_fma_f32", d);
+  run<0, 16>("v_fma_f32", d); run<0, 165>("v_fma_f32", d); run<0, 166>("v_fma_f32", d); run<2, 165>("ds_read_b32 x8 + wait", d); run<0, 164>("v_fma_f32", d); run<0, 32>("v_fma_f32", d);
   run<2, 164>("ds_read_b32 x8 + wait", d); run<3, 164>("ds_write_b32 x8 + wait", d); run<4, 164>("ds_read2_b32 x4 + wait", d);
   run<1, 16>("v_pk_fma_f32", d); run<1, 32>("v_pk_fma_f32", d);
   run<2, 16>("ds_read_b32 x8 + wait", d); run<2, 32>("ds_read_b32 x8 + wait", d);
