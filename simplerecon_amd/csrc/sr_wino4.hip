@@ -591,7 +591,9 @@ __device__ __forceinline__ void w4_transform36_pk(const float* t_rd, float* t_wr
 }
 
 constexpr int W4_WS_RAW2 = 2 * W4_RAW_FLOATS;                       // V buffers start behind the two raw buffers
-constexpr int W4_WS_LDS_BYTES = (2 * W4_RAW_FLOATS + 2 * W4_V_FLOATS) * 4;   // 125 568
+constexpr int W4_WS_OUT = W4_WS_RAW2 + 2 * W4_V_FLOATS;                // the output hand-over buffer (half a region: 16 tiles x 8 pixels x 64 channels)
+constexpr int W4_WS_OUT_FLOATS = 16 * 8 * 64;
+constexpr int W4_WS_LDS_BYTES = (W4_WS_OUT + W4_WS_OUT_FLOATS) * 4;    // 158 336 of the CU's 163 840: one workgroup per CU
 
 // patch loads of the MFMA waves: interior regions take the precomputed lane offsets (no address arithmetic per slab)
 __device__ __forceinline__ void w4_stage_m(const SrWino4Params& p, const W4Item& it, int s, int st_q, int st_pp0,
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
       __syncthreads();   // ---- end of tick k
       W4_TR(3);
       if (closes) {
-        const char* OUT = reinterpret_cast<const char*>(lds + W4_WS_RAW2 + ((k - 1) & 1) * W4_V_FLOATS) + o_rd;
+        const char* OUT = reinterpret_cast<const char*>(lds + W4_WS_OUT) + o_rd;
         const unsigned out_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.out_sp + p.Cout) * 4);
         const __amdgpu_buffer_rsrc_t rs_out = w4_rsrc(p.out + (int64_t)eit.b * p.out_sb, out_img_bytes);
         const unsigned obase = (unsigned)((eit.oy0 * p.W + eit.ox0) * p.out_sp + eit.co0) * 4u;   // scalar
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) y[i] = *reinterpret_cast<const w4_f4*>(OUT + i * 16 * 64 * 4 + (o_cx ^ (32 * i)));
           }
-          __syncthreads();   // half h read: the M waves may write the next half / T(k + 1) may overwrite this V buffer
+          __syncthreads();   // half h read: the M waves may write the next half
           if (!(SR_W4_ABL & 4)) {
             float o[32];
 #pragma unroll
@@ -789,7 +791,8 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
         const W4Item nit = work < p.total ? w4_decode(p, work) : it;
         if (k < K) w4_u_prefetch(rs_u, u_voff, (SR_W4_ABL & 8) ? 0u : (unsigned)nit.co0 * 16u, u_fstride, ua);
         it = nit;
-        float* OUT = lds + W4_WS_RAW2 + ((k - 1) & 1) * W4_V_FLOATS + o_wr_off;
+        // (its own buffer, not the V buffer this wave has just consumed: the other M waves may still be reading that one)
+        float* OUT = lds + W4_WS_OUT + o_wr_off;
         if (SR_W4_ABL & 4) {
           w4_f4 sum = acc[0];
 #pragma unroll
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
 #pragma unroll
             for (int l = 0; l < 4; ++l) *reinterpret_cast<w4_f4*>(OUT + ((r - 2) * 4 + l) * 64) = acc[6 * r + l];
           __syncthreads();   // half 1 visible
-          __syncthreads();   // T has read half 1 (this V buffer is T(k + 1)'s target)
+          __syncthreads();   // T has read half 1 (the next closing tick writes the buffer again)
           W4_TR(7);
         }
 #pragma unroll

@@ -160,13 +160,15 @@ def test_full_size_hot_path_properties():
             return model.hot_path([f[sl] for f in pyr], inp["cur_feats"][sl], inp["src_feats"][sl],
                                   inp["src_extrinsics"][sl], inp["src_poses"][sl], inp["src_Ks"][sl],
                                   inp["cur_invK"][sl], return_mask=True)
-    a, b = run(), run()
+    # (six runs: at batch 2 the decoder's branches run on side HIP streams, and a kernel whose result depends on how its waves
+    # interleave -- r05: the first wave-specialised Winograd form -- differs in roughly two runs out of five, not in every one)
+    a, b, *more = [run() for _ in range(6)]
     one = run(slice(1, 2))
     for i in range(4):
         k = f"depth_pred_s{i}_b1hw"
         assert a[k].shape == (B, 1, (2 * h) >> i, (2 * w) >> i)
         assert torch.isfinite(a[k]).all() and bool((a[k] > 0).all())
-        assert torch.equal(a[k], b[k]), "hot path is not deterministic"
+        assert torch.equal(a[k], b[k]) and all(torch.equal(a[k], m[k]) for m in more), "hot path is not deterministic"
         assert torch.equal(a[k], torch.exp(a[k.replace("depth_", "log_depth_")]))
         # the cost volume is bitwise batch-independent (tests/test_gpu_mlp_volume.py); in the conv stack the launch
         # plan (split-K of the deep layers) depends on the batch size, hence the summation order: agreement, not identity

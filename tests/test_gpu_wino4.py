@@ -108,6 +108,43 @@ def test_wino4_is_deterministic_and_batch_independent():
     assert torch.equal(a[2:3], one)   # per-pixel arithmetic does not depend on the batch
 
 
+def test_ws_form_under_concurrent_streams():
+    """The wave-specialised form next to other kernels on side HIP streams (the decoder's branch parallelism at small batch,
+    networks.py DepthDecoderPP): co-resident workgroups of OTHER kernels take issue slots on some SIMDs of a CU and skew the
+    waves of a workgroup against each other; every output must still equal the quiet single-stream result of the 4-wave
+    form bit for bit.  (r05: the first version handed the finished tile over through the V buffer a wave had just consumed
+    while its sibling waves were still reading it -- run-to-run differences in tests/test_gpu_depth_model.py.)"""
+    torch.manual_seed(9)
+    shapes = [(2, 64, 120, 160, 64), (2, 128, 60, 80, 128), (1, 64, 240, 320, 64)]
+    cases = []
+    for (b, ci, h, w, co) in shapes:
+        conv = torch.nn.Conv2d(ci, co, 3, padding=1).to(DEV)
+        x = torch.randn(b, ci, h, w, device=DEV).contiguous(memory_format=torch.channels_last)
+        res = torch.randn(b, co, h, w, device=DEV).contiguous(memory_format=torch.channels_last)
+        with torch.inference_mode():
+            want = _run("w4", x, conv, res, 0.2).clone()
+            _run("w2", x, conv, res, 0.2)   # (packs the F(2x2) weights outside the concurrent part)
+        cases.append((conv, x, res, want))
+    noise = torch.randn(1 << 22, device=DEV)
+    torch.cuda.synchronize()
+    main, s1, s2 = (torch.cuda.Stream(device=DEV) for _ in range(3))
+    outs = [[] for _ in cases]
+    with torch.inference_mode():
+        for rep in range(10):
+            for i, (conv, x, res, _) in enumerate(cases):
+                with torch.cuda.stream(s1):      # few-wave workgroups with little LDS: they fit next to the 8-wave workgroup
+                    for _ in range(4):
+                        noise = torch.sin(noise) * 1.0001
+                with torch.cuda.stream(s2):
+                    _run("w2", cases[(i + 1) % len(cases)][1], cases[(i + 1) % len(cases)][0], None, 0.2)
+                with torch.cuda.stream(main):
+                    outs[i].append(_run("w4_ws", x, conv, res, 0.2))
+    torch.cuda.synchronize()
+    for i, (_, _, _, want) in enumerate(cases):
+        for rep, got in enumerate(outs[i]):
+            assert torch.equal(got, want), f"shape {shapes[i]}, repetition {rep}: {int((got != want).sum())} elements differ"
+
+
 @pytest.mark.parametrize("act", [None, 0.0, 0.2, "silu"])
 def test_wino4_activation_codes(act):
     torch.manual_seed(8)
