@@ -440,6 +440,57 @@ __global__ void sr_upsample2x_kernel(const float* __restrict__ in, int64_t in_sb
   }
 }
 
+// The same operator, one thread per 2 x 2 block of OUTPUT pixels x 4 channels (r05).  Output rows 2y + 1, 2y + 2 and columns
+// 2x + 1, 2x + 2 interpolate between the same four input pixels (y, y + 1) x (x, x + 1) with weights 3/4, 1/4 (rows / columns
+// 0 and 2H - 1 / 2W - 1: the clamped border, blocks y = -1, x = -1 and y = H - 1, x = W - 1 hold one row / column): 4 loads
+// for 4 stores instead of 16, one index computation instead of four.  Per output the source positions and weights come from
+// the same expressions as in sr_upsample2x_kernel (same rounding, identical results).  Grid: y = (image, block row), x = the
+// (W + 1) * cq threads of a block row; write-bound: 4 bytes written per byte read.
+__global__ __launch_bounds__(256) void sr_upsample2x_quad_kernel(const float* __restrict__ in, int64_t in_sb, int in_sp,
+                                                                 float* __restrict__ out, int64_t out_sb, int out_sp, int B,
+                                                                 int H, int W, int cq) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (W + 1) * cq) return;
+  const int q = t % cq, bx = t / cq - 1;
+  const int xa = min(max(bx, 0), W - 1), xb = min(xa + 1, W - 1);
+  float lx[2], hx[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const float sx = fmaxf(((float)(2 * bx + 1 + r) + 0.5f) * 0.5f - 0.5f, 0.0f);
+    lx[r] = sx - (float)xa;
+    hx[r] = 1.0f - lx[r];
+  }
+  for (int row = blockIdx.y; row < B * (H + 1); row += gridDim.y) {
+    const int b = row / (H + 1), by = row - b * (H + 1) - 1;   // (scalar)
+    const int ya = min(max(by, 0), H - 1), yb = min(ya + 1, H - 1);
+    const float* ib = in + (int64_t)b * in_sb + 4 * q;
+    const float4 a = *reinterpret_cast<const float4*>(ib + ((int64_t)ya * W + xa) * in_sp);
+    const float4 bq = *reinterpret_cast<const float4*>(ib + ((int64_t)ya * W + xb) * in_sp);
+    const float4 c = *reinterpret_cast<const float4*>(ib + ((int64_t)yb * W + xa) * in_sp);
+    const float4 d = *reinterpret_cast<const float4*>(ib + ((int64_t)yb * W + xb) * in_sp);
+    float* ob = out + (int64_t)b * out_sb + 4 * q;
+#pragma unroll
+    for (int ry = 0; ry < 2; ++ry) {
+      const int oy = 2 * by + 1 + ry;
+      if (oy < 0 || oy >= Ho) continue;   // (uniform)
+      const float sy = fmaxf(((float)oy + 0.5f) * 0.5f - 0.5f, 0.0f);
+      const float ly = sy - (float)ya, hy = 1.0f - ly;
+#pragma unroll
+      for (int rx = 0; rx < 2; ++rx) {
+        const int ox = 2 * bx + 1 + rx;
+        if (ox < 0 || ox >= Wo) continue;
+        float4 r;
+        r.x = hy * (hx[rx] * a.x + lx[rx] * bq.x) + ly * (hx[rx] * c.x + lx[rx] * d.x);
+        r.y = hy * (hx[rx] * a.y + lx[rx] * bq.y) + ly * (hx[rx] * c.y + lx[rx] * d.y);
+        r.z = hy * (hx[rx] * a.z + lx[rx] * bq.z) + ly * (hx[rx] * c.z + lx[rx] * d.z);
+        r.w = hy * (hx[rx] * a.w + lx[rx] * bq.w) + ly * (hx[rx] * c.w + lx[rx] * d.w);
+        *reinterpret_cast<float4*>(ob + ((int64_t)oy * Wo + ox) * out_sp) = r;
+      }
+    }
+  }
+}
+
 // depth = exp(log_depth) (reference depth_model.py:392-400), elementwise
 __global__ __launch_bounds__(256) void sr_exp_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -716,6 +767,14 @@ extern "C" int sr_upsample2x_nhwc_fwd(const float* in, int64_t in_batch_stride, 
   if (!in || !out) return SR_ERR_INVALID_ARGUMENT;
   const int vec4 = (((uintptr_t)in & 15) == 0) && (((uintptr_t)out & 15) == 0) && (in_pix_stride % 4 == 0) &&
                    (out_pix_stride % 4 == 0) && (in_batch_stride % 4 == 0) && (out_batch_stride % 4 == 0);
+  if (vec4 && C % 4 == 0 && sr_opt(SR_OPT_UPSAMPLE_QUAD)) {
+    const int cq = C / 4;
+    const int64_t rows = (int64_t)B * (H + 1);
+    hipLaunchKernelGGL(sr_upsample2x_quad_kernel, dim3(((W + 1) * cq + 255) / 256, (unsigned)(rows < 65535 ? rows : 65535)),
+                       dim3(256), 0, (hipStream_t)stream_, in, in_batch_stride, in_pix_stride, out, out_batch_stride,
+                       out_pix_stride, B, H, W, cq);
+    return sr_hip_rc(hipGetLastError());
+  }
   const int64_t total = (int64_t)4 * H * W * ((C + 3) / 4);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(sr_upsample2x_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream_, in, in_batch_stride,

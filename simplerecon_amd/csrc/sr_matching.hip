@@ -271,6 +271,130 @@ __global__ __launch_bounds__(256) void sr_maxblurpool_kernel(const float* __rest
   }
 }
 
+// The streaming form (r05).  The block kernel above reads 12.25 float4 per output (its 7 x 7 windows overlap by 3 rows and 3
+// columns) and leaves the vertical overlap to the L2; ATen's plain streams reach 6 TB/s on this map (scripts/micro/
+// hbm_ceiling.py), the block kernel 3.4.  Here a thread owns 2 output columns x 4 channels and WALKS DOWN a band of output
+// rows: per output row it loads two new input rows of 7 pixels (7 float4 per output), the previous input row and the two
+// partial output rows live in registers, the next iteration's 14 loads are issued before this iteration's arithmetic.  A
+// workgroup = 16 column blocks x 16 channel quads: every row step reads 67 consecutive pixels (17 KB), every output step
+// writes 32 (8 KB).  Same operations in the same order per output as the block kernel (vertical max, horizontal max, horizontal
+// blur j = 0..3, vertical blur i = 0..3): bit-identical.  Only outputs whose window needs no reflection take this path (rows
+// 1 .. (H-4)/2, columns 1 .. (W-4)/2); the frame around them goes through sr_maxblur_generic in the trailing workgroups of the
+// same launch.  Measured (64 images, [64,64,240,320] -> [64,64,120,160], 1.57 GB): 315-337 us = 4.7-5.0 TB/s (block kernel 460 us =
+// 3.4 TB/s); non-temporal loads: 392 us (the 3-column overlap of neighbouring threads is served by the L1 / L2 they bypass).
+struct SrPoolStreamParams {
+  const float* in; int64_t in_sb; int in_sp;
+  float* out; int64_t out_sb; int out_sp;
+  int H, W, Ho, Wo, C4;
+  int oy_lo, oy_hi, ox_lo, ox_hi;     // the streamed outputs: [oy_lo, oy_hi] x [ox_lo, ox_hi]
+  int bands, band_rows, col_blocks, col_groups;   // col_blocks = ceil(columns / 2), col_groups = ceil(col_blocks * C4 / 256)
+  int stream_wgs;                     // workgroups 0 .. stream_wgs - 1 stream, the rest take the frame
+  int frame_rows_top, frame_rows_bottom, frame_cols_left, frame_cols_right;
+};
+
+// (explicit fused multiply-adds: left to -ffp-contract the compiler fuses `f0 h0 + f1 h1` as fma(f1, h1, f0 h0) in the loop
+// body and as fma(f0, h0, f1 h1) in the peeled first iteration -- 1 ulp apart; this is the form the block kernel compiles to)
+__device__ __forceinline__ float4 sr_fma4(float s, float4 a, float4 acc) {
+  return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
+}
+__device__ __forceinline__ float4 sr_scale4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+__global__ __launch_bounds__(256) void sr_maxblurpool_stream_kernel(SrPoolStreamParams p) {
+  const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+  const float* __restrict__ ib = p.in + (int64_t)blockIdx.y * p.in_sb;
+  float* __restrict__ ob = p.out + (int64_t)blockIdx.y * p.out_sb;
+  if ((int)blockIdx.x >= p.stream_wgs) {
+    // ---- the frame: rows [0, oy_lo) and (oy_hi, Ho) at full width, columns [0, ox_lo) and (ox_hi, Wo) of the streamed rows
+    const int Hm = p.H - 1, Wm = p.W - 1;
+    const int full_rows = p.frame_rows_top + p.frame_rows_bottom, side = p.frame_cols_left + p.frame_cols_right;
+    const int n_full = full_rows * p.Wo, n_side = (p.oy_hi - p.oy_lo + 1) * side;
+    const int64_t total = (int64_t)(n_full + n_side) * p.C4;
+    for (int64_t idx = (int64_t)((int)blockIdx.x - p.stream_wgs) * 256 + threadIdx.x; idx < total;
+         idx += (int64_t)((int)gridDim.x - p.stream_wgs) * 256) {
+      const int c4 = (int)(idx % p.C4);
+      const int px = (int)(idx / p.C4);
+      int oy, ox;
+      if (px < n_full) {
+        const int r = px / p.Wo;
+        ox = px - r * p.Wo;
+        oy = r < p.frame_rows_top ? r : p.oy_hi + 1 + (r - p.frame_rows_top);
+      } else {
+        const int q = px - n_full, r = q / side, c = q - r * side;
+        oy = p.oy_lo + r;
+        ox = c < p.frame_cols_left ? c : p.ox_hi + 1 + (c - p.frame_cols_left);
+      }
+      *reinterpret_cast<float4*>(ob + ((int64_t)oy * p.Wo + ox) * p.out_sp + 4 * c4) =
+          sr_maxblur_generic(ib, p.in_sp, p.W, Hm, Wm, oy, ox, c4);
+    }
+    return;
+  }
+  const int band = (int)blockIdx.x / p.col_groups, cg = (int)blockIdx.x - band * p.col_groups;
+  const int t = cg * 256 + (int)threadIdx.x;
+  const int c4 = t % p.C4, cb = t / p.C4;
+  if (cb >= p.col_blocks) return;
+  const int ox0 = p.ox_lo + 2 * cb;
+  const bool two = ox0 + 1 <= p.ox_hi;                       // the last block of an odd column count holds one output
+  const int oy_first = p.oy_lo + band * p.band_rows;
+  const int oy_last = min(oy_first + p.band_rows - 1, p.oy_hi);
+  if (oy_first > oy_last) return;
+  const int x0 = 2 * ox0 - 1;                                // first max-pooled (= input) column of the window
+  int xo[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) xo[j] = min(x0 + j, p.W - 1) * p.in_sp + 4 * c4;   // (clamped: only a one-output block gets there)
+  // input rows: max-pooled row m = max(input rows m, m + 1); output oy blurs max-pooled rows 2 oy - 1 .. 2 oy + 2
+  const float* q = ib + (int64_t)(2 * oy_first - 1) * p.W * p.in_sp;
+  const int64_t rs = (int64_t)p.W * p.in_sp;
+  float4 prev[7], cur[2][7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) prev[j] = sr_ld4(q + xo[j]);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) { cur[0][j] = sr_ld4(q + rs + xo[j]); cur[1][j] = sr_ld4(q + 2 * rs + xo[j]); }
+  q += 3 * rs;
+  float4 acc_old[2], acc_new[2];
+  acc_old[0] = acc_old[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int n = oy_last - oy_first + 1;
+  for (int it = 0; it <= n; ++it) {           // iteration it: max-pooled rows 2 oy - 1, 2 oy of oy = oy_first + it
+    float4 nxt[2][7];
+    if (it < n) {                             // (the rows of iteration it + 1; iteration n needs rows 2 oy_last + 2, + 3: in range)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) { nxt[0][j] = sr_ld4(q + xo[j]); nxt[1][j] = sr_ld4(q + rs + xo[j]); }
+      q += 2 * rs;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float4 vm[7], mp[6];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) { vm[j] = sr_max4(prev[j], cur[r][j]); prev[j] = cur[r][j]; }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) mp[j] = sr_max4(vm[j], vm[j + 1]);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        float4 h = sr_scale4(f[0], mp[2 * b2]);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) h = sr_fma4(f[j], mp[2 * b2 + j], h);
+        if (r == 0) {
+          acc_new[b2] = sr_scale4(f[0], h);
+          acc_old[b2] = sr_fma4(f[2], h, acc_old[b2]);
+        } else {
+          acc_new[b2] = sr_fma4(f[1], h, acc_new[b2]);
+          acc_old[b2] = sr_fma4(f[3], h, acc_old[b2]);
+        }
+      }
+    }
+    if (it >= 1) {
+      float* o = ob + ((int64_t)(oy_first + it - 1) * p.Wo + ox0) * p.out_sp + 4 * c4;
+      *reinterpret_cast<float4*>(o) = acc_old[0];
+      if (two) *reinterpret_cast<float4*>(o + p.out_sp) = acc_old[1];
+    }
+    acc_old[0] = acc_new[0];
+    acc_old[1] = acc_new[1];
+    if (it < n) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) { cur[0][j] = nxt[0][j]; cur[1][j] = nxt[1][j]; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ InstanceNorm2d (+ LeakyReLU) ----------------
 //
 // Per (image, channel) statistics over H*W, biased variance, no affine (nn.InstanceNorm2d defaults; reference
@@ -780,6 +904,39 @@ extern "C" int sr_maxblurpool_nhwc_fwd(const float* in, int64_t in_batch_stride,
       ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
     return SR_ERR_UNSUPPORTED;
   const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
+  if (sr_opt(SR_OPT_POOL_STREAM) && H >= 16 && W >= 16 && B <= 65535) {
+    SrPoolStreamParams p;
+    p.in = in; p.in_sb = in_batch_stride; p.in_sp = in_pix_stride;
+    p.out = out; p.out_sb = out_batch_stride; p.out_sp = out_pix_stride;
+    p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.C4 = C / 4;
+    p.oy_lo = 1; p.oy_hi = (H - 4) / 2; p.ox_lo = 1; p.ox_hi = (W - 4) / 2;   // 2 o - 1 >= 0 and 2 o + 3 <= size - 1
+    const int rows = p.oy_hi - p.oy_lo + 1, cols = p.ox_hi - p.ox_lo + 1;
+    p.col_blocks = (cols + 1) / 2;
+    p.col_groups = (int)(((int64_t)p.col_blocks * p.C4 + 255) / 256);
+    // bands: two workgroups are resident per CU (176 registers); pick the band count whose workgroups fill whole rounds of those
+    // slots (a band of r output rows reads 2 r + 3 input rows), at most ~10 rounds, at least 8 rows per band
+    const int slots = 2 * sr_cus(), per_band = B * p.col_groups;
+    int best_bands = 1;
+    double best = -1.0;
+    for (int nb = 1; nb <= (rows >= 8 ? rows / 8 : 1); ++nb) {
+      const int br = (rows + nb - 1) / nb, real = (rows + br - 1) / br;
+      const int64_t wgs = (int64_t)real * per_band;
+      const int64_t rounds = (wgs + slots - 1) / slots;
+      if (rounds > 10 && best >= 0.0) break;
+      const double eff = (double)wgs / (double)(rounds * slots) * (2.0 * br) / (2.0 * br + 3.0);
+      if (eff > best + 1e-9) { best = eff; best_bands = real; }
+    }
+    p.band_rows = (rows + best_bands - 1) / best_bands;
+    p.bands = (rows + p.band_rows - 1) / p.band_rows;
+    p.stream_wgs = p.bands * p.col_groups;
+    p.frame_rows_top = p.oy_lo; p.frame_rows_bottom = Ho - 1 - p.oy_hi;
+    p.frame_cols_left = p.ox_lo; p.frame_cols_right = Wo - 1 - p.ox_hi;
+    const int64_t frame = ((int64_t)(p.frame_rows_top + p.frame_rows_bottom) * Wo +
+                           (int64_t)rows * (p.frame_cols_left + p.frame_cols_right)) * p.C4;
+    int frame_wgs = (int)((frame + 255) / 256 < 1024 ? (frame + 255) / 256 : 1024);
+    hipLaunchKernelGGL(sr_maxblurpool_stream_kernel, dim3(p.stream_wgs + frame_wgs, B), dim3(256), 0, (hipStream_t)stream_, p);
+    return sr_hip_rc(hipGetLastError());
+  }
   int bw = 2;   // output columns per thread.  4 (SR_POOL_BW=4, Wo % 4 == 0) issues 9.6 instead of 12.25 loads per output and is
   if (sr_opt(SR_OPT_POOL_BW) == 4 && Wo % 4 == 0) bw = 4;   // SLOWER: 0.70 vs 0.45 ms per 64 images
                                                                                             // (half the threads, twice the registers)

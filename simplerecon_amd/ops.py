@@ -691,14 +691,18 @@ def stem7x7(image, conv: nn.Conv2d, bn=None, leaky=0.0, out=None):
     return out
 
 
-def maxblurpool(x):
-    """nn.MaxPool2d(2, stride=1) + antialiased_cnns.BlurPool(filt_size=4, stride=2), fused; channels-last."""
+def maxblurpool(x, out=None):
+    """nn.MaxPool2d(2, stride=1) + antialiased_cnns.BlurPool(filt_size=4, stride=2), fused; channels-last (`out`: a
+    channels-last view to write into, e.g. a channel slice of a larger buffer)."""
     x = as_nhwc(x, "maxblurpool input")
     b, c, h, w = x.shape
     if h < 4 or w < 4:
         raise ValueError(f"maxblurpool needs H, W >= 4, got {(h, w)}")
     ho, wo = (h - 2) // 2 + 1, (w - 2) // 2 + 1
-    out = empty_nhwc(b, c, ho, wo, x.device)
+    if out is None:
+        out = empty_nhwc(b, c, ho, wo, x.device)
+    elif tuple(out.shape) != (b, c, ho, wo) or not _is_nhwc_view(out):
+        raise ValueError(f"`out` must be a channels-last view of shape {(b, c, ho, wo)}")
     if b == 0:
         return out
     isb, isp = _strides(x)

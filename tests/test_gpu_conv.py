@@ -55,6 +55,32 @@ def test_upsample():
     assert_close(y, oracle.upsample2x(x.numpy()), tol=1e-6, what="upsample2x vs oracle")
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 1, 1), (2, 64, 7, 5), (1, 16, 1, 9), (3, 12, 6, 1), (2, 64, 30, 40), (1, 256, 15, 20)])
+def test_upsample_block_form_equals_the_per_pixel_kernel(shape, sr_option):
+    """r05: one thread per 2 x 2 output block (4 loads for 4 stores) against ATen's bilinear x2 (align_corners=False) and, bit
+    for bit, against the per-pixel kernel: 1-pixel maps, odd sizes, a concat-slice destination, non-finite inputs (the
+    clamped border multiplies its second row / column by 0 in both kernels, as ATen does)."""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    b, c, h, w = shape
+    with torch.inference_mode():
+        sr_option("SR_UPSAMPLE_QUAD", 1)
+        y = ops.upsample2x(x)
+        buf = ops.empty_nhwc(b, c + 8, 2 * h, 2 * w, DEV).fill_(3.0)
+        ops.upsample2x(x, out=buf[:, 4:4 + c])
+        xn = x.clone()
+        xn[0, 0, h - 1, w - 1] = float("inf")
+        xn[0, -1, 0, 0] = float("nan")
+        yn = ops.upsample2x(xn)
+        sr_option("SR_UPSAMPLE_QUAD", 0)
+        y0, yn0 = ops.upsample2x(x), ops.upsample2x(xn)
+    ref = torch.nn.functional.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    assert_close(y, ref, tol=1e-6, what=f"upsample2x {shape}")
+    assert torch.equal(y, y0)
+    assert torch.equal(buf[:, 4:4 + c], y) and bool((buf[:, :4] == 3).all()) and bool((buf[:, 4 + c:] == 3).all())
+    assert torch.equal(torch.isnan(yn), torch.isnan(yn0)) and torch.equal(yn.nan_to_num(7.0, 8.0, 9.0), yn0.nan_to_num(7.0, 8.0, 9.0))
+
+
 @pytest.mark.parametrize("name", list(gc.NET_CASES))
 def test_encoder_decoder(name):
     case = gc.NET_CASES[name]

@@ -69,6 +69,31 @@ def test_maxblurpool(shape):
     assert_close(y, ref, tol=1e-6, what=f"maxblurpool {shape}")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (1, 8, 17, 23), (3, 64, 48, 64), (2, 16, 37, 18), (1, 64, 240, 320), (2, 4, 19, 16)])
+def test_maxblurpool_streaming_form_equals_the_block_kernel(shape, sr_option):
+    """r05: the row-streaming kernel (2 output columns x 4 channels per thread walking down a band of rows; frame pixels in
+    trailing workgroups of the same launch) against the oracle and, bit for bit, against the block kernel it replaces --
+    odd / even sizes (one-output column blocks, clamped loads), several bands, writes into / reads from channel slices."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape, dtype=np.float32)
+    xd = torch.from_numpy(x).to(DEV)
+    with torch.inference_mode():
+        sr_option("SR_POOL_STREAM", 1)
+        y = ops.maxblurpool(xd)
+        buf_in = ops.empty_nhwc(shape[0], shape[1] + 8, shape[2], shape[3], DEV).normal_()
+        buf_in[:, 4:4 + shape[1]] = xd
+        ho, wo = y.shape[2], y.shape[3]
+        buf_out = ops.empty_nhwc(shape[0], shape[1] + 12, ho, wo, DEV).fill_(5.0)
+        ops.maxblurpool(buf_in[:, 4:4 + shape[1]], out=buf_out[:, 8:8 + shape[1]])
+        sr_option("SR_POOL_STREAM", 0)
+        y0 = ops.maxblurpool(xd)
+    torch.cuda.synchronize()
+    assert_close(y, oracle.blurpool4_s2(oracle.maxpool2_s1(x)), tol=1e-6, what=f"streaming maxblurpool {shape}")
+    assert torch.equal(y, y0), f"{int((y != y0).sum())} elements differ from the block kernel"
+    assert torch.equal(buf_out[:, 8:8 + shape[1]], y)
+    assert bool((buf_out[:, :8] == 5).all()) and bool((buf_out[:, 8 + shape[1]:] == 5).all())
+
+
 @pytest.mark.parametrize("shape,leaky", [((2, 128, 10, 18), 0.2), ((3, 16, 30, 40), None), ((1, 16, 120, 160), None),
                                          ((1, 48, 7, 5), 0.2), ((2, 128, 120, 160), 0.2)])
 def test_instance_norm(shape, leaky):
@@ -161,9 +186,11 @@ def test_batchnorm_fold_matches_unfolded_oracle():
     assert_close(y_shift, ref2, tol=1e-5, what="conv + folded BatchNorm after a buffer update")
 
 
-def test_full_size_properties():
+def test_full_size_properties(monkeypatch):
     """640x480 images (BASELINE cfg2/3 size): InstanceNorm'd outputs have zero mean / unit variance per image and
-    channel, and every image is processed independently of its batch neighbours (bitwise)."""
+    channel, and every image is processed independently of its batch neighbours -- bitwise while the launch plan is the same;
+    since r05 the 3x3 layers take F(4x4) or F(2x2) Winograd by how well the batch fills the chip (csrc/sr_wino4.hip,
+    sr_conv_prefers_wino4: 3 images = 240 work items -> F(4x4), 1 image = 80 -> F(2x2)), and then to the fp32 bar."""
     enc = synthetic.seeded_fill_(ResnetMatchingEncoder(18, 16), seed=1).to(DEV).eval()
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn((3, 3, 480, 640), generator=g).to(DEV)
@@ -171,7 +198,13 @@ def test_full_size_properties():
         y = enc(x)
         y1 = enc(x[1:2])
     assert tuple(y.shape) == (3, 16, 120, 160)
-    assert torch.equal(y[1:2], y1)
+    assert_close(y1, y[1:2], tol=1e-5, what="image 1 alone vs inside the batch (F(2x2) vs F(4x4) layer1)")
+    with monkeypatch.context() as mp:
+        mp.setattr(ops, "WINO4_MODE", 0)     # the same kernel at both batch sizes: bit for bit
+        with torch.inference_mode():
+            z, z1 = enc(x), enc(x[1:2])
+    assert torch.equal(z[1:2], z1)
+    assert_close(y, z, tol=1e-5, what="F(4x4) vs F(2x2) layer1")
     m = y.double().mean(dim=(2, 3))
     v = y.double().var(dim=(2, 3), unbiased=False)
     assert float(m.abs().max()) < 1e-4 and float((v - 1).abs().max()) < 1e-3, (float(m.abs().max()), float((v - 1).abs().max()))

@@ -57,12 +57,14 @@ def test_error_against_fp64_next_to_the_fp32_kernel(shape, monkeypatch, sr_optio
     """f16 pieces (weights pre-scaled by 2^8): as close to an fp64 convolution as the fp32-MFMA kernel (measured: 0.9-1.0 x its
     rms error); bf16 pieces: 16-18 bits, ~25 x the fp32 kernel's rms error -- still 1e-6 of the output range."""
     B, ci, H, W, co = shape
+    monkeypatch.setattr(ops, "WINO4_MODE", 0)   # "the fp32 kernel" = F(2x2) sr_wino_kernel, the one the split kernels restate
     g = torch.Generator().manual_seed(ci + H)
     conv = torch.nn.Conv2d(ci, co, 3, padding=1).to(DEV)
     x = torch.randn((B, ci, H, W), generator=g).to(DEV)
     res = torch.randn((B, co, H, W), generator=g).to(DEV)
-    ref = torch.nn.functional.leaky_relu(
-        torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double(), 0.2)
+    with torch.no_grad():
+        ref = torch.nn.functional.leaky_relu(
+            torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1) + res.double(), 0.2)
     rms = {}
     for mode in ("0", "bf16", "f16"):
         sr_option("SR_WINO_SPLIT", mode)
