@@ -590,6 +590,39 @@ __device__ __forceinline__ void w4_transform36_pk(const float* t_rd, float* t_wr
   }
 }
 
+// The same transform with BOTH halves of the wave on one (tile, channel pair): lanes 0-31 take patch columns 0-2 of the column
+// pass and rows 0-2 of the row pass, lanes 32-63 columns / rows 3-5; between the passes 18 v_permlane32_swap hand each half
+// the three columns of its rows that the other half computed.  Per slab and wave 18 + 18 LDS accesses, 72 packed operations
+// and 18 swaps instead of 36 + 36 and 144 -- the T waves' instructions are matrix-pipe time (see above).  Same operations on
+// the same values: bit-identical.  t_rd / t_wr carry the half's offset (3 columns of the patch / 18 frequencies).
+__device__ __forceinline__ void w4_transform36_split(const float* t_rd, float* t_wr) {
+  if (SR_W4_ABL & 1) return;
+  w4_f2 T[6][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    w4_f2 d[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const w4_f2*>(t_rd + (r * W4_PS + k) * W4_RS);
+    w4_bt2(d[0], d[1], d[2], d[3], d[4], d[5], T[0][k], T[1][k], T[2][k], T[3][k], T[4][k], T[5][k]);
+  }
+#pragma unroll
+  for (int ii = 0; ii < 3; ++ii) {
+    w4_f2 R[6], v[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        // new a = [a.lo | b.lo], new b = [a.hi | b.hi]: a = row ii (lower half's), b = row 3 + ii (upper half's)
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(T[ii][k][e]), __float_as_uint(T[3 + ii][k][e]), false, false);
+        R[k][e] = __uint_as_float(r[0]);
+        R[3 + k][e] = __uint_as_float(r[1]);
+      }
+    w4_bt2(R[0], R[1], R[2], R[3], R[4], R[5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<w4_f2*>(t_wr + (ii * 6 + j) * 256) = v[j];
+  }
+}
+
 constexpr int W4_WS_RAW2 = 2 * W4_RAW_FLOATS;                       // V buffers start behind the two raw buffers
 constexpr int W4_WS_OUT = W4_WS_RAW2 + 2 * W4_V_FLOATS;                // the output hand-over buffer (half a region: 16 tiles x 8 pixels x 64 channels)
 constexpr int W4_WS_OUT_FLOATS = 16 * 8 * 64;
@@ -630,13 +663,13 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
 
   if (role_t) {
     // ================= T waves: transform + output side
-    // transform role: work item (tile, channel pair) = 32 * wave + lane for lanes 0-31 of every T wave
-    const bool t_on = lane < 32;
-    const int t_item = 32 * wave + (lane & 31);
+    // transform role: work item (tile, channel pair) = 32 * wave + (lane & 31); the two halves of the wave share it
+    // (w4_transform36_split: columns / rows 0-2 in lanes 0-31, 3-5 in lanes 32-63)
+    const int t_item = 32 * wave + (lane & 31), t_half = lane >> 5;
     const int t_ci = 2 * (t_item & 7), t_tile = t_item >> 3;
     const int t_sig = (0x1230 >> (t_tile & 12)) & 3;
-    const int t_rd_off = ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3)) * W4_RS + t_ci;
-    const int t_wr_off = W4_WS_RAW2 + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
+    const int t_rd_off = ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3) + 3 * t_half) * W4_RS + t_ci;
+    const int t_wr_off = W4_WS_RAW2 + t_half * 18 * 256 + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
     // output role: channel quad o_c of the pixels pxl_i = (tid >> 4) + 16 i, i = 0 .. 7, of a half tile (16 tiles x 2 x 4 pixels:
     // pxl = 8 tile + 4 kk + l).  With t0 = tid >> 7, kk = (tid >> 6) & 1, l = (tid >> 4) & 3:  tile_i = t0 + 2 i, so pixel i of half h
     // sits at row 4 (i >> 1) + 2 h + kk, column 4 t0 + 8 (i & 1) + l of the region: ONE lane offset per tensor (row kk, column
@@ -676,7 +709,7 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
           }
       }
       W4_TR(1);
-      if (k < K && t_on) w4_transform36_pk(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off);
+      if (k < K) w4_transform36_split(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off);
       W4_TR(2);
       __syncthreads();   // ---- end of tick k
       W4_TR(3);
