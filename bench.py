@@ -229,6 +229,7 @@ def main():
     if collective:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    _flush_c_stdio()   # (every rank, before rank 0 prints: whatever the collective library buffered goes out ahead of the JSON line)
 
     frames = world * wl.frames_per_step * args.steps
     out = {
@@ -268,10 +269,21 @@ def main():
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         if world == 1 and name == bench_workloads.DEFAULT and args.experiments and not args.no_experiments:
             out["experiments"] = [_fenced_experiment("hero_cfg3_f16x3_convs", min(args.steps, 10), args.warmup)]
+        _flush_c_stdio()
         print(json.dumps(out), flush=True)
     if collective:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _flush_c_stdio():
+    """RCCL writes its version banner through C stdio; on a pipe that buffer is flushed at process exit, i.e. AFTER the JSON
+    line.  Flushing it first keeps the JSON line the last line of rank 0's stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":
