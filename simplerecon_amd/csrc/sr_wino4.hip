@@ -936,6 +936,10 @@ extern "C" int sr_wino4_pack_weights(const float* weight, int Cout, int Cin, flo
 //   * one round of 150-256 items (60x80 / 30x40 levels at batch 8): the wave-specialised form wins by ~16 % (one workgroup
 //     per CU has no second-round tail; F(2x2)'s 8x16 regions leave more of the chip idle there);
 //   * everything else (two partial rounds, < 150 items, 15x20 maps, batch 1): F(2x2) with its split-K plans stays.
+// (Measured and rejected at the end of r05, after the transform waves' split transform: widening the rule to what the isolated
+// sweep then favoured -- the wave-specialised form also for Cin 65..128 and for the 320-item 60x80 layers -- made the STEP slower,
+// 27.17-27.19 against 26.98-27.09 ms on one box: a 158-KB workgroup shares its CU with nothing, and the decoder's three branch
+// streams fill each other's tails only with the smaller kernels.)
 // `mode` 0: never, 1: this rule, 2: the 4-wave form wherever the kernel applies (tests).
 extern "C" int sr_conv_prefers_wino4(int B, int H, int W, int Cin, int Cout, int mode) {
   if (mode == 0 || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 4 != 0 || Cout % 4 != 0) return 0;
