@@ -9,7 +9,7 @@ Reference path: experiment_modules/depth_model.py:358-405 (what bench.py times a
 Batch 1 is checked in full; of a batch of 8 (the timed batch size: other tile plans, no split-K) frames 0 and 7.
 Checked per frame: the cost volume, `lowest_cost`, `overall_mask`, every CVEncoder level, all four
 `log_depth_pred_s*` / `depth_pred_s*` at 1e-4 range-relative, and element-wise p99 < 1.5e-5 / max < 3e-5 on `depth_pred_s0`
-(2x what is measured; every measured error is written to gpurun_out/parity_e2e.json -> profiles/r04_parity.json).
+(2x what is measured; every measured error is written to gpurun_out/parity_e2e.json -> profiles/r04_parity.json, r05_parity.json).
 """
 import json
 import os
@@ -104,7 +104,7 @@ class _Case:
 
     def check(self, out, i, b, what, elementwise=None):
         """frame i of the HIP outputs against oracle frame b.  Every measured error goes into the parity record
-        (`RECORD`, written to gpurun_out/parity_e2e.json at module teardown; profiles/r04_parity.json is a copy)."""
+        (`RECORD`, written to gpurun_out/parity_e2e.json at module teardown; profiles/r0N_parity.json are copies)."""
         r = self.oracle_frame(b)
         rec = RECORD.setdefault(what, {})
 
