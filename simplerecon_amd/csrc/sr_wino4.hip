@@ -76,10 +76,10 @@ struct SrWino4Params {
 #endif
 };
 #ifdef SR_W4_TRACE
-#define W4_TR_N 96
+#define W4_TR_N 128   // the last 4 slots of group 0: shader clock / 100-MHz wall clock at the start and the end of the workgroup
 #define W4_TR(code)                                                                                              \
   do {                                                                                                           \
-    if (tid == 0 && tr_n < W4_TR_N && blockIdx.x < 16)                                                            \
+    if (tid == 0 && tr_n < W4_TR_N - 4 && blockIdx.x < 16)                                                          \
       p.trace[((size_t)blockIdx.x * 2 + grp) * W4_TR_N + tr_n++] = ((unsigned long long)(code) << 56) | (clock64() & 0xffffffffffffffull); \
   } while (0)
 #else
@@ -265,11 +265,12 @@ __device__ __forceinline__ void w4_transform(const float* t_rd, float* t_wr) {
 }
 
 // the first W4_PD frequency pairs' weight fragments of a slab (issued a barrier ahead of the MFMA tick that uses them)
+template <int NA = W4_NA, int PD = W4_PD>
 __device__ __forceinline__ void w4_u_prefetch(__amdgpu_buffer_rsrc_t rs_u, unsigned u_voff, unsigned u_slab, unsigned u_fstride,
-                                              w4_f4 (&ua)[W4_NA][2]) {
+                                              w4_f4 (&ua)[NA][2]) {
   if (SR_W4_ABL & (2 | 32)) return;
 #pragma unroll
-  for (int fp = 0; fp < W4_PD; ++fp) {
+  for (int fp = 0; fp < PD; ++fp) {
     ua[fp][0] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * fp) * u_fstride);
     ua[fp][1] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * fp + 1) * u_fstride);
   }
@@ -277,14 +278,17 @@ __device__ __forceinline__ void w4_u_prefetch(__amdgpu_buffer_rsrc_t rs_u, unsig
 
 // 36 frequencies x (16 co x 16 tiles x 16 ci): pairs of frequencies interleaved (dependent MFMAs 64 clk apart); the first
 // W4_PD pairs of weight fragments are already in ua[]
+// FIRST: the accumulators start at zero (an item's first slab): the first MFMA of every frequency takes the constant 0 as its C
+// operand instead of 144 registers that somebody had to clear.
+template <bool FIRST = false, int NA = W4_NA, int PD = W4_PD>
 __device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsigned u_voff, unsigned u_slab, unsigned u_fstride,
-                                             const float* m_rd, w4_f4 (&ua)[W4_NA][2], w4_f4 (&acc)[36], int lane) {
+                                             const float* m_rd, w4_f4 (&ua)[NA][2], w4_f4 (&acc)[36], int lane) {
   if (SR_W4_ABL & 2) return;
   w4_prio_mfma();
   w4_f4 vb[2][2];
   if (SR_W4_ABL & 32) {
 #pragma unroll
-    for (int a = 0; a < W4_NA; ++a) ua[a][0] = ua[a][1] = w4_f4{1.0f, 2.0f, 3.0f, (float)u_slab};
+    for (int a = 0; a < NA; ++a) ua[a][0] = ua[a][1] = w4_f4{1.0f, 2.0f, 3.0f, (float)u_slab};
     vb[0][0] = vb[0][1] = vb[1][0] = vb[1][1] = w4_f4{1.0f, 0.5f, 0.25f, (float)lane};
   } else {
     vb[0][0] = *reinterpret_cast<const w4_f4*>(m_rd);
@@ -292,9 +296,9 @@ __device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsign
   }
 #pragma unroll
   for (int fp = 0; fp < 18; ++fp) {
-    if (!(SR_W4_ABL & 32) && fp + W4_PD < 18) {
-      ua[(fp + W4_PD) % W4_NA][0] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + W4_PD)) * u_fstride);
-      ua[(fp + W4_PD) % W4_NA][1] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + W4_PD) + 1) * u_fstride);
+    if (!(SR_W4_ABL & 32) && fp + PD < 18) {
+      ua[(fp + PD) % NA][0] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + PD)) * u_fstride);
+      ua[(fp + PD) % NA][1] = w4_load(rs_u, u_voff, u_slab + (unsigned)(2 * (fp + PD) + 1) * u_fstride);
     }
     if (!(SR_W4_ABL & 32) && fp + 1 < 18) {
       vb[(fp + 1) & 1][0] = *reinterpret_cast<const w4_f4*>(m_rd + (2 * fp + 2) * 256);
@@ -302,8 +306,9 @@ __device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsign
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % W4_NA][0][e], vb[fp & 1][0][e], acc[2 * fp], 0, 0, 0);
-      acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % W4_NA][1][e], vb[fp & 1][1][e], acc[2 * fp + 1], 0, 0, 0);
+      const w4_f4 zero = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+      acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % NA][0][e], vb[fp & 1][0][e], (FIRST && e == 0) ? zero : acc[2 * fp], 0, 0, 0);
+      acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % NA][1][e], vb[fp & 1][1][e], (FIRST && e == 0) ? zero : acc[2 * fp + 1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);   // keep the two accumulators interleaved (left alone hipcc issues 4 dependent MFMAs in a row)
     }
   }
@@ -516,48 +521,8 @@ __global__ __launch_bounds__(512, 2) void sr_wino4pp_kernel(SrWino4Params p) {
   for (; bars < bars_all; ++bars) __syncthreads();   // (the other group is still working)
 }
 
-// ---- the wave-specialised form (variant 3): ONE 8-wave workgroup per CU; waves 0-3 ("M") stream the MFMAs and move the input
-// patches (loads + LDS stores: a handful of instructions per slab), waves 4-7 ("T") transform the patches and own the output
-// side of every work item: residual prefetch, bias + residual + activation, stores.
-// Why: scripts/micro/mfma_overlap.hip (profiles/r02_mfma_valu_overlap.txt): a wave that issues nothing but MFMAs keeps its
-// full rate next to a VALU wave on the same SIMD (64.3 vs 64.5 clk per 32x32x2 MFMA) while the VALU wave still issues every
-// 13 clk; the same VALU instructions INSIDE the MFMA wave cost 5-6.5 clk of matrix-pipe time each.  And the r05 ablations /
-// s_memtime traces of the other two forms: an item's epilogue costs 16-20 k clocks -- its 16 residual loads per lane are
-// latency-bound (4 KB in flight per wave), its stores write half cache lines -- during which that workgroup issues no MFMA.
-// Per TICK (one workgroup barrier), k = 0 .. K over the slabs of all the workgroup's items in a row:
-//   T waves: V[k & 1] = B^T d B of raw[k & 1]                                   (slab k)
-//   M waves: MFMAs of slab k - 1 on V[(k - 1) & 1]; then patch k + 1 (in registers since tick k - 1) -> raw[(k + 1) & 1] and
-//            the loads of patch k + 2.
-// raw and V are double-buffered (125.6 KB of LDS): one barrier per tick orders everything.  When slab k - 1 closes an item,
-// the M waves run the output transform in place and hand the 16 x 16 x 64 output tile to the T waves in two halves THROUGH
-// the V buffer they just finished reading (free until T(k + 1)): M writes rows 0-1 of every 4 x 4 tile, barrier, T reads
-// them (a thread takes float4s of whole 256-byte pixel records: its stores are full cache lines), barrier, M writes rows 2-3,
-// barrier, T reads, barrier -- three extra barriers per item; the T waves add bias and the residual they prefetched a tick
-// earlier (16 float4 in registers these waves have to spare), apply the activation and store.
-__device__ __forceinline__ void w4_transform36(const float* t_rd, float* t_wr) {
-  if (SR_W4_ABL & 1) return;
-  float t[6][6];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    float d[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) d[r] = t_rd[(r * W4_PS + c) * W4_RS];
-    w4_bt(d[0], d[1], d[2], d[3], d[4], d[5], t[0][c], t[1][c], t[2][c], t[3][c], t[4][c], t[5][c]);
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float v[6];
-    w4_bt(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) t_wr[(i * 6 + j) * 256] = v[j];
-  }
-}
-
-// The same transform on channel PAIRS with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: two IEEE fmas per
-// instruction, component-wise the very operations of w4_bt -- bit-identical): a thread takes (tile, 2 channels), reads 8-byte
-// pairs from the patch and writes 8-byte pairs of V.  128 work items per slab = lanes 0-31 of each of the four T waves: half
-// the VALU and LDS instructions per wave of the one-channel form.  (MFMA and VALU instructions of the two waves of a SIMD do
-// not overlap -- scripts/micro/mfma16_overlap.hip --, so the T waves' instruction count is matrix-pipe time.)
+// packed fp32 arithmetic on channel PAIRS (v_pk_fma_f32 / v_pk_add_f32: two IEEE fmas per instruction, component-wise the very
+// operations of w4_bt -- bit-identical)
 typedef float w4_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ w4_f2 w4_fma2(float a, w4_f2 b, w4_f2 c) { return __builtin_elementwise_fma(w4_f2{a, a}, b, c); }
 __device__ __forceinline__ void w4_bt2(w4_f2 d0, w4_f2 d1, w4_f2 d2, w4_f2 d3, w4_f2 d4, w4_f2 d5, w4_f2& t0, w4_f2& t1, w4_f2& t2,
@@ -571,30 +536,101 @@ __device__ __forceinline__ void w4_bt2(w4_f2 d0, w4_f2 d1, w4_f2 d2, w4_f2 d3, w
   t4 = w4_fma2(-2.0f, e, c);
   t5 = w4_fma2(-4.25f, d3, d1) + d5;
 }
-__device__ __forceinline__ void w4_transform36_pk(const float* t_rd, float* t_wr) {
-  if (SR_W4_ABL & 1) return;
-  w4_f2 t[6][6];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    w4_f2 d[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const w4_f2*>(t_rd + (r * W4_PS + c) * W4_RS);
-    w4_bt2(d[0], d[1], d[2], d[3], d[4], d[5], t[0][c], t[1][c], t[2][c], t[3][c], t[4][c], t[5][c]);
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    w4_f2 v[6];
-    w4_bt2(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<w4_f2*>(t_wr + (i * 6 + j) * 256) = v[j];
-  }
+// ---- the wave-specialised form (variant 3; rewritten in r06): ONE 8-wave workgroup per CU; waves 0-3 ("M") do nothing but
+// stream the MFMAs (weight fragments from L2, V fragments from LDS) and, when an item's last slab is done, run the output
+// transform in place and hand the finished 16 x 16 x 64 tile over through LDS; waves 4-7 ("T") own BOTH memory sides: they move
+// the input patches (global -> registers -> LDS), transform them into V, and turn the finished tiles into stores (residual +
+// bias + activation, whole 256-byte pixel records).
+// What r06 measured on the r05 form (profiles/r06_w4ws_trace.txt; 64 -> 64 at 8 x 240 x 320: 206 us, 143 without the output
+// side, 170 without the patch movement) and what this form does about it:
+//   * the r05 M waves also loaded the patches, in the same in-order vmcnt queue as their weight fragments: the first MFMA of a tick
+//     waited for the L2 misses of a patch that was not needed for another tick (the last slab of an item ran 5-10 k clocks
+//     instead of 4.9 k).  Here the M waves' only memory traffic is the weight stream, prefetched four frequency pairs ahead;
+//   * a wave next to an MFMA stream issues ONE instruction per MFMA (scripts/micro/mfma16_overlap.hip), so every T-wave
+//     instruction is worth 37 clocks while the M waves stream.  The r05 T waves executed ~1 550 instructions per 64 -> 64 item
+//     (576 MFMA slots): the item decode's integer divisions on every tick (~110), both sums and a select per value around a
+//     uniform `has_res`, a branch per store; the M waves idled at the barrier behind them.  Here: ~145 per tick + ~230 per item;
+//     the item cursor advances by additions, residual / activation class are template parameters;
+//   * the M waves' output transform runs on channel pairs (240 v_pk_* instead of 432 instructions), the accumulators are not
+//     cleared (the first MFMA of a frequency takes C = 0);
+//   * tried and dropped: patches straight into the T waves' registers in transform layout (18 8-byte loads per lane, no staging
+//     buffer, whole tile in LDS, no hand-over barriers) -- correct, but each such wave-load touches eight 64-byte segments and
+//     the patch is fetched 2.25x: the texture-address unit needed ~2 k clocks per tick for them next to the weight stream's 2.3 k
+//     (of a 4.9-k tick) and the T waves became the critical path (202 us).
+// Per TICK (one workgroup barrier F), k = 0 .. K over the slabs of all the workgroup's items in a row:
+//   T waves: [tile half 0 of the item that closed in tick k - 1: LDS -> registers; barriers B2, B3]
+//            patch k + 1 (in registers since tick k - 1) -> raw[(k + 1) & 1]; loads of patch k + 2;
+//            [that item's output side: half 0, then half 1 from LDS];  V[k & 1] = B^T d B of raw[k & 1];
+//            [residual loads of the item the M waves are closing in this tick]
+//   M waves: MFMAs of slab k - 1 on V[(k - 1) & 1]; if that closes an item: Y = A^T M A in place, rows 0-1 of every tile -> LDS,
+//            F, B2 (the T waves have read them), rows 2-3 -> LDS, B3.
+// raw and V are double-buffered, the hand-over buffer holds half a tile: 158 336 of the CU's 163 840 bytes.
+// Weight-fragment register sets / prefetch distance (frequency pairs) of the M waves: the CU's vector-memory pipeline returns
+// data in order ACROSS waves, so a weight fragment (an L2 hit) requested behind the T waves' patch / residual loads (L2 misses)
+// arrives when THEY do; the M waves have the registers for a longer lead (256 clocks per pair).
+#ifndef SR_W4WS_NA
+#define SR_W4WS_NA 5
+#define SR_W4WS_PD 4
+#endif
+constexpr int W4WS_NA = SR_W4WS_NA, W4WS_PD = SR_W4WS_PD;
+#ifndef SR_W4WS_TUNE
+#define SR_W4WS_TUNE 0   // experiments: 1: output transform at s_setprio 3; 2: residual loads after the closing tick's transform
+#endif
+constexpr int W4_WS_RAW2 = 2 * W4_RAW_FLOATS;                          // V buffers start behind the two raw buffers
+constexpr int W4_WS_OUT = W4_WS_RAW2 + 2 * W4_V_FLOATS;                // the output hand-over buffer (half a region: 16 tiles x 8 pixels x 64 channels)
+constexpr int W4_WS_OUT_FLOATS = 16 * 8 * 64;
+constexpr int W4_WS_LDS_BYTES = (W4_WS_OUT + W4_WS_OUT_FLOATS) * 4;    // 158 336 of the CU's 163 840: one workgroup per CU
+
+// A^T on channel pairs (v_pk_*: the M waves' output transform is issue-bound, half the instructions of the float4 form).  The
+// scalings are powers of two (exact), so the value of each output equals w4_at's bit for bit.
+__device__ __forceinline__ void w4_at2(w4_f2 m0, w4_f2 m1, w4_f2 m2, w4_f2 m3, w4_f2 m4, w4_f2 m5, w4_f2& s0, w4_f2& s1, w4_f2& s2,
+                                       w4_f2& s3) {
+  const w4_f2 p = m1 + m2, q = m1 - m2, u = m3 + m4, v = m3 - m4;
+  s0 = (m0 + p) + u;
+  s1 = w4_fma2(0.5f, q, 2.0f * v);
+  s2 = w4_fma2(0.25f, p, 4.0f * u);
+  s3 = w4_fma2(0.125f, q, w4_fma2(8.0f, v, m5));
+}
+__device__ __forceinline__ void w4_at_pk(w4_f4& a0, w4_f4& a1, w4_f4& a2, w4_f4& a3, const w4_f4& a4, const w4_f4& a5) {
+  w4_f2 lo[4], hi[4];
+  w4_at2(w4_f2{a0[0], a0[1]}, w4_f2{a1[0], a1[1]}, w4_f2{a2[0], a2[1]}, w4_f2{a3[0], a3[1]}, w4_f2{a4[0], a4[1]}, w4_f2{a5[0], a5[1]},
+         lo[0], lo[1], lo[2], lo[3]);
+  w4_at2(w4_f2{a0[2], a0[3]}, w4_f2{a1[2], a1[3]}, w4_f2{a2[2], a2[3]}, w4_f2{a3[2], a3[3]}, w4_f2{a4[2], a4[3]}, w4_f2{a5[2], a5[3]},
+         hi[0], hi[1], hi[2], hi[3]);
+  a0 = w4_f4{lo[0][0], lo[0][1], hi[0][0], hi[0][1]};
+  a1 = w4_f4{lo[1][0], lo[1][1], hi[1][0], hi[1][1]};
+  a2 = w4_f4{lo[2][0], lo[2][1], hi[2][0], hi[2][1]};
+  a3 = w4_f4{lo[3][0], lo[3][1], hi[3][0], hi[3][1]};
 }
 
-// The same transform with BOTH halves of the wave on one (tile, channel pair): lanes 0-31 take patch columns 0-2 of the column
-// pass and rows 0-2 of the row pass, lanes 32-63 columns / rows 3-5; between the passes 18 v_permlane32_swap hand each half
-// the three columns of its rows that the other half computed.  Per slab and wave 18 + 18 LDS accesses, 72 packed operations
-// and 18 swaps instead of 36 + 36 and 144 -- the T waves' instructions are matrix-pipe time (see above).  Same operations on
-// the same values: bit-identical.  t_rd / t_wr carry the half's offset (3 columns of the patch / 18 frequencies).
+// The work-item cursor of a role: (region column, region row, image, output-channel block) of item `work`, advanced by the grid
+// stride with additions and carries (scalar unit) -- the divisions of w4_decode happen twice per launch, not once per tick.
+struct W4Cursor { int rx, ry, b, cb; };
+__device__ __forceinline__ W4Cursor w4_cursor(const SrWino4Params& p, int work) {
+  W4Cursor c;
+  int rem = work;
+  c.rx = rem % p.regions_x; rem /= p.regions_x;
+  c.ry = rem % p.regions_y; rem /= p.regions_y;
+  c.b = rem % p.B;
+  c.cb = rem / p.B;
+  return c;
+}
+__device__ __forceinline__ void w4_cursor_advance(const SrWino4Params& p, W4Cursor& c, const W4Cursor& step) {
+  c.rx += step.rx;
+  int carry = c.rx >= p.regions_x; c.rx -= carry ? p.regions_x : 0;
+  c.ry += step.ry + carry;
+  carry = c.ry >= p.regions_y; c.ry -= carry ? p.regions_y : 0;
+  c.b += step.b + carry;
+  carry = c.b >= p.B; c.b -= carry ? p.B : 0;
+  c.cb += step.cb + carry;
+}
+__device__ __forceinline__ W4Item w4_item(const W4Cursor& c) { return W4Item{c.b, 16 * c.ry, 16 * c.rx, 64 * c.cb}; }
+
+// The transform with BOTH halves of a wave on one (tile, channel pair): lanes 0-31 take patch columns 0-2 of the column pass and
+// rows 0-2 of the row pass, lanes 32-63 columns / rows 3-5; between the passes 18 v_permlane32_swap hand each half the three
+// columns of its rows that the other half computed.  Per slab and wave 9 + 9 LDS instructions (ds_read2 / ds_write2), 72 packed
+// operations and 18 swaps.  Component-wise the very operations of w4_bt: bit-identical to the other kernel forms.  t_rd / t_wr
+// carry the half's offset (3 columns of the patch / 18 frequencies).
 __device__ __forceinline__ void w4_transform36_split(const float* t_rd, float* t_wr) {
   if (SR_W4_ABL & 1) return;
   w4_f2 T[6][3];
@@ -623,149 +659,70 @@ __device__ __forceinline__ void w4_transform36_split(const float* t_rd, float* t
   }
 }
 
-constexpr int W4_WS_RAW2 = 2 * W4_RAW_FLOATS;                       // V buffers start behind the two raw buffers
-constexpr int W4_WS_OUT = W4_WS_RAW2 + 2 * W4_V_FLOATS;                // the output hand-over buffer (half a region: 16 tiles x 8 pixels x 64 channels)
-constexpr int W4_WS_OUT_FLOATS = 16 * 8 * 64;
-constexpr int W4_WS_LDS_BYTES = (W4_WS_OUT + W4_WS_OUT_FLOATS) * 4;    // 158 336 of the CU's 163 840: one workgroup per CU
-
-// patch loads of the MFMA waves: interior regions take the precomputed lane offsets (no address arithmetic per slab)
-__device__ __forceinline__ void w4_stage_m(const SrWino4Params& p, const W4Item& it, int s, int st_q, int st_pp0,
+// patch loads of the T waves: interior regions take the precomputed lane offsets (no address arithmetic per slab).  `valid` false
+// (uniform; past the workgroup's last slab): the same six instructions with every lane switched off -- a load that is skipped on
+// SOME path makes the compiler's s_waitcnt for the loads in flight wait for everything.
+__device__ __forceinline__ void w4ws_stage(const SrWino4Params& p, const W4Item& it, int s, bool valid, int st_q, int st_pp0,
                                            const unsigned (&st_off)[W4_STAGE], w4_f4 (&st)[W4_STAGE]) {
+  if (SR_W4_ABL & 16) return;
   const bool interior = (it.oy0 >= 1) & (it.ox0 >= 1) & (it.oy0 + 17 <= p.H) & (it.ox0 + 17 <= p.W);   // uniform
-  if (!interior) { w4_stage(p, it, s, st_q, st_pp0, st); return; }
   const unsigned in_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.in_sp + p.Cin) * 4);
   const __amdgpu_buffer_rsrc_t rs_in = w4_rsrc(p.in + (int64_t)it.b * p.in_sb, in_img_bytes);
-  const unsigned base = (unsigned)(((it.oy0 - 1) * p.W + (it.ox0 - 1)) * p.in_sp + 16 * s) * 4u;   // scalar offset operand
-  if (16 * s + 16 <= p.Cin) {   // (uniform) every channel quad of the slab exists
+  const bool chan_ok = valid & (16 * s + 4 * st_q + 4 <= p.Cin);
+  if (interior) {
+    const unsigned base = (unsigned)(((it.oy0 - 1) * p.W + (it.ox0 - 1)) * p.in_sp + 16 * s) * 4u;   // scalar offset operand
+    if (valid && 16 * s + 16 <= p.Cin) {   // (uniform) every channel quad of the slab exists
 #pragma unroll
-    for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load(rs_in, st_off[j], base);
+      for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load(rs_in, st_off[j], base);
+    } else {
+#pragma unroll
+      for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load(rs_in, chan_ok ? st_off[j] : W4_OOB, base);
+    }
   } else {
-    const bool chan_ok = 16 * s + 4 * st_q + 4 <= p.Cin;
+    const unsigned q_off = (unsigned)(16 * s + 4 * st_q) * 4u;
 #pragma unroll
-    for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load(rs_in, chan_ok ? st_off[j] : W4_OOB, base);
+    for (int j = 0; j < W4_STAGE; ++j) {
+      const int pp = st_pp0 + 64 * j;
+      const int r = (pp * 3641) >> 16, c = pp - 18 * r;
+      const int y = it.oy0 - 1 + r, x = it.ox0 - 1 + c;
+      const bool ok = chan_ok & (pp < W4_PS * W4_PS) & (y >= 0) & (y < p.H) & (x >= 0) & (x < p.W);
+      st[j] = w4_load(rs_in, w4_sel(ok, (unsigned)((y * p.W + x) * p.in_sp) * 4u + q_off), 0u);
+    }
   }
 }
 
+// GENERIC_ACT false: LeakyReLU with 0 <= slope <= 1 (max(v, slope v)) or no activation -- every 3x3 convolution of the reference's
+// BasicBlock stack; true: any activation code (sr_activate_group: SiLU of the image-prior encoder's blocks).  Two kernels instead
+// of three code paths per output batch in one (the SiLU path alone is 420 instructions per 32 values).
+// RES: the layer adds a residual (a load on SOME path spoils the wait counts of everything behind it, see w4ws_stage).
+template <bool GENERIC_ACT, bool RES>
 __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   w4_prio_other();
-  const int role_t = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // 0: MFMA waves, 1: transform / output waves
+  const int role_t = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // 0: MFMA waves, 1: transform / memory waves
   const int tid = threadIdx.x & 255;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // this workgroup's items: blockIdx.x, + gridDim.x, ...; K = n S slabs in a row; slab k - 1 closes an item iff k % S == 0
   const int n_items = ((int)p.total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int K = n_items * p.S;
+  const bool one_slab = p.S == 1;   // an item closes on EVERY tick: half 1 of a tile is read in the tick that writes half 0 of the next
+  const W4Cursor step = w4_cursor(p, (int)gridDim.x);
 #ifdef SR_W4_TRACE
   int tr_n = 0;
   const int grp = role_t;
+  const unsigned long long tr_c0 = clock64(), tr_w0 = wall_clock64();
 #endif
 
   if (role_t) {
-    // ================= T waves: transform + output side
-    // transform role: work item (tile, channel pair) = 32 * wave + (lane & 31); the two halves of the wave share it
-    // (w4_transform36_split: columns / rows 0-2 in lanes 0-31, 3-5 in lanes 32-63)
+    // ================= T waves
+    // transform role: work item (tile, channel pair) = 32 * wave + (lane & 31), shared by the two halves of the wave
     const int t_item = 32 * wave + (lane & 31), t_half = lane >> 5;
     const int t_ci = 2 * (t_item & 7), t_tile = t_item >> 3;
     const int t_sig = (0x1230 >> (t_tile & 12)) & 3;
     const int t_rd_off = ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3) + 3 * t_half) * W4_RS + t_ci;
     const int t_wr_off = W4_WS_RAW2 + t_half * 18 * 256 + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
-    // output role: channel quad o_c of the pixels pxl_i = (tid >> 4) + 16 i, i = 0 .. 7, of a half tile (16 tiles x 2 x 4 pixels:
-    // pxl = 8 tile + 4 kk + l).  With t0 = tid >> 7, kk = (tid >> 6) & 1, l = (tid >> 4) & 3:  tile_i = t0 + 2 i, so pixel i of half h
-    // sits at row 4 (i >> 1) + 2 h + kk, column 4 t0 + 8 (i & 1) + l of the region: ONE lane offset per tensor (row kk, column
-    // 4 t0 + l, channel quad) plus a scalar per (i, h) -- no address arithmetic per access.
-    const int o_c = tid & 15, o_t0 = tid >> 7, o_kk = (tid >> 6) & 1, o_l = (tid >> 4) & 3;
-    const unsigned o_lane = (unsigned)((o_kk * p.W + 4 * o_t0 + o_l) * p.out_sp + 4 * o_c) * 4u;
-    const unsigned r_lane = (unsigned)((o_kk * p.W + 4 * o_t0 + o_l) * p.res_sp + 4 * o_c) * 4u;
-    const int o_rd = ((tid >> 4) * 64) * 4;                 // byte offset of pixel 0's record in OUT
-    const int o_cx = 16 * (o_c ^ o_t0);                     // its 16-byte chunk; pixel i: chunk o_c ^ tile_i = (o_c ^ t0) ^ 2 i
-    const float slope = sr_uniform(p.slope);
-    const bool has_res = p.res != nullptr && !(SR_W4_ABL & 4);   // uniform
-    int ep_work = blockIdx.x;   // the item whose epilogue comes next
-    w4_f4 rv[2][8];
-    __syncthreads();   // (the M waves' first patch is in raw[0])
-    for (int k = 0; k <= K; ++k) {
-      const bool closes = k >= 1 && (k % p.S) == 0;   // (uniform) slab k - 1 is the last of its item
-      const W4Item eit = w4_decode(p, ep_work);
-      const bool cq_ok = eit.co0 + 4 * o_c < p.Cout;
-      const bool full = (eit.oy0 + 16 <= p.H) & (eit.ox0 + 16 <= p.W);   // uniform
-      if (closes && has_res) {
-        // residual of the whole 16 x 16 x 64 tile: 16 float4 per thread, a tick (plus the M waves' output transform) ahead
-        const unsigned res_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.res_sp + p.Cout) * 4);
-        const __amdgpu_buffer_rsrc_t rs_res = w4_rsrc(p.res + (int64_t)eit.b * p.res_sb, res_img_bytes);
-        const unsigned rbase = (unsigned)((eit.oy0 * p.W + eit.ox0) * p.res_sp + eit.co0) * 4u;   // scalar
-        const unsigned rl = cq_ok ? r_lane : W4_OOB;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const unsigned d = (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.res_sp) * 4u;   // scalar
-            if (full) {
-              rv[h][i] = w4_load(rs_res, rl, rbase + d);
-            } else {
-              const bool ok = (eit.oy0 + 4 * (i >> 1) + 2 * h + o_kk < p.H) & (eit.ox0 + 4 * o_t0 + 8 * (i & 1) + o_l < p.W);
-              rv[h][i] = w4_load(rs_res, ok ? rl : W4_OOB, rbase + d);
-            }
-          }
-      }
-      W4_TR(1);
-      if (k < K) w4_transform36_split(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off);
-      W4_TR(2);
-      __syncthreads();   // ---- end of tick k
-      W4_TR(3);
-      if (closes) {
-        const char* OUT = reinterpret_cast<const char*>(lds + W4_WS_OUT) + o_rd;
-        const unsigned out_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.out_sp + p.Cout) * 4);
-        const __amdgpu_buffer_rsrc_t rs_out = w4_rsrc(p.out + (int64_t)eit.b * p.out_sb, out_img_bytes);
-        const unsigned obase = (unsigned)((eit.oy0 * p.W + eit.ox0) * p.out_sp + eit.co0) * 4u;   // scalar
-        const unsigned ol = cq_ok ? o_lane : W4_OOB;
-        w4_f4 bv = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (p.bias) bv = __builtin_bit_cast(w4_f4, __builtin_amdgcn_raw_buffer_load_b128(w4_rsrc(p.bias, (int64_t)p.Cout * 4),
-                                                                                         (int)(cq_ok ? (unsigned)(eit.co0 + 4 * o_c) * 4u : W4_OOB), 0, 0));
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          w4_f4 y[8];
-          if (!(SR_W4_ABL & 4)) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) y[i] = *reinterpret_cast<const w4_f4*>(OUT + i * 16 * 64 * 4 + (o_cx ^ (32 * i)));
-          }
-          __syncthreads();   // half h read: the M waves may write the next half
-          if (!(SR_W4_ABL & 4)) {
-            float o[32];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              w4_f4 v = y[i] + bv;
-              if (has_res) v = v + rv[h][i];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[4 * i + e] = v[e];
-            }
-            sr_activate_group(o, slope);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const unsigned d = obase + (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.out_sp) * 4u;   // scalar
-              unsigned voff = ol + d;
-              if (!full) {
-                const bool ok = (eit.oy0 + 4 * (i >> 1) + 2 * h + o_kk < p.H) & (eit.ox0 + 4 * o_t0 + 8 * (i & 1) + o_l < p.W);
-                voff = ok ? voff : W4_OOB;
-              }
-              w4_store(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out, voff);
-            }
-          }
-          if (h == 0) __syncthreads();   // the M waves have written half 1
-        }
-        ep_work += (int)gridDim.x;
-        W4_TR(4);
-      }
-    }
-  } else {
-    // ================= M waves: MFMAs + patch movement + output transform
-    const int m_j = lane & 15, m_kq = lane >> 4;
-    const int m_sig = (0x1230 >> (m_j & 12)) & 3;
-    const int m_rd_off = W4_WS_RAW2 + m_j * 16 + 4 * (m_kq ^ m_sig);
-    const unsigned u_voff = (unsigned)(m_kq * p.Co_pad + 16 * wave + m_j) * 16u;
-    const unsigned u_fstride = (SR_W4_ABL & 8) ? 0u : (unsigned)p.S * 4u * (unsigned)p.Co_pad * 16u;
-    const unsigned u_sstride = (SR_W4_ABL & 8) ? 0u : 4u * (unsigned)p.Co_pad * 16u;
-    const __amdgpu_buffer_rsrc_t rs_u = w4_rsrc(p.wu, (int64_t)36 * p.S * 4 * p.Co_pad * 16);
+    // patch role: channel quad st_q of the patch pixels st_pp0 + 64 j
     const int st_q = tid & 3, st_pp0 = tid >> 2;
     const int st_wr_off = st_pp0 * W4_RS + 4 * st_q;
     unsigned st_off[W4_STAGE];
@@ -775,98 +732,230 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
       const int r = (pp * 3641) >> 16, c = pp - 18 * r;
       st_off[j] = pp < W4_PS * W4_PS ? (unsigned)((r * p.W + c) * p.in_sp + 4 * st_q) * 4u : W4_OOB;
     }
-    // OUT hand-over: this lane's 16-byte chunk of the pixel records of its tile
-    const int o_wr_off = m_j * 8 * 64 + 4 * ((4 * wave + m_kq) ^ m_j);
-    w4_f4 acc[36];
-#pragma unroll
-    for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
-    w4_f4 ua[W4_NA][2];
+    // output role: channel quad o_c of the pixels pxl_i = (tid >> 4) + 16 i, i = 0 .. 7, of a half tile (16 tiles x 2 x 4 pixels:
+    // pxl = 8 tile + 4 kk + l).  With t0 = tid >> 7, kk = (tid >> 6) & 1, l = (tid >> 4) & 3:  tile_i = t0 + 2 i, so pixel i of half h
+    // sits at row 4 (i >> 1) + 2 h + kk, column 4 t0 + 8 (i & 1) + l of the region: ONE lane offset per tensor (row kk, column
+    // 4 t0 + l, channel quad) plus a scalar per (i, h) -- no address arithmetic per access; a wave covers four neighbouring pixels
+    // x 64 channels per access (whole 256-byte records).
+    const int o_c = tid & 15, o_t0 = tid >> 7, o_kk = (tid >> 6) & 1, o_l = (tid >> 4) & 3;
+    const unsigned o_lane = (unsigned)((o_kk * p.W + 4 * o_t0 + o_l) * p.out_sp + 4 * o_c) * 4u;
+    const unsigned r_lane = (unsigned)((o_kk * p.W + 4 * o_t0 + o_l) * p.res_sp + 4 * o_c) * 4u;
+    const char* const OUT = reinterpret_cast<const char*>(lds + W4_WS_OUT) + ((tid >> 4) * 64) * 4;   // pixel 0's record
+    const int o_cx = 16 * (o_c ^ o_t0);                     // its 16-byte chunk; pixel i: chunk o_c ^ tile_i = (o_c ^ t0) ^ 2 i
+    const float slope = sr_uniform(p.slope);
+    constexpr bool has_res = RES && !(SR_W4_ABL & 4);
+    const unsigned out_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.out_sp + p.Cout) * 4);
+    const unsigned res_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.res_sp + p.Cout) * 4);
+
+    W4Cursor ld = w4_cursor(p, (int)blockIdx.x);   // the patch to load next: slab ld_s of item ld
+    int ld_s = 0;
+    W4Cursor ep = ld;                              // the item whose output tile comes next
     w4_f4 st[W4_STAGE];
-    int work = blockIdx.x, s = 0;
-    W4Item it = w4_decode(p, work);
-    int ld_work = blockIdx.x, ld_s = 0;   // load cursor: the patch st[] is loaded with next
-    W4Item ld_it = it;
-    auto advance = [&]() {
-      if (++ld_s == p.S) { ld_s = 0; ld_work += (int)gridDim.x; if (ld_work < p.total) ld_it = w4_decode(p, ld_work); }
+    w4_f4 rv[16];
+    w4_f4 bv;
+
+    auto load_next = [&](bool valid) {
+      w4ws_stage(p, w4_item(ld), ld_s, valid, st_q, st_pp0, st_off, st);
+      if (++ld_s == p.S) { ld_s = 0; w4_cursor_advance(p, ld, step); }
     };
     auto store_patch = [&](int par) {
+      if (SR_W4_ABL & 16) return;
       float* wr = lds + par * W4_RAW_FLOATS + st_wr_off;
 #pragma unroll
       for (int j = 0; j < W4_STAGE - 1; ++j) *reinterpret_cast<w4_f4*>(wr + j * 64 * W4_RS) = st[j];
       if (tid < 16) *reinterpret_cast<w4_f4*>(wr + (W4_STAGE - 1) * 64 * W4_RS) = st[W4_STAGE - 1];
     };
-    if (!(SR_W4_ABL & 16)) {   // patch 0 -> raw[0] (read by T(0) in tick 0, behind the first barrier ... which is tick 0's own
-      w4_stage_m(p, ld_it, ld_s, st_q, st_pp0, st_off, st);   //  barrier: so it has to land BEFORE tick 0 -- an extra barrier)
-      advance();
-      store_patch(0);
-      if (K > 1) { w4_stage_m(p, ld_it, ld_s, st_q, st_pp0, st_off, st); advance(); }
-    }
+    // residual of the whole 16 x 16 x 64 tile of item `eit` + its bias quad (an empty buffer reads 0): 17 loads
+    auto residual_loads = [&](const W4Item& eit) {
+      if (SR_W4_ABL & 4) return;
+      const bool cq_ok = eit.co0 + 4 * o_c < p.Cout;
+      bv = __builtin_bit_cast(w4_f4, __builtin_amdgcn_raw_buffer_load_b128(w4_rsrc(p.bias ? p.bias : p.wu, p.bias ? (int64_t)p.Cout * 4 : 0),
+                                                                          (int)(cq_ok ? (unsigned)(eit.co0 + 4 * o_c) * 4u : W4_OOB), 0, 0));
+      if (!has_res) return;
+      const bool full = (eit.oy0 + 16 <= p.H) & (eit.ox0 + 16 <= p.W);   // uniform
+      const __amdgpu_buffer_rsrc_t rs_res = w4_rsrc(p.res + (int64_t)eit.b * p.res_sb, res_img_bytes);
+      const unsigned rbase = (unsigned)((eit.oy0 * p.W + eit.ox0) * p.res_sp + eit.co0) * 4u;   // scalar
+      const unsigned rl = cq_ok ? r_lane : W4_OOB;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned d = (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.res_sp) * 4u;   // scalar
+          if (full) {
+            rv[8 * h + i] = w4_load(rs_res, rl, rbase + d);
+          } else {
+            const bool ok = (eit.oy0 + 4 * (i >> 1) + 2 * h + o_kk < p.H) & (eit.ox0 + 4 * o_t0 + 8 * (i & 1) + o_l < p.W);
+            rv[8 * h + i] = w4_load(rs_res, ok ? rl : W4_OOB, rbase + d);
+          }
+        }
+    };
+    auto read_half = [&](w4_f4 (&y)[8]) {
+      if (SR_W4_ABL & 4) return;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = *reinterpret_cast<const w4_f4*>(OUT + i * 16 * 64 * 4 + (o_cx ^ (32 * i)));
+    };
+    // half h of the tile of item `eit`: + bias + residual, activation, stores
+    auto output_half = [&](const W4Item& eit, int h, const w4_f4 (&y)[8]) {
+      if (SR_W4_ABL & 4) return;
+      const bool cq_ok = eit.co0 + 4 * o_c < p.Cout;
+      const bool full = (eit.oy0 + 16 <= p.H) & (eit.ox0 + 16 <= p.W);   // uniform
+      const __amdgpu_buffer_rsrc_t rs_out = w4_rsrc(p.out + (int64_t)eit.b * p.out_sb, out_img_bytes);
+      const unsigned obase = (unsigned)((eit.oy0 * p.W + eit.ox0) * p.out_sp + eit.co0) * 4u;   // scalar
+      const unsigned ol = cq_ok ? o_lane : W4_OOB;
+      float o[32];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        w4_f4 v = y[i] + bv;
+        if (has_res) v = v + rv[8 * h + i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[4 * i + e] = v[e];
+      }
+      if (GENERIC_ACT) {
+        sr_activate_group(o, slope);
+      } else if (slope >= 0.0f) {   // (uniform) LeakyReLU, 0 <= slope <= 1: max(v, slope v) -- v_pk_mul_f32 + 2 v_max_f32 per pair
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const w4_f2 t = slope * w4_f2{o[2 * i], o[2 * i + 1]};
+          o[2 * i] = sr_vmax(o[2 * i], t[0]);
+          o[2 * i + 1] = sr_vmax(o[2 * i + 1], t[1]);
+        }
+      }
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          w4_store(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out,
+                   ol + obase + (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.out_sp) * 4u);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool ok = (eit.oy0 + 4 * (i >> 1) + 2 * h + o_kk < p.H) & (eit.ox0 + 4 * o_t0 + 8 * (i & 1) + o_l < p.W);
+          const unsigned voff = ol + obase + (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.out_sp) * 4u;
+          w4_store(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out, ok ? voff : W4_OOB);
+        }
+      }
+    };
+
+    load_next(true);                  // patch 0 -> raw[0]; patch 1 -> registers
+    store_patch(0);
+    load_next(1 < K);
     __syncthreads();   // raw[0] visible
+    int cs = 0;        // k % S of the tick about to run
     for (int k = 0; k <= K; ++k) {
-      const bool closes = k >= 1 && (k % p.S) == 0;
+      const bool ep_now = k >= 2 && cs == (one_slab ? 0 : 1);   // (uniform) an item closed in tick k - 1: half 0 of its tile is in LDS
+      const bool closing = k >= 1 && cs == 0;                  // (uniform) the M waves close an item in THIS tick
+      cs = cs + 1 == p.S ? 0 : cs + 1;
+      const W4Item eit = w4_item(ep);
+      w4_f4 y[8];
       W4_TR(1);
-      if (k >= 1) {
-        const unsigned u_item = (SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u;
-        w4_mfma_tick(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, lds + ((k - 1) & 1) * W4_V_FLOATS + m_rd_off, ua, acc,
-                     lane);
-        ++s;
+      if (ep_now) {
+        read_half(y);
+        __syncthreads();   // B2: half 0 is in registers
+        __syncthreads();   // B3: the M waves have written half 1
       }
+      if (closing && !one_slab && !(SR_W4WS_TUNE & 2)) residual_loads(eit);   // consumed in the next tick (a tick and a half of lead: L2 misses, ~3 us under load)
+      // the transform FIRST: it needs nothing from memory (raw[k & 1] is in LDS since the last tick), so the patch loads requested at
+      // the end of the last tick have this whole tick to land before store_patch waits for them
+      if (k < K) w4_transform36_split(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off);
       W4_TR(2);
-      if (!(SR_W4_ABL & 16) && k + 1 < K) {
-        store_patch((k + 1) & 1);
-        W4_TR(5);
-        if (k + 2 < K) { w4_stage_m(p, ld_it, ld_s, st_q, st_pp0, st_off, st); advance(); }
+      if (closing && !one_slab && (SR_W4WS_TUNE & 2)) residual_loads(eit);
+      if (ep_now) {
+        output_half(eit, 0, y);
+        read_half(y);
+        output_half(eit, 1, y);
+        w4_cursor_advance(p, ep, step);
+        W4_TR(4);
+        if (one_slab) __syncthreads();   // B4: half 1 read -- the M waves may write half 0 of the next tile
       }
+      if (closing && one_slab) residual_loads(w4_item(ep));   // (an item closes on every tick: only now are rv / bv free)
+      if (k + 1 < K) store_patch((k + 1) & 1);
+      load_next(k + 2 < K);
+      W4_TR(5);
+      __syncthreads();   // ---- F: end of tick k
       W4_TR(3);
-      if (closes) {
+    }
+    {   // the last item closed in tick K
+      const W4Item eit = w4_item(ep);
+      w4_f4 y[8];
+      read_half(y);
+      __syncthreads();   // B2
+      __syncthreads();   // B3
+      output_half(eit, 0, y);
+      read_half(y);
+      output_half(eit, 1, y);
+    }
+  } else {
+    // ================= M waves: weight stream + MFMAs + output transform
+    const int m_j = lane & 15, m_kq = lane >> 4;
+    const int m_sig = (0x1230 >> (m_j & 12)) & 3;
+    const int m_rd_off = W4_WS_RAW2 + m_j * 16 + 4 * (m_kq ^ m_sig);
+    const unsigned u_voff = (unsigned)(m_kq * p.Co_pad + 16 * wave + m_j) * 16u;
+    const unsigned u_fstride = (SR_W4_ABL & 8) ? 0u : (unsigned)p.S * 4u * (unsigned)p.Co_pad * 16u;
+    const unsigned u_sstride = (SR_W4_ABL & 8) ? 0u : 4u * (unsigned)p.Co_pad * 16u;
+    const __amdgpu_buffer_rsrc_t rs_u = w4_rsrc(p.wu, (int64_t)36 * p.S * 4 * p.Co_pad * 16);
+    // this lane's 16-byte chunk (output channels 16 wave + 4 m_kq ...) of the 8 pixel records of its tile's half
+    float* const OUT = lds + W4_WS_OUT + m_j * 8 * 64 + 4 * ((4 * wave + m_kq) ^ m_j);
+    w4_f4 acc[36];
+    w4_f4 ua[W4WS_NA][2];
+    W4Cursor cur = w4_cursor(p, (int)blockIdx.x);
+    int s = 0;
+    w4_u_prefetch<W4WS_NA, W4WS_PD>(rs_u, u_voff, (SR_W4_ABL & 8) ? 0u : (unsigned)(64 * cur.cb) * 16u, u_fstride, ua);
+    __syncthreads();   // (raw[0] visible to the T waves)
+    __syncthreads();   // ---- F: end of tick 0
+    for (int k = 1; k <= K; ++k) {
+      W4_TR(1);
+      const unsigned u_item = (SR_W4_ABL & 8) ? 0u : (unsigned)(64 * cur.cb) * 16u;
+      const float* vrd = lds + ((k - 1) & 1) * W4_V_FLOATS + m_rd_off;
+      if (s == 0) w4_mfma_tick<true, W4WS_NA, W4WS_PD>(rs_u, u_voff, u_item, u_fstride, vrd, ua, acc, lane);
+      else w4_mfma_tick<false, W4WS_NA, W4WS_PD>(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, vrd, ua, acc, lane);
+      W4_TR(2);
+      if (++s == p.S) {   // (uniform) slab k - 1 closed an item
         s = 0;
-        work += (int)gridDim.x;
-        const W4Item nit = work < p.total ? w4_decode(p, work) : it;
-        if (k < K) w4_u_prefetch(rs_u, u_voff, (SR_W4_ABL & 8) ? 0u : (unsigned)nit.co0 * 16u, u_fstride, ua);
-        it = nit;
-        // (its own buffer, not the V buffer this wave has just consumed: the other M waves may still be reading that one)
-        float* OUT = lds + W4_WS_OUT + o_wr_off;
+        w4_cursor_advance(p, cur, step);
+        if (k < K) w4_u_prefetch<W4WS_NA, W4WS_PD>(rs_u, u_voff, (SR_W4_ABL & 8) ? 0u : (unsigned)(64 * cur.cb) * 16u, u_fstride, ua);
         if (SR_W4_ABL & 4) {
           w4_f4 sum = acc[0];
 #pragma unroll
           for (int f = 1; f < 36; ++f) sum = sum + acc[f];
           if (sum[0] + sum[1] + sum[2] + sum[3] == 1.2345e33f) p.out[tid] = sum[0];
-          __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+          if (one_slab && k >= 2) __syncthreads();
+          __syncthreads(); __syncthreads(); __syncthreads();
         } else {
-          // Y = A^T M A in place; rows 0-1 of every tile -> OUT, [T reads], rows 2-3 -> OUT
+          // Y = A^T M A in place: columns, then output rows 0-1 -> LDS, [F], rows 2-3 while the T waves fetch half 0, [B2], -> LDS, [B3]
+          if (SR_W4WS_TUNE & 1) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-          for (int j = 0; j < 6; ++j)
-            w4_at(acc[j], acc[6 + j], acc[12 + j], acc[18 + j], acc[24 + j], acc[30 + j], acc[j], acc[6 + j], acc[12 + j],
-                  acc[18 + j]);
+          for (int j = 0; j < 6; ++j) w4_at_pk(acc[j], acc[6 + j], acc[12 + j], acc[18 + j], acc[24 + j], acc[30 + j]);
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            w4_at(acc[6 * r], acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3], acc[6 * r + 4], acc[6 * r + 5], acc[6 * r],
-                  acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3]);
-#pragma unroll
-            for (int l = 0; l < 4; ++l) *reinterpret_cast<w4_f4*>(OUT + (r * 4 + l) * 64) = acc[6 * r + l];
-          }
+          for (int r = 0; r < 2; ++r) w4_at_pk(acc[6 * r], acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3], acc[6 * r + 4], acc[6 * r + 5]);
           W4_TR(6);
-          __syncthreads();   // ---- end of tick k: half 0 visible
+          if (one_slab && k >= 2) __syncthreads();   // B4: the T waves have read half 1 of the previous tile
 #pragma unroll
-          for (int r = 2; r < 4; ++r)
-            w4_at(acc[6 * r], acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3], acc[6 * r + 4], acc[6 * r + 5], acc[6 * r],
-                  acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3]);
-          __syncthreads();   // T has read half 0
+          for (int r = 0; r < 2; ++r)
 #pragma unroll
-          for (int r = 2; r < 4; ++r)
-#pragma unroll
-            for (int l = 0; l < 4; ++l) *reinterpret_cast<w4_f4*>(OUT + ((r - 2) * 4 + l) * 64) = acc[6 * r + l];
-          __syncthreads();   // half 1 visible
-          __syncthreads();   // T has read half 1 (the next closing tick writes the buffer again)
+            for (int l = 0; l < 4; ++l) *reinterpret_cast<w4_f4*>(OUT + (4 * r + l) * 64) = acc[6 * r + l];
           W4_TR(7);
-        }
+          __syncthreads();   // ---- F: end of tick k (half 0 visible)
 #pragma unroll
-        for (int f = 0; f < 36; ++f) acc[f] = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
+          for (int r = 2; r < 4; ++r) w4_at_pk(acc[6 * r], acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3], acc[6 * r + 4], acc[6 * r + 5]);
+          __syncthreads();   // B2: the T waves hold half 0
+#pragma unroll
+          for (int r = 2; r < 4; ++r)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) *reinterpret_cast<w4_f4*>(OUT + (4 * (r - 2) + l) * 64) = acc[6 * r + l];
+          __syncthreads();   // B3: half 1 visible
+          if (SR_W4WS_TUNE & 1) w4_prio_other();
+        }
       } else {
-        if (k < K) w4_u_prefetch(rs_u, u_voff, ((SR_W4_ABL & 8) ? 0u : (unsigned)it.co0 * 16u) + (unsigned)s * u_sstride, u_fstride, ua);
-        __syncthreads();   // ---- end of tick k
+        if (k < K) w4_u_prefetch<W4WS_NA, W4WS_PD>(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, ua);
+        W4_TR(7);
+        __syncthreads();   // ---- F: end of tick k
       }
     }
+#ifdef SR_W4_TRACE
+    if (tid == 0 && blockIdx.x < 16) {
+      unsigned long long* t = p.trace + ((size_t)blockIdx.x * 2) * W4_TR_N + (W4_TR_N - 4);
+      t[0] = tr_c0; t[1] = tr_w0; t[2] = clock64(); t[3] = wall_clock64();
+    }
+#endif
   }
 }
 
@@ -1028,12 +1117,15 @@ static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, c
   if (variant == 3) {   // wave-specialised: 4 MFMA waves + 4 transform waves, one workgroup per CU
     int blocks = w4_num_cus();
     if (blocks > p.total) blocks = p.total;
-    hipError_t e = hipFuncSetAttribute((const void*)sr_wino4ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_WS_LDS_BYTES);
+    const bool generic_act = !((leaky_slope >= 0.0f && leaky_slope <= 1.0f) || (leaky_slope < 0.0f && leaky_slope > -1.5f));
+    auto kernel = generic_act ? (residual ? sr_wino4ws_kernel<true, true> : sr_wino4ws_kernel<true, false>)
+                              : (residual ? sr_wino4ws_kernel<false, true> : sr_wino4ws_kernel<false, false>);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_WS_LDS_BYTES);
     if (e != hipSuccess) return sr_hip_rc(e);
 #ifdef SR_W4_TRACE
     w4_trace_begin(p, (hipStream_t)stream_);
 #endif
-    hipLaunchKernelGGL(sr_wino4ws_kernel, dim3(blocks), dim3(512), W4_WS_LDS_BYTES, (hipStream_t)stream_, p);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(512), W4_WS_LDS_BYTES, (hipStream_t)stream_, p);
 #ifdef SR_W4_TRACE
     w4_trace_end(blocks, (hipStream_t)stream_);
 #endif

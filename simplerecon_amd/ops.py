@@ -340,10 +340,13 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
     replaces the module's symmetric padding by TensorFlow-"SAME" padding (tf_same_pads).  library_gemm=True lets a 1x1
     conv over a dense map run as a hipBLASLt GEMM (faster on the MBConv shapes; its algorithm choice depends on the number
     of pixels; only with SR_CONV1X1_GEMM=lib since r04).  Batch-size invariance: every kernel on the default path is run-to-run
-    deterministic; 3x3 results are also bitwise independent of the batch size UNLESS the launch plan splits K (the split-K
-    factor of the Winograd / direct / pointwise plans is chosen from the total number of work items, B included) -- a 1x1 /
-    stride-1 convolution with Cin >= 128 on a few pixel tiles may give B = 1 and B = 8 different low-order bits
-    (tests/test_gpu_determinism.py pins both statements).  `gate` ([B, Cin], 1x1 / stride-1 convs only): the input is scaled
+    deterministic, but the RESULT OF A FRAME MAY DEPEND ON THE BATCH IT IS IN (and on the CU count of the device) in its low-order
+    bits: the launch plans are chosen from the total number of work items, B included -- a 3x3 / stride-1 layer runs F(4x4)
+    Winograd at one batch size and F(2x2) at another (sr_conv_prefers_wino4: 64 -> 64 at 240x320 is F(2x2) at B = 1, F(4x4) at
+    B = 8; error constants 3e-7 vs 1.3e-6 of the output range), and the Winograd / direct / pointwise plans split K on small
+    maps.  Within ONE plan the per-pixel arithmetic does not depend on B.  tests/test_gpu_determinism.py pins the run-to-run
+    statement and the 1x1 cases, tests/test_gpu_e2e_full_size.py::test_batch_1_and_batch_8_agree_frame_by_frame the model-level
+    agreement (to the element-wise tolerance each holds against the oracle, not bitwise).  `gate` ([B, Cin], 1x1 / stride-1 convs only): the input is scaled
     per image and input channel while it is loaded (the squeeze-excite gate of an MBConv block).  Returns a channels-last view."""
     _lib.refuse_autograd(x, conv.weight)
     x = as_nhwc(x, "conv input")

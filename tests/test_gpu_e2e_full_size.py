@@ -192,4 +192,24 @@ def test_batch_8_at_benchmarked_shape_matches_oracle_chain(case):
         if isinstance(v, torch.Tensor) and v.is_floating_point():
             assert torch.isfinite(v).all(), k
     case.check(out, 0, 0, "batch 8, frame 0")
+    case.check(out, 3, 3, "batch 8, frame 3")   # (r06: two interior frames as well -- F(4x4) Winograd carries most 3x3 launches)
+    case.check(out, 4, 4, "batch 8, frame 4")
     case.check(out, B - 1, B - 1, "batch 8, frame 7")
+
+
+def test_batch_1_and_batch_8_agree_frame_by_frame(case):
+    """The SAME frame alone and inside a batch of 8.  The 3x3 launch plans depend on the number of work items (B included) and on
+    the CU count of the device: at batch 8 the full-resolution 64-channel layers run F(4x4) Winograd, at batch 1 F(2x2) (error
+    constants 1.3e-6 vs 3e-7 of the output range, csrc/sr_wino4.hip sr_conv_prefers_wino4), deep layers split K at batch 1 only.
+    So the two results are NOT bit-identical; pinned here: they agree within the element-wise bound each of them holds against
+    the oracle (the docstring of ops.conv2d used to promise batch-size independence for every 3x3 layer)."""
+    one = case.run_hip(slice(2, 3))
+    eight = case.run_hip(slice(0, B))
+    a, b = one["depth_pred_s0_b1hw"][0:1].double(), eight["depth_pred_s0_b1hw"][2:3].double()
+    rel = ((a - b).abs() / b.abs().clamp_min(1e-6)).max().item()
+    print(f"batch 1 vs batch 8, frame 2: max element-wise relative difference of depth_pred_s0 {rel:.2e}")
+    assert rel < ELEMENTWISE_MAX, rel
+    assert torch.equal(one["overall_mask_bhw"][0], eight["overall_mask_bhw"][2])
+    for lv, (x, y) in enumerate(zip(one["levels"], eight["levels"])):
+        d = (x[0:1].double() - y[2:3].double()).abs().max().item() / y[2:3].double().abs().max().item()
+        assert d < 2e-5, (lv, d)
