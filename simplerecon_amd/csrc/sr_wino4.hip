@@ -77,10 +77,14 @@ struct SrWino4Params {
 };
 #ifdef SR_W4_TRACE
 #define W4_TR_N 128   // the last 4 slots of group 0: shader clock / 100-MHz wall clock at the start and the end of the workgroup
+// (the scheduling barriers keep the compiler from moving arithmetic across the clock read)
 #define W4_TR(code)                                                                                              \
   do {                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    const unsigned long long tr_now = clock64();                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
     if (tid == 0 && tr_n < W4_TR_N - 4 && blockIdx.x < 16)                                                          \
-      p.trace[((size_t)blockIdx.x * 2 + grp) * W4_TR_N + tr_n++] = ((unsigned long long)(code) << 56) | (clock64() & 0xffffffffffffffull); \
+      p.trace[((size_t)blockIdx.x * 2 + grp) * W4_TR_N + tr_n++] = ((unsigned long long)(code) << 56) | (tr_now & 0xffffffffffffffull); \
   } while (0)
 #else
 #define W4_TR(code) do {} while (0)
@@ -280,7 +284,19 @@ __device__ __forceinline__ void w4_u_prefetch(__amdgpu_buffer_rsrc_t rs_u, unsig
 // W4_PD pairs of weight fragments are already in ua[]
 // FIRST: the accumulators start at zero (an item's first slab): the first MFMA of every frequency takes the constant 0 as its C
 // operand instead of 144 registers that somebody had to clear.
-template <bool FIRST = false, int NA = W4_NA, int PD = W4_PD>
+template <int N>
+__device__ __forceinline__ void w4_yield() {   // N wait states (s_nop takes 1 .. 16)
+  if (N > 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop %0" ::"n"(N > 16 ? 15 : N - 1));
+    if (N > 16) asm volatile("s_nop %0" ::"n"(N > 16 ? N - 17 : 0));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// YIELD > 0: s_nop YIELD - 1 behind every MFMA.  An MFMA wave whose NEXT MFMA waits for the matrix pipe holds the SIMD's issue
+// port (scripts/micro/mfma16_overlap.hip: the other wave gets one instruction per MFMA); while it idles in an s_nop the other
+// wave issues freely.  The nops themselves hide under the 32-clock MFMA.
+template <bool FIRST = false, int NA = W4_NA, int PD = W4_PD, int YIELD = 0>
 __device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsigned u_voff, unsigned u_slab, unsigned u_fstride,
                                              const float* m_rd, w4_f4 (&ua)[NA][2], w4_f4 (&acc)[36], int lane) {
   if (SR_W4_ABL & 2) return;
@@ -308,7 +324,9 @@ __device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsign
     for (int e = 0; e < 4; ++e) {
       const w4_f4 zero = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
       acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % NA][0][e], vb[fp & 1][0][e], (FIRST && e == 0) ? zero : acc[2 * fp], 0, 0, 0);
+      w4_yield<YIELD>();
       acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % NA][1][e], vb[fp & 1][1][e], (FIRST && e == 0) ? zero : acc[2 * fp + 1], 0, 0, 0);
+      w4_yield<YIELD>();
       __builtin_amdgcn_sched_barrier(0);   // keep the two accumulators interleaved (left alone hipcc issues 4 dependent MFMAs in a row)
     }
   }
@@ -573,9 +591,11 @@ __device__ __forceinline__ void w4_bt2(w4_f2 d0, w4_f2 d1, w4_f2 d2, w4_f2 d3, w
 #define SR_W4WS_PD 4
 #endif
 constexpr int W4WS_NA = SR_W4WS_NA, W4WS_PD = SR_W4WS_PD;
-#ifndef SR_W4WS_TUNE
-#define SR_W4WS_TUNE 0   // experiments: 1: output transform at s_setprio 3; 2: residual loads after the closing tick's transform
+#ifndef SR_W4WS_YIELD
+#define SR_W4WS_YIELD 0
 #endif
+constexpr int W4WS_YIELD = SR_W4WS_YIELD;   // wait states the M waves idle behind every MFMA (w4_mfma_tick)
+
 constexpr int W4_WS_RAW2 = 2 * W4_RAW_FLOATS;                          // V buffers start behind the two raw buffers
 constexpr int W4_WS_OUT = W4_WS_RAW2 + 2 * W4_V_FLOATS;                // the output hand-over buffer (half a region: 16 tiles x 8 pixels x 64 channels)
 constexpr int W4_WS_OUT_FLOATS = 16 * 8 * 64;
@@ -591,7 +611,24 @@ __device__ __forceinline__ void w4_at2(w4_f2 m0, w4_f2 m1, w4_f2 m2, w4_f2 m3, w
   s2 = w4_fma2(0.25f, p, 4.0f * u);
   s3 = w4_fma2(0.125f, q, w4_fma2(8.0f, v, m5));
 }
+#ifndef SR_W4WS_TUNE
+#define SR_W4WS_TUNE 0   // A/B builds: 4: scalar output transform (384 v_* instead of 240 v_pk_*: same time, r06)
+#endif
+__device__ __forceinline__ float w4_opaque(float x) { asm volatile("" : "+v"(x)); return x; }   // (keeps the SLP vectoriser from pairing)
 __device__ __forceinline__ void w4_at_pk(w4_f4& a0, w4_f4& a1, w4_f4& a2, w4_f4& a3, const w4_f4& a4, const w4_f4& a5) {
+  if (SR_W4_ABL & 64) { a0 = a0 + a4; a1 = a1 + a5; return; }   // (timing experiments: nearly no arithmetic)
+  if (SR_W4WS_TUNE & 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float m0 = a0[e], m1 = a1[e], m2 = a2[e], m3 = a3[e], m4 = a4[e], m5 = a5[e];
+      const float p = w4_opaque(m1 + m2), q = w4_opaque(m1 - m2), u = w4_opaque(m3 + m4), v = w4_opaque(m3 - m4);
+      a0[e] = w4_opaque(w4_opaque(m0 + p) + u);
+      a1[e] = w4_opaque(fmaf(0.5f, q, w4_opaque(2.0f * v)));
+      a2[e] = w4_opaque(fmaf(0.25f, p, w4_opaque(4.0f * u)));
+      a3[e] = w4_opaque(fmaf(0.125f, q, w4_opaque(fmaf(8.0f, v, m5))));
+    }
+    return;
+  }
   w4_f2 lo[4], hi[4];
   w4_at2(w4_f2{a0[0], a0[1]}, w4_f2{a1[0], a1[1]}, w4_f2{a2[0], a2[1]}, w4_f2{a3[0], a3[1]}, w4_f2{a4[0], a4[1]}, w4_f2{a5[0], a5[1]},
          lo[0], lo[1], lo[2], lo[3]);
@@ -852,12 +889,11 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
         __syncthreads();   // B2: half 0 is in registers
         __syncthreads();   // B3: the M waves have written half 1
       }
-      if (closing && !one_slab && !(SR_W4WS_TUNE & 2)) residual_loads(eit);   // consumed in the next tick (a tick and a half of lead: L2 misses, ~3 us under load)
+      if (closing && !one_slab) residual_loads(eit);   // consumed in the next tick (a tick and a half of lead: L2 misses, ~3 us under load)
       // the transform FIRST: it needs nothing from memory (raw[k & 1] is in LDS since the last tick), so the patch loads requested at
       // the end of the last tick have this whole tick to land before store_patch waits for them
       if (k < K) w4_transform36_split(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off);
       W4_TR(2);
-      if (closing && !one_slab && (SR_W4WS_TUNE & 2)) residual_loads(eit);
       if (ep_now) {
         output_half(eit, 0, y);
         read_half(y);
@@ -905,8 +941,8 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
       W4_TR(1);
       const unsigned u_item = (SR_W4_ABL & 8) ? 0u : (unsigned)(64 * cur.cb) * 16u;
       const float* vrd = lds + ((k - 1) & 1) * W4_V_FLOATS + m_rd_off;
-      if (s == 0) w4_mfma_tick<true, W4WS_NA, W4WS_PD>(rs_u, u_voff, u_item, u_fstride, vrd, ua, acc, lane);
-      else w4_mfma_tick<false, W4WS_NA, W4WS_PD>(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, vrd, ua, acc, lane);
+      if (s == 0) w4_mfma_tick<true, W4WS_NA, W4WS_PD, W4WS_YIELD>(rs_u, u_voff, u_item, u_fstride, vrd, ua, acc, lane);
+      else w4_mfma_tick<false, W4WS_NA, W4WS_PD, W4WS_YIELD>(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, vrd, ua, acc, lane);
       W4_TR(2);
       if (++s == p.S) {   // (uniform) slab k - 1 closed an item
         s = 0;
@@ -921,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
           __syncthreads(); __syncthreads(); __syncthreads();
         } else {
           // Y = A^T M A in place: columns, then output rows 0-1 -> LDS, [F], rows 2-3 while the T waves fetch half 0, [B2], -> LDS, [B3]
-          if (SR_W4WS_TUNE & 1) __builtin_amdgcn_s_setprio(3);
+          W4_TR(8);
 #pragma unroll
           for (int j = 0; j < 6; ++j) w4_at_pk(acc[j], acc[6 + j], acc[12 + j], acc[18 + j], acc[24 + j], acc[30 + j]);
 #pragma unroll
@@ -931,18 +967,21 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
 #pragma unroll
           for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int l = 0; l < 4; ++l) *reinterpret_cast<w4_f4*>(OUT + (4 * r + l) * 64) = acc[6 * r + l];
+            for (int l = 0; l < 4; ++l) if (!(SR_W4_ABL & 128) || acc[0][0] == 1.2345e33f) *reinterpret_cast<w4_f4*>(OUT + (4 * r + l) * 64) = acc[6 * r + l];
           W4_TR(7);
           __syncthreads();   // ---- F: end of tick k (half 0 visible)
+          W4_TR(12);
 #pragma unroll
           for (int r = 2; r < 4; ++r) w4_at_pk(acc[6 * r], acc[6 * r + 1], acc[6 * r + 2], acc[6 * r + 3], acc[6 * r + 4], acc[6 * r + 5]);
+          W4_TR(9);
           __syncthreads();   // B2: the T waves hold half 0
+          W4_TR(10);
 #pragma unroll
           for (int r = 2; r < 4; ++r)
 #pragma unroll
-            for (int l = 0; l < 4; ++l) *reinterpret_cast<w4_f4*>(OUT + (4 * (r - 2) + l) * 64) = acc[6 * r + l];
+            for (int l = 0; l < 4; ++l) if (!(SR_W4_ABL & 128) || acc[0][0] == 1.2345e33f) *reinterpret_cast<w4_f4*>(OUT + (4 * (r - 2) + l) * 64) = acc[6 * r + l];
           __syncthreads();   // B3: half 1 visible
-          if (SR_W4WS_TUNE & 1) w4_prio_other();
+          W4_TR(11);
         }
       } else {
         if (k < K) w4_u_prefetch<W4WS_NA, W4WS_PD>(rs_u, u_voff, u_item + (unsigned)s * u_sstride, u_fstride, ua);
@@ -1021,7 +1060,8 @@ extern "C" int sr_wino4_pack_weights(const float* weight, int Cout, int Cin, flo
 // (profiles/r05_wino4_shape_sweep.txt: every 3x3 shape of the hero conv stack at batch 8 / 1 and the matching encoder's
 // layer1 at 64 images, all three kernels):
 //   * many work items (>= 512, the last round >= 80 % full of 256 workgroups, <= 10 % region padding): F(4x4) wins by
-//     8-26 %; the wave-specialised form on short slab chains (Cin <= 64), the 4-wave form on long ones;
+//     10-30 %; r05: the wave-specialised form on short slab chains (Cin <= 64), the 4-wave form on long ones; since the r06
+//     rewrite the wave-specialised form at every slab count (3-5 % ahead of the 4-wave form at Cin = 128 / 192, step -0.05 ms);
 //   * one round of 150-256 items (60x80 / 30x40 levels at batch 8): the wave-specialised form wins by ~16 % (one workgroup
 //     per CU has no second-round tail; F(2x2)'s 8x16 regions leave more of the chip idle there);
 //   * everything else (two partial rounds, < 150 items, 15x20 maps, batch 1): F(2x2) with its split-K plans stays.
@@ -1044,7 +1084,7 @@ extern "C" int sr_conv_prefers_wino4(int B, int H, int W, int Cin, int Cout, int
     const long rounds = (items + cus - 1) / cus;
     const double fill = (double)items / (double)(rounds * cus);
     if (util < 0.9 || fill < 0.8) return 0;
-    return Cin <= 64 ? 3 : 1;
+    return 3;   // (r05: the 4-wave form for Cin > 64; the r06 wave-specialised form wins at every slab count -- profiles/r06_wino4_shape_sweep.txt)
   }
   if (items * 10 >= cus * 6 && items <= cus && util >= 0.75) return 3;   // one round on >= 60 % of the CUs
   return 0;

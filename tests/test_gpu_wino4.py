@@ -214,7 +214,7 @@ def test_ops_conv2d_dispatches_wino4_by_rule_and_by_switch(monkeypatch):
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip("the rule's answers below are those of a 256-CU device (items per round of CUs)")
     assert lib.sr_conv_prefers_wino4(8, 240, 320, 64, 64, 1) == 3      # short slab chain: the wave-specialised form
-    assert lib.sr_conv_prefers_wino4(8, 240, 320, 192, 64, 1) == 1     # long one: two 4-wave workgroups per CU
+    assert lib.sr_conv_prefers_wino4(8, 240, 320, 192, 64, 1) == 3     # long one: r05 the 4-wave form, since r06 the same
     assert lib.sr_conv_prefers_wino4(1, 240, 320, 64, 64, 1) == 0      # 300 items in two partial rounds: F(2x2)
     assert lib.sr_conv_prefers_wino4(8, 120, 160, 64, 64, 1) == 3      # 640 items = 2.5 rounds of 256 workgroups
     assert lib.sr_conv_prefers_wino4(8, 60, 80, 64, 64, 1) == 3        # one round on 160 CUs
