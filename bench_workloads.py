@@ -250,6 +250,7 @@ class HeroCfg3:
     feature_volume_type = "mlp_feature_volume"
 
     dtype = "f32"
+    ROTATE = 3   # resident input batches step(i) cycles through
 
     def __init__(self, dev, rank, B=None, streams=1, with_encoder=True, name=None, graph=False, prior=None, split=None, split_convs=False):
         from simplerecon_amd import depth_model as dm
@@ -297,6 +298,14 @@ class HeroCfg3:
             g = torch.Generator(device="cpu").manual_seed(1000 + rank)
             self.cur_image = torch.randn((self.B, 3, 4 * self.h, 4 * self.w), generator=g).to(dev)
             self.src_image = torch.randn((self.B, self.K, 3, 4 * self.h, 4 * self.w), generator=g).to(dev)
+        # step(i) rotates over ROTATE resident batches (VERDICT r05 hygiene (a): the 236 MB of images of ONE batch are about the
+        # size of the Infinity Cache, so 20 steps on the same batch could have read them from there).  Batch 0 is the one the
+        # parity / profile helpers use; the others differ in images, poses and intrinsics.
+        self.batches = [(self.inp, getattr(self, "cur_image", None), getattr(self, "src_image", None))]
+        for j in range(1, self.ROTATE if with_encoder else 1):
+            inp_j = synthetic.cost_volume_inputs(self.B, self.K, self.Cc, self.h, self.w, seed=rank + 17 * j, device=dev)
+            self.batches.append((inp_j, torch.randn((self.B, 3, 4 * self.h, 4 * self.w), generator=g).to(dev),
+                                 torch.randn((self.B, self.K, 3, 4 * self.h, 4 * self.w), generator=g).to(dev)))
         self.results = []
         self.last = None
 
@@ -311,8 +320,8 @@ class HeroCfg3:
         return self.model.hot_path(pyramid, cur_f, src_f, ext, poses, Ks, invK, return_mask=True)
 
     def step(self, i=0):
-        inp = self.inp
-        first = [self.cur_image, self.src_image] if self.with_encoder else [inp["cur_feats"], inp["src_feats"]]
+        inp, cur_image, src_image = self.batches[0 if self.use_graph else i % len(self.batches)]   # (a graph replays on its own buffers)
+        first = [cur_image, src_image] if self.with_encoder else [inp["cur_feats"], inp["src_feats"]]
         args = (first, None if self.prior else self.pyramid, inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
                 inp["cur_invK"])
         if self.use_graph:
@@ -346,6 +355,7 @@ class HeroCfg3:
                             + (" (BASELINE.json configs[2]: hero_model.yaml, batch 8)" if self.B == 8 and
                                self.feature_volume_type == "mlp_feature_volume" else ""),
                 "frames_per_step_per_gpu": self.B,
+                "resident_input_batches": 1 if self.use_graph else len(self.batches),   # step i runs on batch i mod this
                 # main stream(s) + the image-prior encoder's side stream + the two branch streams of the decoder (its
                 # right / diagonal / up branches fork for every node up to `branch_stream_max_regions` regions)
                 "hip_streams_per_gpu": self.streams + (1 if (self.prior and getattr(self.model, "prior_on_side_stream", True))
@@ -607,6 +617,7 @@ class HeroCfg4Stream(HeroCfg3):
     layout with a rigid jitter seeded by i): a keyframe is the same data on whatever rank / in whatever batch it lands,
     so the gathered result of N ranks equals the 1-rank result (tests/test_gpu_multirank.py)."""
     name = "hero_cfg4_stream"
+    ROTATE = 1   # (every step generates its own keyframes)
 
     def __init__(self, dev, rank, max_batches=256):
         super().__init__(dev, rank, name="hero_cfg4_stream")

@@ -284,18 +284,27 @@ __device__ __forceinline__ void w4_u_prefetch(__amdgpu_buffer_rsrc_t rs_u, unsig
 // W4_PD pairs of weight fragments are already in ua[]
 // FIRST: the accumulators start at zero (an item's first slab): the first MFMA of every frequency takes the constant 0 as its C
 // operand instead of 144 registers that somebody had to clear.
+#ifndef SR_W4WS_YIELD
+#define SR_W4WS_YIELD 0
+#endif
+#ifndef SR_W4WS_YIELD_PERIOD
+#define SR_W4WS_YIELD_PERIOD 1
+#endif
+constexpr int W4WS_YIELD = SR_W4WS_YIELD;   // wait states the M waves idle behind every W4WS_YIELD_PERIOD-th MFMA (w4_mfma_tick)
+constexpr int W4WS_YIELD_PERIOD = SR_W4WS_YIELD_PERIOD;
+// YIELD > 0 (wave-specialised form): `s_nop YIELD - 1` behind every MFMA.  An fp32 MFMA holds the wave's issue for its 32 clocks and
+// the M wave re-arbitrates with its next MFMA at once: the T wave on the SIMD gets a slot only every second or third MFMA
+// (profiles/r06_w4ws_trace.txt: its 51-instruction column pass takes the whole 4.9-k-clock stream) and does the rest of its tick
+// AFTER the stream while the M waves idle at the barrier.  A few wait states per MFMA are issue slots the T wave takes; they
+// cost the M wave their full length, so only as many as the T wave's work needs.
 template <int N>
-__device__ __forceinline__ void w4_yield() {   // N wait states (s_nop takes 1 .. 16)
+__device__ __forceinline__ void w4_yield() {
   if (N > 0) {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop %0" ::"n"(N > 16 ? 15 : N - 1));
-    if (N > 16) asm volatile("s_nop %0" ::"n"(N > 16 ? N - 17 : 0));
+    asm volatile("s_nop %0" ::"n"(N > 16 ? 15 : (N > 0 ? N - 1 : 0)));
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-// YIELD > 0: s_nop YIELD - 1 behind every MFMA.  An MFMA wave whose NEXT MFMA waits for the matrix pipe holds the SIMD's issue
-// port (scripts/micro/mfma16_overlap.hip: the other wave gets one instruction per MFMA); while it idles in an s_nop the other
-// wave issues freely.  The nops themselves hide under the 32-clock MFMA.
 template <bool FIRST = false, int NA = W4_NA, int PD = W4_PD, int YIELD = 0>
 __device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsigned u_voff, unsigned u_slab, unsigned u_fstride,
                                              const float* m_rd, w4_f4 (&ua)[NA][2], w4_f4 (&acc)[36], int lane) {
@@ -324,9 +333,9 @@ __device__ __forceinline__ void w4_mfma_tick(__amdgpu_buffer_rsrc_t rs_u, unsign
     for (int e = 0; e < 4; ++e) {
       const w4_f4 zero = w4_f4{0.0f, 0.0f, 0.0f, 0.0f};
       acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % NA][0][e], vb[fp & 1][0][e], (FIRST && e == 0) ? zero : acc[2 * fp], 0, 0, 0);
-      w4_yield<YIELD>();
+      if ((8 * fp + 2 * e) % W4WS_YIELD_PERIOD == 0) w4_yield<YIELD>();
       acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[fp % NA][1][e], vb[fp & 1][1][e], (FIRST && e == 0) ? zero : acc[2 * fp + 1], 0, 0, 0);
-      w4_yield<YIELD>();
+      if ((8 * fp + 2 * e + 1) % W4WS_YIELD_PERIOD == 0) w4_yield<YIELD>();
       __builtin_amdgcn_sched_barrier(0);   // keep the two accumulators interleaved (left alone hipcc issues 4 dependent MFMAs in a row)
     }
   }
@@ -591,10 +600,6 @@ __device__ __forceinline__ void w4_bt2(w4_f2 d0, w4_f2 d1, w4_f2 d2, w4_f2 d3, w
 #define SR_W4WS_PD 4
 #endif
 constexpr int W4WS_NA = SR_W4WS_NA, W4WS_PD = SR_W4WS_PD;
-#ifndef SR_W4WS_YIELD
-#define SR_W4WS_YIELD 0
-#endif
-constexpr int W4WS_YIELD = SR_W4WS_YIELD;   // wait states the M waves idle behind every MFMA (w4_mfma_tick)
 
 constexpr int W4_WS_RAW2 = 2 * W4_RAW_FLOATS;                          // V buffers start behind the two raw buffers
 constexpr int W4_WS_OUT = W4_WS_RAW2 + 2 * W4_V_FLOATS;                // the output hand-over buffer (half a region: 16 tiles x 8 pixels x 64 channels)
@@ -663,34 +668,50 @@ __device__ __forceinline__ void w4_cursor_advance(const SrWino4Params& p, W4Curs
 }
 __device__ __forceinline__ W4Item w4_item(const W4Cursor& c) { return W4Item{c.b, 16 * c.ry, 16 * c.rx, 64 * c.cb}; }
 
-// The transform with BOTH halves of a wave on one (tile, channel pair): lanes 0-31 take patch columns 0-2 of the column pass and
-// rows 0-2 of the row pass, lanes 32-63 columns / rows 3-5; between the passes 18 v_permlane32_swap hand each half the three
-// columns of its rows that the other half computed.  Per slab and wave 9 + 9 LDS instructions (ds_read2 / ds_write2), 72 packed
-// operations and 18 swaps.  Component-wise the very operations of w4_bt: bit-identical to the other kernel forms.  t_rd / t_wr
-// carry the half's offset (3 columns of the patch / 18 frequencies).
-__device__ __forceinline__ void w4_transform36_split(const float* t_rd, float* t_wr) {
+// The T waves' transform: a lane takes one (tile, channel pair) and HALF of the vertical frequencies -- waves 4, 5 rows i = 0..2 of
+// T = B^T d (the t0, t1, t2 outputs of w4_bt: 6 packed operations per patch column, patch rows 0-4), waves 6, 7 rows 3..5 (t3, t4,
+// t5: 6 more, patch rows 1-5) --, then its three rows of V = T B.  Per slab and wave: 15 ds_read2_b64, 72 packed operations,
+// 9 ds_write2st64_b64 -- 96 instructions.  (r05 / early r06: the two halves of ONE wave shared an item, each took three patch
+// COLUMNS through all six vertical frequencies and 18 v_permlane32_swap handed the halves their rows: 129 instructions; every
+// instruction of these waves costs a 37-clock slot next to the MFMA stream.)  Component-wise the very operations of w4_bt in the
+// same order: bit-identical to the other kernel forms.  `upper` is wave-uniform; t_wr carries the half's offset (18 frequencies).
+#ifdef SR_W4_TRACE
+#define W4_TF_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); tf_stamp[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+__device__ __forceinline__ void w4_transform36_half(const float* t_rd, float* t_wr, bool upper, unsigned long long (&tf_stamp)[2]) {
+#else
+#define W4_TF_STAMP(i) do {} while (0)
+__device__ __forceinline__ void w4_transform36_half(const float* t_rd, float* t_wr, bool upper) {
+#endif
   if (SR_W4_ABL & 1) return;
-  w4_f2 T[6][3];
+  w4_f2 T[3][6];
+  if (!upper) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    w4_f2 d[6];
+    for (int k = 0; k < 6; ++k) {
+      w4_f2 d[5];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const w4_f2*>(t_rd + (r * W4_PS + k) * W4_RS);
-    w4_bt2(d[0], d[1], d[2], d[3], d[4], d[5], T[0][k], T[1][k], T[2][k], T[3][k], T[4][k], T[5][k]);
+      for (int r = 0; r < 5; ++r) d[r] = *reinterpret_cast<const w4_f2*>(t_rd + (r * W4_PS + k) * W4_RS);
+      const w4_f2 a = w4_fma2(-4.0f, d[2], d[4]), b = w4_fma2(-4.0f, d[1], d[3]);
+      T[0][k] = w4_fma2(-4.25f, d[2], d[0]) + d[4];
+      T[1][k] = w4_fma2(0.5f, b, a);
+      T[2][k] = w4_fma2(-0.5f, b, a);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      w4_f2 d[6];
+#pragma unroll
+      for (int r = 1; r < 6; ++r) d[r] = *reinterpret_cast<const w4_f2*>(t_rd + (r * W4_PS + k) * W4_RS);
+      const w4_f2 c = w4_fma2(-0.25f, d[2], d[4]), e = w4_fma2(-0.25f, d[1], d[3]);
+      T[0][k] = w4_fma2(2.0f, e, c);
+      T[1][k] = w4_fma2(-2.0f, e, c);
+      T[2][k] = w4_fma2(-4.25f, d[3], d[1]) + d[5];
+    }
   }
+  W4_TF_STAMP(0);
 #pragma unroll
   for (int ii = 0; ii < 3; ++ii) {
-    w4_f2 R[6], v[6];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        // new a = [a.lo | b.lo], new b = [a.hi | b.hi]: a = row ii (lower half's), b = row 3 + ii (upper half's)
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(T[ii][k][e]), __float_as_uint(T[3 + ii][k][e]), false, false);
-        R[k][e] = __uint_as_float(r[0]);
-        R[3 + k][e] = __uint_as_float(r[1]);
-      }
-    w4_bt2(R[0], R[1], R[2], R[3], R[4], R[5], v[0], v[1], v[2], v[3], v[4], v[5]);
+    w4_f2 v[6];
+    w4_bt2(T[ii][0], T[ii][1], T[ii][2], T[ii][3], T[ii][4], T[ii][5], v[0], v[1], v[2], v[3], v[4], v[5]);
 #pragma unroll
     for (int j = 0; j < 6; ++j) *reinterpret_cast<w4_f2*>(t_wr + (ii * 6 + j) * 256) = v[j];
   }
@@ -753,11 +774,11 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
 
   if (role_t) {
     // ================= T waves
-    // transform role: work item (tile, channel pair) = 32 * wave + (lane & 31), shared by the two halves of the wave
-    const int t_item = 32 * wave + (lane & 31), t_half = lane >> 5;
+    // transform role: work item (tile, channel pair) = 64 * (wave & 1) + lane, vertical frequencies 3 (wave >> 1) .. + 2
+    const int t_item = 64 * (wave & 1) + lane, t_half = wave >> 1;   // (t_half is wave-uniform)
     const int t_ci = 2 * (t_item & 7), t_tile = t_item >> 3;
     const int t_sig = (0x1230 >> (t_tile & 12)) & 3;
-    const int t_rd_off = ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3) + 3 * t_half) * W4_RS + t_ci;
+    const int t_rd_off = ((4 * (t_tile >> 2)) * W4_PS + 4 * (t_tile & 3)) * W4_RS + t_ci;
     const int t_wr_off = W4_WS_RAW2 + t_half * 18 * 256 + t_tile * 16 + 4 * ((t_ci >> 2) ^ t_sig) + (t_ci & 3);
     // patch role: channel quad st_q of the patch pixels st_pp0 + 64 j
     const int st_q = tid & 3, st_pp0 = tid >> 2;
@@ -892,7 +913,14 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
       if (closing && !one_slab) residual_loads(eit);   // consumed in the next tick (a tick and a half of lead: L2 misses, ~3 us under load)
       // the transform FIRST: it needs nothing from memory (raw[k & 1] is in LDS since the last tick), so the patch loads requested at
       // the end of the last tick have this whole tick to land before store_patch waits for them
-      if (k < K) w4_transform36_split(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off);
+#ifdef SR_W4_TRACE
+      unsigned long long tf_stamp[2] = {0, 0};
+      if (k < K) w4_transform36_half(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off, t_half != 0, tf_stamp);
+      if (tid == 0 && tr_n < W4_TR_N - 4 && blockIdx.x < 16 && k < K)
+        p.trace[((size_t)blockIdx.x * 2 + grp) * W4_TR_N + tr_n++] = (9ull << 56) | (tf_stamp[0] & 0xffffffffffffffull);
+#else
+      if (k < K) w4_transform36_half(lds + (k & 1) * W4_RAW_FLOATS + t_rd_off, lds + (k & 1) * W4_V_FLOATS + t_wr_off, t_half != 0);
+#endif
       W4_TR(2);
       if (ep_now) {
         output_half(eit, 0, y);
