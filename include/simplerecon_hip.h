@@ -582,7 +582,8 @@ int sr_rgb_stem3x3s2_fwd(const float* image, int64_t sb, int64_t sc, int64_t sy,
  * experiment_modules/depth_model.py:110-116 builds the encoder from timm), which stays sr_pw_conv_nhwc_fwd with `gate`.
  * `w_expand` [mid][Cin], `w_dw9c` [9][mid] tap-major, `w_reduce` [rd][mid], `w_excite` [mid][rd]; `out` [B][H*W][mid]
  * channels-last view, `pool` [B][mid] (channel sums, by-product), `gate` [B][mid]; `counters`: B zeroed 32-bit words that the
- * call leaves zeroed (one arrival counter per image: the last workgroup of an image computes its gates).  Deterministic.
+ * call leaves zeroed (one arrival counter per image: the last workgroup of an image computes its gates).  `counters` must not be
+ * shared by launches that may be in flight at the same time (different streams): one buffer per stream.  Deterministic.
  * sr_mbconv_fused_supported(): Cin in {128, 160, 256}, mid % 16 == 0, rd <= 64, H*W*64 bytes within the LDS budget. */
 int sr_mbconv_fused_supported(int H, int W, int Cin, int mid, int rd);
 int sr_mbconv_expand_dw_se_fwd(const float* in, int64_t in_batch_stride, int in_pix_stride, const float* w_expand,

@@ -193,6 +193,7 @@ def check(rc, what):
 # the library never reads the environment again and hosts change a switch through these calls.  Process-wide.
 SPLIT_MODES = {"": 0, "0": 0, "off": 0, "fp32": 0, "bf16": 1, "f16": 2, "fp16": 2}
 _SPLIT_NAMES = {0: "", 1: "bf16", 2: "f16"}
+SPLIT_OPTION_NAMES = ("SR_MLP_SPLIT", "SR_WINO_SPLIT")   # the options that take a mode NAME; every other option is an integer
 
 
 OPTION_LISTENERS = []   # callables (name, value) run after every set_option: caches of plan queries hang themselves in here
@@ -226,6 +227,8 @@ def set_option(name, value):
     """Sets option `name` (an int; the split modes also take 'bf16' / 'f16' / '' / an unknown string = -1: refused by the
     entry points).  Returns the previous value."""
     if isinstance(value, str):
+        if name not in SPLIT_OPTION_NAMES:
+            raise ValueError(f"option {name} takes an integer, got {value!r}")   # (ADVICE r05: a typo used to become -1 silently)
         value = SPLIT_MODES.get(value, -1)
     prev = C.c_int(0)
     check(lib().sr_option_set(_option_id(name), int(value), C.byref(prev)), "sr_option_set")

@@ -420,13 +420,23 @@ class FeatureVolumeManager(CostVolumeManager):
         nws = lib.sr_mlp_volume_workspace_bytes(b, k, c, h, w, hidden)
         ws = self._get_workspace(nws, dev)
         sb, sd, sp = self._volume_strides(vol)
+        from . import ops   # (ops.PROFILE: bench.py's in-step kernel table)
+        prof = ops.PROFILE
         with _lib.on_device(dev):
+            if prof is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             rc = lib.sr_mlp_volume_fwd(
                 _lib.ptr(cur), _lib.ptr(src), _lib.ptr(Ks), _lib.ptr(T), _lib.ptr(Tp), _lib.ptr(invK),
                 _lib.ptr(planes), *planes.stride(), *[_lib.ptr(t) for t in params], hidden,
                 C.c_float(0.01),  # nn.LeakyReLU default slope (reference networks.py:139)
                 b, k, c, h, w, self.num_depth_bins, _lib.ptr(vol), sb, sd, sp, _lib.ptr(lowest),
                 _lib.ptr(mask), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            if prof is not None:
+                ev1.record()
+                cin = c * (k + 1) + 10 * k + 4
+                prof.append(("sr_mlp_volume_fwd", 2.0 * (cin * hidden + hidden * hidden + hidden) * b * self.num_depth_bins * h * w,
+                             ev0, ev1, (), None))
         _lib.check(rc, "sr_mlp_volume_fwd")
         return vol, lowest, mask
 

@@ -24,6 +24,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "sr_common.h"
 
 namespace {
@@ -1055,15 +1057,34 @@ __global__ void sr_wino4_pack_kernel(const float* __restrict__ w, float* __restr
   }
 }
 
+// CU count of the CURRENT device (cached per device id; -1 = not asked yet)
+constexpr int W4_MAX_DEVICES = 64;
+int w4_current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < W4_MAX_DEVICES ? dev : 0;
+}
 int w4_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    else cus = 256;
+  static std::atomic<int> cus[W4_MAX_DEVICES];
+  const int dev = w4_current_device();
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev].store(v, std::memory_order_relaxed);
   }
-  return cus;
+  return v;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device) instead of once per launch; a device that refuses the
+// size answers SR_ERR_UNSUPPORTED (the caller falls back to the F(2x2) kernel) -- ADVICE r05.
+int w4_allow_lds(const void* kernel, int slot, int bytes) {
+  static std::atomic<int> state[8][W4_MAX_DEVICES];   // 0: not set, 1: ok, 2: refused
+  const int dev = w4_current_device();
+  int st = state[slot][dev].load(std::memory_order_acquire);
+  if (st == 0) {
+    st = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : 2;
+    if (st == 2) (void)hipGetLastError();
+    state[slot][dev].store(st, std::memory_order_release);
+  }
+  return st == 1 ? SR_OK : SR_ERR_UNSUPPORTED;
 }
 
 inline bool w4_al16(const void* ptr) { return (((uintptr_t)ptr) & 15) == 0; }
@@ -1188,8 +1209,7 @@ static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, c
     const bool generic_act = !((leaky_slope >= 0.0f && leaky_slope <= 1.0f) || (leaky_slope < 0.0f && leaky_slope > -1.5f));
     auto kernel = generic_act ? (residual ? sr_wino4ws_kernel<true, true> : sr_wino4ws_kernel<true, false>)
                               : (residual ? sr_wino4ws_kernel<false, true> : sr_wino4ws_kernel<false, false>);
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_WS_LDS_BYTES);
-    if (e != hipSuccess) return sr_hip_rc(e);
+    if (int rc = w4_allow_lds((const void*)kernel, (generic_act ? 2 : 0) + (residual ? 1 : 0), W4_WS_LDS_BYTES)) return rc;
 #ifdef SR_W4_TRACE
     w4_trace_begin(p, (hipStream_t)stream_);
 #endif
@@ -1202,8 +1222,7 @@ static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, c
   if (variant != 2) {   // two independent 4-wave workgroups per CU
     int blocks = 2 * w4_num_cus();
     if (blocks > p.total) blocks = p.total;
-    hipError_t e = hipFuncSetAttribute((const void*)sr_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES);
-    if (e != hipSuccess) return sr_hip_rc(e);
+    if (int rc = w4_allow_lds((const void*)sr_wino4_kernel, 4, W4_LDS_BYTES)) return rc;
     hipLaunchKernelGGL(sr_wino4_kernel, dim3(blocks), dim3(256), W4_LDS_BYTES, (hipStream_t)stream_, p);
     return sr_hip_rc(hipGetLastError());
   }
@@ -1212,8 +1231,7 @@ static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, c
 #ifdef SR_W4_TRACE
   w4_trace_begin(p, (hipStream_t)stream_);
 #endif
-  hipError_t e = hipFuncSetAttribute((const void*)sr_wino4pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_LDS_BYTES);
-  if (e != hipSuccess) return sr_hip_rc(e);
+  if (int rc = w4_allow_lds((const void*)sr_wino4pp_kernel, 5, 2 * W4_LDS_BYTES)) return rc;
   hipLaunchKernelGGL(sr_wino4pp_kernel, dim3(blocks), dim3(512), 2 * W4_LDS_BYTES, (hipStream_t)stream_, p);
 #ifdef SR_W4_TRACE
   w4_trace_end(blocks, (hipStream_t)stream_);

@@ -326,7 +326,8 @@ _lib.OPTION_LISTENERS.append(_drop_shape_queries)
 
 
 def _shape_query(lib, name, *shape):
-    key = (name, shape)
+    # (the answers may depend on the CU count of the CURRENT device: sr_conv_prefers_wino4, the split-K plans)
+    key = (name, shape, torch.cuda.current_device() if torch.cuda.is_available() else -1)
     v = _SHAPE_QUERIES.get(key)
     if v is None:
         v = _SHAPE_QUERIES[key] = getattr(lib, name)(*shape)
@@ -989,7 +990,10 @@ def se_gates(pool_partial, pixels, conv_reduce: nn.Conv2d, conv_expand: nn.Conv2
     return gate
 
 
-_MBX_COUNTERS = {}   # device -> zeroed int32 arrival counters of sr_mbconv_expand_dw_se_fwd (the call leaves them zeroed)
+# (device, stream) -> zeroed int32 arrival counters of sr_mbconv_expand_dw_se_fwd (the call leaves them zeroed).  Per STREAM: two
+# fused launches in flight on different streams must not interleave their atomicAdds on one buffer -- launches on one
+# stream are ordered.  A captured graph keeps the buffer of the stream it was captured on.
+_MBX_COUNTERS = {}
 
 
 def mbconv_fused_supported(x, conv_pw: nn.Conv2d, conv_dw: nn.Conv2d, se):
@@ -1019,9 +1023,10 @@ def mbconv_expand_dw_se(x, conv_pw: nn.Conv2d, bn1, conv_dw: nn.Conv2d, bn2, se)
     gate = torch.empty((b, mid), dtype=torch.float32, device=x.device)
     if b == 0:
         return out, gate
-    cnt = _MBX_COUNTERS.get(x.device)
+    ckey = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    cnt = _MBX_COUNTERS.get(ckey)
     if cnt is None or cnt.numel() < b:
-        cnt = _MBX_COUNTERS[x.device] = torch.zeros(max(b, 64), dtype=torch.int32, device=x.device)
+        cnt = _MBX_COUNTERS[ckey] = torch.zeros(max(b, 64), dtype=torch.int32, device=x.device)
     isb, isp = _strides(x)
     osb, osp = _strides(out)
     with _lib.on_device(x.device):
