@@ -42,13 +42,20 @@ def _amp_fwd(fwd):
     return wrapper
 
 
-# fp16 / bf16 STORAGE of the saved activations under torch.autocast (SR_AUTOCAST_HALF_STORAGE=0: keep fp32).  The
+# fp16 / bf16 STORAGE of the saved activations under torch.autocast (SR_AUTOCAST_HALF_STORAGE=1; default since r06: fp32).  The
 # reference's autocast keeps activations in half precision (options.py:100-101); here the kernels compute and hand over
 # fp32, but what autograd SAVES for the backward pass -- the bulk of a training step's memory -- is stored in the autocast
 # dtype and widened again when the backward kernel needs it.  A tensor saved by several operators (a producer saves its
 # output for the activation's derivative, the consumer saves it as its input) is narrowed once and shared.
-STORE_HALF = os.environ.get("SR_AUTOCAST_HALF_STORAGE", "1") != "0"
-# 16-bit KERNEL I/O under torch.autocast (r04; SR_AUTOCAST_HALF_IO=0: fp32 kernels + 16-bit storage as in r03).  Inside an
+#
+# r06: both 16-bit switches are OFF by default.  They buy memory (3.8 instead of 5.9 GiB peak at batch 2, 640x480, 7 views) and
+# cost time: the backward kernels are fp32, so every saved tensor is narrowed once and widened once by cast kernels (892 + 593
+# launches per step).  Measured training step (scripts/train_step_micro.py 2, profiles/r06_train_autocast.txt): fp32 77.7 ms;
+# bf16 autocast with storage + I/O 87.0, storage only 85.8, I/O only 83.1, neither (fp32 kernels under autocast) 78.4.  Until the
+# backward kernels read 16-bit operands themselves, "autocast is not slower than fp32"  is the default and the
+# memory saving is opt-in: SR_AUTOCAST_HALF_STORAGE=1 SR_AUTOCAST_HALF_IO=1.
+STORE_HALF = os.environ.get("SR_AUTOCAST_HALF_STORAGE", "0") != "0"
+# 16-bit KERNEL I/O under torch.autocast (r04; SR_AUTOCAST_HALF_IO=1; default since r06: fp32 kernels).  Inside an
 # autocast region the convolutions of the conv stack (BasicBlock / CVEncoder / DepthDecoderPP: _ConvBiasAct) read and write
 # their activations in the autocast dtype -- the Winograd and pointwise kernels load four fp16 / bf16 channels as one 8-byte
 # access, widen them on the way into LDS / registers, accumulate in fp32 (fp32 weights, fp32 MFMA) and round the result once
@@ -56,7 +63,7 @@ STORE_HALF = os.environ.get("SR_AUTOCAST_HALF_STORAGE", "1") != "0"
 # is 16-bit, like the reference's `precision: 16` training (options.py:100-101, train.py:132), with fp32 instead of fp16
 # accumulation inside a layer.  The backward kernels (weight / bias gradients, activation derivative, data gradient) run on
 # fp32 copies of the saved tensors; stride-2 and explicitly padded convolutions convert at their boundary.
-HALF_IO = os.environ.get("SR_AUTOCAST_HALF_IO", "1") != "0"
+HALF_IO = os.environ.get("SR_AUTOCAST_HALF_IO", "0") != "0"
 _IO_CODE = {torch.float16: 1, torch.bfloat16: 2}
 
 

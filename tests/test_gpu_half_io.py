@@ -92,6 +92,8 @@ def test_pointwise_16bit_io_equals_the_rounded_fp32_kernel(shape, dt):
 def test_conv_stack_trains_with_16bit_activations_under_autocast(dt, monkeypatch):
     """CVEncoder -> DepthDecoderPP under torch.autocast: activations between the layers and what autograd saves are 16-bit,
     the log-depth outputs agree with the fp32 run to half precision and so do the parameter gradients."""
+    monkeypatch.setattr(autograd_ops, "HALF_IO", True)       # (opt-in since r06: SR_AUTOCAST_HALF_IO=1 SR_AUTOCAST_HALF_STORAGE=1)
+    monkeypatch.setattr(autograd_ops, "STORE_HALF", True)
     torch.manual_seed(0)
     enc = synthetic.seeded_fill_(CVEncoder(16, [8, 12, 16, 24], [16, 24, 32, 48]), seed=1).to(DEV)
     dec = synthetic.seeded_fill_(DepthDecoderPP([6] + enc.num_ch_enc), seed=2).to(DEV)
