@@ -30,6 +30,9 @@ def main(rnd):
         f, w = agg(tag, "FETCH_SIZE"), agg(tag, "WRITE_SIZE")
         if not f:
             continue
+        combined = {}
+        for key in kerns:   # (a kernel the step no longer launches must not keep a stale entry)
+            out.pop(key, None)
         lines.append(f"## {wl}\n\n| kernel | launches | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM-side bytes/launch (2F+W)*1024 |\n|---|---|---|---|---|")
         for rank, (k, (n, v)) in enumerate(sorted(f.items(), key=lambda kv: -kv[1][1])):
             wn, wv = w.get(k, [0, 0.0])
@@ -37,9 +40,16 @@ def main(rnd):
             if rank < 14 or any(sub in k for sub in kerns.values()):
                 lines.append(f"| `{k[:70]}` | {n} | {v/n:.1f} | {wv/max(wn,1):.1f} | {b/1e6:.1f} MB |")
             for key, sub in kerns.items():
-                if sub in k:
-                    m = re.search(r"sr_\w+(<[^(]*>)?", k)
-                    out[key] = {"bytes": b, "kernel": m.group(0) if m else k[:60]}
+                if sub in k:   # several instantiations of one kernel (r06: sr_wino4ws_kernel<GENERIC_ACT, RES>): launch-weighted mean
+                    m = re.search(r"sr_\w+", k)
+                    acc = combined.setdefault(key, [0, 0.0, m.group(0) if m else k[:60], set()])
+                    acc[0] += n
+                    acc[1] += b * n
+                    acc[3].add(k[:90])
+        for key, (cn, cb, cname, inst) in combined.items():
+            if cn:
+                one = re.search(r"sr_\w+(<[^(]*>)?", sorted(inst)[0]).group(0) if len(inst) == 1 else cname
+                out[key] = {"bytes": cb / cn, "kernel": one, "launches": cn}
         lines.append("")
     json.dump(out, open(path, "w"), indent=1)
     open(os.path.join(R, "profiles", f"{rnd}_pmc_traffic.md"), "w").write(

@@ -325,9 +325,9 @@ def _drop_shape_queries(*_):
 _lib.OPTION_LISTENERS.append(_drop_shape_queries)
 
 
-def _shape_query(lib, name, *shape):
-    # (the answers may depend on the CU count of the CURRENT device: sr_conv_prefers_wino4, the split-K plans)
-    key = (name, shape, torch.cuda.current_device() if torch.cuda.is_available() else -1)
+def _shape_query(lib, name, *shape, dev=None):
+    # `dev`: device index of the tensors (the answers may depend on the device's CU count: sr_conv_prefers_wino4, split-K plans)
+    key = (name, shape, dev)
     v = _SHAPE_QUERIES.get(key)
     if v is None:
         v = _SHAPE_QUERIES[key] = getattr(lib, name)(*shape)
@@ -371,7 +371,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
     padded = pads != (k // 2,) * 4
     if padded and replicate:
         raise _lib.HipLibraryError("explicit padding is implemented for zero padding only")
-    use_wino = (not replicate) and (not padded) and bool(_shape_query(lib, "sr_conv_prefers_wino", b, h, w, ci, co, k, s))
+    use_wino = (not replicate) and (not padded) and bool(_shape_query(lib, "sr_conv_prefers_wino", b, h, w, ci, co, k, s, dev=x.device.index))
     if residual is not None:
         residual = as_nhwc(residual, "residual")
         if tuple(residual.shape) != (b, co, ho, wo):
@@ -401,7 +401,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
         gflag = 'true' if gate is not None else 'false'
         with _lib.on_device(x.device):
             if tiled:
-                nbytes = _shape_query(lib, "sr_pw_conv_tiled_workspace_bytes", m, ci, co)
+                nbytes = _shape_query(lib, "sr_pw_conv_tiled_workspace_bytes", m, ci, co, dev=x.device.index)
                 ws = _workspace(x.device, "pw_splitk", nbytes) if nbytes else None
             if prof is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -479,7 +479,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 return out
             if rc != 2:   # SR_ERR_UNSUPPORTED: no library algorithm for this shape -> the HIP kernel below
                 _lib.check(rc, "sr_gemm1x1_nhwc_fwd")
-    w4_form = _shape_query(lib, "sr_conv_prefers_wino4", b, h, w, ci, co, WINO4_MODE) \
+    w4_form = _shape_query(lib, "sr_conv_prefers_wino4", b, h, w, ci, co, WINO4_MODE, dev=x.device.index) \
         if (use_wino and WINO4_MODE and not wino_split_mode()) else 0   # 0: F(2x2); 1 / 3: the kernel form the rule picks
     if w4_form:
         al = lambda t, sb_, sp_: t is None or (t.data_ptr() % 16 == 0 and sp_ % 4 == 0 and sb_ % 4 == 0)
@@ -515,7 +515,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                                                rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, *pads, slope,
                                                _lib.stream_ptr(x.device))
         elif use_wino:
-            nbytes = _shape_query(lib, "sr_wino_splitk_workspace_bytes", b, h, w, ci, co)   # 0 unless the plan splits K
+            nbytes = _shape_query(lib, "sr_wino_splitk_workspace_bytes", b, h, w, ci, co, dev=x.device.index)   # 0 unless the plan splits K
             ws = _workspace(x.device, "wino_splitk", nbytes) if nbytes else None
             rc = lib.sr_conv3x3_wino_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
                                                      _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
@@ -525,7 +525,7 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                                                   _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
                                                   co, k, s, slope, _lib.stream_ptr(x.device))
         else:
-            nbytes = _shape_query(lib, "sr_conv_splitk_workspace_bytes", b, h, w, ci, co, k, s)   # 0 unless it may split K
+            nbytes = _shape_query(lib, "sr_conv_splitk_workspace_bytes", b, h, w, ci, co, k, s, dev=x.device.index)   # 0 unless it may split K
             ws = _workspace(x.device, "conv_splitk", nbytes) if nbytes else None
             rc = lib.sr_conv2d_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
                                                rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope,

@@ -119,7 +119,8 @@ def test_mbconv_front_half_in_one_launch(shape, mid):
         gate_ref = ops.se_gates(pool, h * w, se.conv_reduce, se.conv_expand)
     torch.cuda.synchronize()
     assert torch.equal(d, d2) and torch.equal(gate, gate2)
-    assert int(ops._MBX_COUNTERS[xt.device].abs().sum()) == 0
+    cnt = ops._MBX_COUNTERS[(xt.device, torch.cuda.current_stream(xt.device).cuda_stream)]   # (one buffer per stream since r06)
+    assert int(cnt.abs().sum()) == 0
     sd1 = {k_: _np(v) for k_, v in bn1.state_dict().items()}
     sd2 = {k_: _np(v) for k_, v in bn2.state_dict().items()}
     e = oracle.silu(oracle.batchnorm_eval(oracle.conv2d(x, _np(pw.weight), None), sd1, "", eps=1e-3))
