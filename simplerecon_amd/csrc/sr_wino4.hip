@@ -618,6 +618,9 @@ __device__ __forceinline__ void w4_at2(w4_f2 m0, w4_f2 m1, w4_f2 m2, w4_f2 m3, w
   s2 = w4_fma2(0.25f, p, 4.0f * u);
   s3 = w4_fma2(0.125f, q, w4_fma2(8.0f, v, m5));
 }
+#ifndef SR_W4WS_XCD
+#define SR_W4WS_XCD 1   // (A/B: 0 = items dealt round-robin to the workgroups)
+#endif
 #ifndef SR_W4WS_TUNE
 #define SR_W4WS_TUNE 0   // A/B builds: 4: scalar output transform (384 v_* instead of 240 v_pk_*: same time, r06)
 #endif
@@ -763,11 +766,24 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
   const int tid = threadIdx.x & 255;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // this workgroup's items: blockIdx.x, + gridDim.x, ...; K = n S slabs in a row; slab k - 1 closes an item iff k % S == 0
+  // this workgroup's items: first, first + item_stride, ...; K = n S slabs in a row; slab k - 1 closes an item iff k % S == 0
+#if SR_W4WS_XCD
+  // XCD-aware work order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only) and every XCD has its own L2, so
+  // each XCD walks a CONTIGUOUS eighth of the items (a band of region rows of one image): the 2-pixel halo a patch shares with its
+  // neighbours is fetched through the fabric once per XCD instead of once per region (round-robin: 1.31 x the algorithmic bytes).
+  const int xcd = (int)blockIdx.x & 7, n_x = ((int)gridDim.x - xcd + 7) >> 3;   // workgroups of this XCD
+  const int x_chunk = ((int)p.total + 7) >> 3;
+  const int first = xcd * x_chunk + ((int)blockIdx.x >> 3), x_end = min((int)p.total, (xcd + 1) * x_chunk);
+  const int n_items = first < x_end ? (x_end - first + n_x - 1) / n_x : 0;
+  const int item_stride = n_x;
+  if (n_items == 0) return;   // (uniform: the whole workgroup, before any barrier)
+#else
   const int n_items = ((int)p.total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int first = (int)blockIdx.x, item_stride = (int)gridDim.x;
+#endif
   const int K = n_items * p.S;
   const bool one_slab = p.S == 1;   // an item closes on EVERY tick: half 1 of a tile is read in the tick that writes half 0 of the next
-  const W4Cursor step = w4_cursor(p, (int)gridDim.x);
+  const W4Cursor step = w4_cursor(p, item_stride);
 #ifdef SR_W4_TRACE
   int tr_n = 0;
   const int grp = role_t;
@@ -807,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
     const unsigned out_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.out_sp + p.Cout) * 4);
     const unsigned res_img_bytes = (unsigned)(((int64_t)(p.H * p.W - 1) * p.res_sp + p.Cout) * 4);
 
-    W4Cursor ld = w4_cursor(p, (int)blockIdx.x);   // the patch to load next: slab ld_s of item ld
+    W4Cursor ld = w4_cursor(p, first);   // the patch to load next: slab ld_s of item ld
     int ld_s = 0;
     W4Cursor ep = ld;                              // the item whose output tile comes next
     w4_f4 st[W4_STAGE];
@@ -962,7 +978,7 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
     float* const OUT = lds + W4_WS_OUT + m_j * 8 * 64 + 4 * ((4 * wave + m_kq) ^ m_j);
     w4_f4 acc[36];
     w4_f4 ua[W4WS_NA][2];
-    W4Cursor cur = w4_cursor(p, (int)blockIdx.x);
+    W4Cursor cur = w4_cursor(p, first);
     int s = 0;
     w4_u_prefetch<W4WS_NA, W4WS_PD>(rs_u, u_voff, (SR_W4_ABL & 8) ? 0u : (unsigned)(64 * cur.cb) * 16u, u_fstride, ua);
     __syncthreads();   // (raw[0] visible to the T waves)
