@@ -14,7 +14,10 @@ bench)
   for wl in hero_b1 hero_cfg3_noprior hero_cfg3_graph hero_b1_graph hero_cfg4_stream hero_cfg5_volume hero_cfg5 dot_cfg2 dot_b8; do
     timeout 400 python bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_$wl.json 2> $O/bench_$wl.err
   done
-  timeout 600 python bench.py --gpus 1 --force-collective --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_hero_cfg3_rccl_world1.json 2> $O/bench_rccl.err
+  for try in 1 2 3; do   # (the RCCL world-1 line came back empty once in a while right behind the other bench processes: retry)
+    timeout 600 python bench.py --gpus 1 --force-collective --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_hero_cfg3_rccl_world1.json 2> $O/bench_rccl.err
+    [ -s $O/bench_hero_cfg3_rccl_world1.json ] && break; sleep 5
+  done
   cut -c1-400 $O/bench_hero_cfg3.json; for wl in hero_b1 hero_cfg3_noprior hero_cfg3_graph hero_b1_graph hero_cfg4_stream hero_cfg5_volume hero_cfg5 dot_cfg2 dot_b8 hero_cfg3_rccl_world1; do cut -c1-190 $O/bench_$wl.json; done ;;
 fenced)   # the split-precision experiments: never the headline
   for wl in hero_cfg3_bf16x3 hero_cfg3_f16x3 hero_cfg3_bf16x3_convs hero_cfg3_f16x3_convs hero_b1_graph_f16x3_convs; do
