@@ -194,6 +194,10 @@ def check(rc, what):
 SPLIT_MODES = {"": 0, "0": 0, "off": 0, "fp32": 0, "bf16": 1, "f16": 2, "fp16": 2}
 _SPLIT_NAMES = {0: "", 1: "bf16", 2: "f16"}
 SPLIT_OPTION_NAMES = ("SR_MLP_SPLIT", "SR_WINO_SPLIT")   # the options that take a mode NAME; every other option is an integer
+# The split modes are read by the weight-packing AND by the launching entry points: a change between the two would feed one
+# format's packed weights to the other format's kernel.  Changing them and [pack + launch] hold this lock.
+import threading  # noqa: E402
+SPLIT_GUARD = threading.RLock()
 
 
 OPTION_LISTENERS = []   # callables (name, value) run after every set_option: caches of plan queries hang themselves in here
@@ -231,7 +235,11 @@ def set_option(name, value):
             raise ValueError(f"option {name} takes an integer, got {value!r}")   # (a typo used to become -1 silently)
         value = SPLIT_MODES.get(value, -1)
     prev = C.c_int(0)
-    check(lib().sr_option_set(_option_id(name), int(value), C.byref(prev)), "sr_option_set")
+    if name in SPLIT_OPTION_NAMES:
+        with SPLIT_GUARD:
+            check(lib().sr_option_set(_option_id(name), int(value), C.byref(prev)), "sr_option_set")
+    else:
+        check(lib().sr_option_set(_option_id(name), int(value), C.byref(prev)), "sr_option_set")
     _OPTION_MIRROR[name] = int(value)
     for fn in OPTION_LISTENERS:
         fn(name, int(value))

@@ -161,15 +161,36 @@ def any_batchnorm_training(module):
     statistics cannot be folded into the conv weights).  The layer list is gathered once per module TREE: walking `modules()`
     costs ~1 ms per forward on the EfficientNetV2-S pyramid, so the list is cached together with the process-wide submodule
     registration count it was gathered under -- replacing a layer anywhere (also deep in the tree, which r04's key of
-    (training, number of direct children) missed) invalidates it.  The layers' own `training` flags are read on every call."""
+    (training, number of direct children) missed) invalidates it, and every cached layer is re-checked against its parent's
+    `_modules` entry (mutations the hook cannot see).  The layers' own `training` flags are read on every call."""
     rec = module.__dict__.get("_sr_bn_layers")
+    if rec is not None and rec[0] == _TREE_EPOCH[0]:
+        # the registration hook does not see direct mutations of `_modules` (del m.bn, ModuleList.__delitem__ / insert, fx or
+        # quantisation swaps): every cached layer must still sit where it was found (ADVICE r05; ~100 dict lookups)
+        for parent, name, layer in rec[1]:
+            if parent._modules.get(name) is not layer:
+                rec = None
+                break
     if rec is None or rec[0] != _TREE_EPOCH[0]:
-        rec = (_TREE_EPOCH[0], [m for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)])
+        found = []
+        for parent in module.modules():
+            for name, child in parent._modules.items():
+                if isinstance(child, nn.modules.batchnorm._BatchNorm):
+                    found.append((parent, name, child))
+        if isinstance(module, nn.modules.batchnorm._BatchNorm):
+            found.append((_Holder(module), "self", module))
+        rec = (_TREE_EPOCH[0], found)
         module.__dict__["_sr_bn_layers"] = rec
-    for m in rec[1]:
+    for _, _, m in rec[1]:
         if m.training:
             return True
     return False
+
+
+class _Holder:
+    """Stand-in parent for a batch-norm layer that is itself the root of the query."""
+    def __init__(self, m):
+        self._modules = {"self": m}
 
 
 def _dense_nhwc(t):

@@ -422,7 +422,7 @@ class FeatureVolumeManager(CostVolumeManager):
         sb, sd, sp = self._volume_strides(vol)
         from . import ops   # (ops.PROFILE: bench.py's in-step kernel table)
         prof = ops.PROFILE
-        with _lib.on_device(dev):
+        with _lib.SPLIT_GUARD, _lib.on_device(dev):   # (SR_MLP_SPLIT is read by the packing and by the sweep inside this one call)
             if prof is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()

@@ -5,6 +5,7 @@ A "channels-last view" is a logically [B,C,H,W] torch tensor whose memory is [B,
 this tensor occupying channels [c0, c0+C) of each pixel -- either a dense channels_last tensor or
 a channel slice `buf[:, c0:c1]` of one.  Kernels take (pointer, batch stride, pixel stride)."""
 import ctypes as C
+import contextlib
 import os
 import weakref
 
@@ -504,6 +505,15 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 return out
             if rc != 2:   # SR_ERR_UNSUPPORTED (per-image byte range): the F(2x2) kernel below
                 _lib.check(rc, "sr_conv3x3_wino4_nhwc_fwd")
+    guard = _lib.SPLIT_GUARD if use_wino else contextlib.nullcontext()   # (pack and launch must see ONE split mode)
+    with guard:
+        return _conv2d_launch(lib, x, conv, bn, residual, out, leaky, act, use_wino, padded, replicate, pads, prof,
+                              b, h, w, ci, co, k, s, ho, wo, isb, isp, osb, osp, rsb, rsp)
+
+
+def _conv2d_launch(lib, x, conv, bn, residual, out, leaky, act, use_wino, padded, replicate, pads, prof,
+                   b, h, w, ci, co, k, s, ho, wo, isb, isp, osb, osp, rsb, rsp):
+    """The F(2x2) Winograd / direct / padded / replicate launch of conv2d (its tail: everything behind the dispatch)."""
     wp, bias = packed_wino_weight(conv, bn) if use_wino else packed_weight(conv, bn)
     slope = C.c_float(_act_code(leaky, act))
     with _lib.on_device(x.device):

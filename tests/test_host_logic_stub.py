@@ -283,3 +283,21 @@ def test_batchnorm_layer_cache_sees_replacements_deep_in_the_tree():
     assert not A.any_batchnorm_training(m)
     m[0][1].train()                                  # a flag flipped on the leaf only
     assert A.any_batchnorm_training(m)
+
+
+def test_batchnorm_layer_cache_sees_direct_mutations_of_modules():
+    """torch's registration hook does not fire for direct `_modules` mutations (del m.bn, ModuleList.__delitem__,
+    fx / quantisation swaps); a cached layer that no longer sits where it was found invalidates the cache."""
+    from torch import nn
+    from simplerecon_amd import autograd_ops as A
+    inner = nn.Sequential(nn.BatchNorm2d(3))
+    m = nn.Sequential(nn.Conv2d(3, 3, 1), inner).eval()
+    assert not A.any_batchnorm_training(m)
+    fresh = nn.BatchNorm2d(3)                        # training mode
+    inner._modules["0"] = fresh                      # swapped in behind the hook's back
+    assert A.any_batchnorm_training(m)
+    del inner._modules["0"]                          # and removed the same way
+    assert not A.any_batchnorm_training(m)
+    bn = nn.BatchNorm2d(2)                           # a batch-norm layer as the root of the query
+    assert A.any_batchnorm_training(bn)
+    assert not A.any_batchnorm_training(bn.eval())
