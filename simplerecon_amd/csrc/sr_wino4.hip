@@ -1,4 +1,5 @@
-// sr_wino4.hip -- 3x3 / stride-1 convolutions through Winograd F(4x4, 3x3) on the fp32 matrix cores (gfx950), r05.
+// sr_wino4.hip -- 3x3 / stride-1 convolutions through Winograd F(4x4, 3x3) on the fp32 matrix cores (gfx950), r05; the
+// wave-specialised form every F(4x4) launch takes since r06 is described at sr_wino4ws_kernel below.
 //
 // Same operator as sr_conv3x3_wino_nhwc_fwd (conv + bias + residual + LeakyReLU of the reference's BasicBlock,
 // modules/layers.py:24-85), same arithmetic class (fp32 products, fp32 accumulation).  F(4x4, 3x3) needs 36 multiplies per
@@ -8,8 +9,9 @@
 // A^T is a dyadic rational (exact in fp32); measured fp32 error 1.3e-6 of the output range on a 64-channel layer (points
 // 0, +-1, +-2: 2.4e-6; F(2x2): 3e-7), far inside the 1e-4 parity bar -- tests/test_gpu_wino4.py holds it against fp64.
 //
-// Work item = 4 x 4 Winograd tiles (16 x 16 output pixels) x 64 output channels; a workgroup (4 waves, 2 per CU) walks
-// items persistently.  Per 16-channel slab of the input:
+// Work item = 4 x 4 Winograd tiles (16 x 16 output pixels) x 64 output channels; a workgroup walks items persistently.  In the
+// first form (sr_wino4_kernel: 4 waves, two workgroups per CU; kept for A/B and as the bit-identity reference), per 16-channel
+// slab of the input:
 //   S  the 18 x 18 pixel patch goes global -> registers -> LDS (`raw`, 20 floats per pixel); the loads of slab s + 1 are
 //      issued before the transform of slab s and have a whole slab of lead,
 //   T  thread (tile, ci) applies V = B^T d B to its 6 x 6 patch: 36 ds_read_b32, 144 VALU, 36 ds_write_b32 into
@@ -575,11 +577,12 @@ __device__ __forceinline__ void w4_bt2(w4_f2 d0, w4_f2 d1, w4_f2 d2, w4_f2 d3, w
 //   * the r05 M waves also loaded the patches, in the same in-order vmcnt queue as their weight fragments: the first MFMA of a tick
 //     waited for the L2 misses of a patch that was not needed for another tick (the last slab of an item ran 5-10 k clocks
 //     instead of 4.9 k).  Here the M waves' only memory traffic is the weight stream, prefetched four frequency pairs ahead;
-//   * a wave next to an MFMA stream issues ONE instruction per MFMA (scripts/micro/mfma16_overlap.hip), so every T-wave
-//     instruction is worth 37 clocks while the M waves stream.  The r05 T waves executed ~1 550 instructions per 64 -> 64 item
-//     (576 MFMA slots): the item decode's integer divisions on every tick (~110), both sums and a select per value around a
-//     uniform `has_res`, a branch per store; the M waves idled at the barrier behind them.  Here: ~145 per tick + ~230 per item;
-//     the item cursor advances by additions, residual / activation class are template parameters;
+//   * a wave next to an MFMA stream issues at most ONE instruction per MFMA (scripts/micro/mfma16_overlap.hip; in this kernel
+//     one per two or three), so every T-wave instruction is worth 40-90 clocks while the M waves stream.  The r05 T waves executed
+//     ~1 550 instructions per 64 -> 64 item (576 MFMA slots): the item decode's integer divisions on every tick (~110), both
+//     sums and a select per value around a uniform `has_res`, a branch per store; the M waves idled at the barrier behind them.
+//     Here: ~120 per tick + ~250 per item; the item cursor advances by additions, residual / activation class are template
+//     parameters, the transform needs no lane swaps;
 //   * the M waves' output transform runs on channel pairs (240 v_pk_* instead of 432 instructions), the accumulators are not
 //     cleared (the first MFMA of a frequency takes C = 0);
 //   * tried and dropped: patches straight into the T waves' registers in transform layout (18 8-byte loads per lane, no staging
@@ -588,9 +591,10 @@ __device__ __forceinline__ void w4_bt2(w4_f2 d0, w4_f2 d1, w4_f2 d2, w4_f2 d3, w
 //     (of a 4.9-k tick) and the T waves became the critical path (202 us).
 // Per TICK (one workgroup barrier F), k = 0 .. K over the slabs of all the workgroup's items in a row:
 //   T waves: [tile half 0 of the item that closed in tick k - 1: LDS -> registers; barriers B2, B3]
-//            patch k + 1 (in registers since tick k - 1) -> raw[(k + 1) & 1]; loads of patch k + 2;
-//            [that item's output side: half 0, then half 1 from LDS];  V[k & 1] = B^T d B of raw[k & 1];
-//            [residual loads of the item the M waves are closing in this tick]
+//            [residual loads of the item the M waves are closing in this tick: consumed a tick and a half later]
+//            V[k & 1] = B^T d B of raw[k & 1]   (first: it needs nothing from memory, the patch loads in flight get the whole tick)
+//            [the closed item's output side: half 0, then half 1 from LDS]
+//            patch k + 1 (in registers since tick k - 1) -> raw[(k + 1) & 1]; loads of patch k + 2
 //   M waves: MFMAs of slab k - 1 on V[(k - 1) & 1]; if that closes an item: Y = A^T M A in place, rows 0-1 of every tile -> LDS,
 //            F, B2 (the T waves have read them), rows 2-3 -> LDS, B3.
 // raw and V are double-buffered, the hand-over buffer holds half a tile: 158 336 of the CU's 163 840 bytes.
