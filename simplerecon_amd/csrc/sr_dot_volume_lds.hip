@@ -162,17 +162,25 @@ __device__ __forceinline__ void sr_pair_taps(const SrPair& s, bool ok0, bool ok1
 // Staging of a footprint box, chunk by chunk (compile-time recursion keeps the register array statically indexed):
 // chunk u of this wave = chunk (wave + 4u) of the box = 16 consecutive texels of one row; lane = (texel, channel quad).
 // row = chunk / nchunk through a 16.16 fixed-point reciprocal (exact for the < 128 chunks of a box): scalar ALU only.
+// r06: buffer loads -- the row part of a chunk's address is scalar (soffset = clamped row * row bytes), the lane part is
+// clamp(lane column + chunk column) * 64 + channel quad: 3 vector instructions per chunk instead of the 11 of the 64-bit flat
+// address (PMC r02-r06: the sweep's issue port is saturated, 2 785 VALU + 1 466 SALU per wave; a fifth of them was this
+// address arithmetic).  Same texels, same order, same values.
 template <int U, int NU, int U0>
 __device__ __forceinline__ void sr_stage_load(const SrLdsCtx& c, sr_f4 (&v)[NU], unsigned rcp_nchunk, int nchunk,
-                                              int nchunks, int minx, int miny) {
+                                              int nchunks, int lane_x0, int miny, __amdgpu_buffer_rsrc_t rs_img) {
   if constexpr (U < NU) {
     const int ch = c.wave + 4 * (U0 + U);
     if (ch < nchunks) {
-      const int ry = (int)(((unsigned)ch * rcp_nchunk) >> 16), cx = ch - ry * nchunk;
-      const int tq = c.lane & 3, tt = c.lane >> 2;
-      const int gx = min(max(minx - 1 + cx * 16 + tt, 0), c.w - 1), gy = min(max(miny - 1 + ry, 0), c.h - 1);
-      v[U] = *reinterpret_cast<const sr_f4*>(c.img + ((size_t)(gy * c.w + gx)) * 16 + tq * 4);
-      sr_stage_load<U + 1, NU, U0>(c, v, rcp_nchunk, nchunk, nchunks, minx, miny);
+      const int ry = (int)(((unsigned)ch * rcp_nchunk) >> 16), cx = ch - ry * nchunk;   // (scalar)
+      const int gy = min(max(miny - 1 + ry, 0), c.h - 1);                               // (scalar)
+      const int gx = min(max(lane_x0 + cx * 16, 0), c.w - 1);
+#ifdef SR_DOT_ABL_HOT   // (timing experiment: every staging load hits the same L1-resident texels -- what the load latency costs)
+      v[U] = __builtin_bit_cast(sr_f4, __builtin_amdgcn_raw_buffer_load_b128(rs_img, (gx & 1) * 64 + (c.lane & 3) * 16, (gy & 1) * 64, 0));
+#else
+      v[U] = __builtin_bit_cast(sr_f4, __builtin_amdgcn_raw_buffer_load_b128(rs_img, gx * 64 + (c.lane & 3) * 16, gy * c.w * 64, 0));
+#endif
+      sr_stage_load<U + 1, NU, U0>(c, v, rcp_nchunk, nchunk, nchunks, lane_x0, miny, rs_img);
     }
   }
 }
@@ -225,15 +233,18 @@ __device__ __forceinline__ void sr_lds_unit(SrLdsCtx& c, const unsigned (&xy)[G]
     // two batches (6 + the rest of the <= NU chunks of a wave): 24 staging registers instead of 40 keep the kernel
     // inside the 128-register budget of 4 workgroups per CU; typical boxes (<= 24 chunks) need the first batch only
     constexpr int NU = (CAP / 16 + 3) / 4, NA = NU < 6 ? NU : 6;
+    const __amdgpu_buffer_rsrc_t rs_img =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.img), 0, c.h * c.w * 64, 0x00020000);
+    const int lane_x0 = minx - 1 + (c.lane >> 2);
     {
       sr_f4 v[NA];
-      sr_stage_load<0, NA, 0>(c, v, rcp_nchunk, nchunk, nchunks, minx, miny);
+      sr_stage_load<0, NA, 0>(c, v, rcp_nchunk, nchunk, nchunks, lane_x0, miny, rs_img);
       sr_stage_store<CAP, 0, NA, 0>(c, v, nchunks);
     }
     if constexpr (NU > NA) {
       if (c.wave + 4 * NA < nchunks) {
         sr_f4 v[NU - NA];
-        sr_stage_load<0, NU - NA, NA>(c, v, rcp_nchunk, nchunk, nchunks, minx, miny);
+        sr_stage_load<0, NU - NA, NA>(c, v, rcp_nchunk, nchunk, nchunks, lane_x0, miny, rs_img);
         sr_stage_store<CAP, 0, NU - NA, NA>(c, v, nchunks);
       }
     }
