@@ -181,6 +181,12 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     collective = world > 1 or args.force_collective
+    # RCCL prints a version banner on STDOUT when its first communicator comes up ("RCCL version : ..."): the contract is ONE JSON
+    # line there.  Everything the process (and the libraries under it) writes to file descriptor 1 goes to stderr instead; the
+    # JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
@@ -270,7 +276,8 @@ def main():
         if world == 1 and name == bench_workloads.DEFAULT and args.experiments and not args.no_experiments:
             out["experiments"] = [_fenced_experiment("hero_cfg3_f16x3_convs", min(args.steps, 10), args.warmup)]
         _flush_c_stdio()
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if collective:
         dist.barrier()
         dist.destroy_process_group()
