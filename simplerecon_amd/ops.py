@@ -505,74 +505,73 @@ def conv2d(x, conv: nn.Conv2d, residual=None, leaky=None, out=None, bn=None, act
                 return out
             if rc != 2:   # SR_ERR_UNSUPPORTED (per-image byte range): the F(2x2) kernel below
                 _lib.check(rc, "sr_conv3x3_wino4_nhwc_fwd")
-    guard = _lib.SPLIT_GUARD if use_wino else contextlib.nullcontext()   # (pack and launch must see ONE split mode)
-    with guard:
-        return _conv2d_launch(lib, x, conv, bn, residual, out, leaky, act, use_wino, padded, replicate, pads, prof,
-                              b, h, w, ci, co, k, s, ho, wo, isb, isp, osb, osp, rsb, rsp)
-
-
-def _conv2d_launch(lib, x, conv, bn, residual, out, leaky, act, use_wino, padded, replicate, pads, prof,
-                   b, h, w, ci, co, k, s, ho, wo, isb, isp, osb, osp, rsb, rsp):
-    """The F(2x2) Winograd / direct / padded / replicate launch of conv2d (its tail: everything behind the dispatch)."""
-    wp, bias = packed_wino_weight(conv, bn) if use_wino else packed_weight(conv, bn)
-    slope = C.c_float(_act_code(leaky, act))
-    with _lib.on_device(x.device):
-        if prof is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        if padded:
-            rc = lib.sr_conv2d_padded_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
-                                               rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, *pads, slope,
-                                               _lib.stream_ptr(x.device))
-        elif use_wino:
-            nbytes = _shape_query(lib, "sr_wino_splitk_workspace_bytes", b, h, w, ci, co, dev=x.device.index)   # 0 unless the plan splits K
-            ws = _workspace(x.device, "wino_splitk", nbytes) if nbytes else None
-            rc = lib.sr_conv3x3_wino_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
-                                                     _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
-                                                     co, slope, _lib.ptr(ws), nbytes, _lib.stream_ptr(x.device))
-        elif replicate:
-            rc = lib.sr_conv2d_replicate_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
-                                                  _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
-                                                  co, k, s, slope, _lib.stream_ptr(x.device))
-        else:
-            nbytes = _shape_query(lib, "sr_conv_splitk_workspace_bytes", b, h, w, ci, co, k, s, dev=x.device.index)   # 0 unless it may split K
-            ws = _workspace(x.device, "conv_splitk", nbytes) if nbytes else None
-            rc = lib.sr_conv2d_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
-                                               rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope,
-                                               _lib.ptr(ws), nbytes, _lib.stream_ptr(x.device))
-        if prof is not None:
-            ev1.record()
-            v4 = int(x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0)
-            if use_wino:
-                vin = bool(v4 and ci % 4 == 0)
-                al = lambda t, sb_, sp_: t is None or (t.data_ptr() % 16 == 0 and sp_ % 4 == 0 and sb_ % 4 == 0)
-                vout = vin and co % 4 == 0 and al(out, osb, osp) and al(residual, rsb, rsp) and \
-                    (bias is None or bias.data_ptr() % 16 == 0)
-                name = lib.sr_wino_kernel_name(b, h, w, ci, co, int(vin), int(vout)).decode()
-                if wino_split_mode():   # (the fenced variant: sr_wino_split_kernel<NT, FMT>)
-                    name = name.replace("sr_wino_kernel<", "sr_wino_split_kernel<").replace(
-                        ", true, true>", f", {1 if wino_split_mode() == 'bf16' else 2}>")
-            else:
-                name = lib.sr_conv_kernel_name(b, h, w, ci, co, k, s, v4).decode()
-            executed = None
-            if use_wino:  # multiplies actually issued: 16 per 2x2 tile and (ci, co) pair, on padded regions / channels
-                regions = ((h + 7) // 8) * ((w + 15) // 16)
-                executed = 2.0 * b * regions * 32 * 16 * ((ci + 15) // 16 * 16) * ((co + 31) // 32 * 32)
-            prof.append((name, 2.0 * b * ho * wo * co * ci * k * k, ev0, ev1,
-                         (b, ci, h, w, co, k, s, ho, wo, residual is not None), executed))
-    if use_wino and rc == 2 and not wino_split_mode():
-        # SR_ERR_UNSUPPORTED from the Winograd entry point (a per-image byte range past 2^31: its buffer descriptors carry 32-bit
-        # offsets): the implicit-GEMM kernel serves the shape with 64-bit addressing, as it did before r04
-        if prof is not None:
-            prof.pop()
-        wp, bias = packed_weight(conv, bn)
+    # (pack and launch must see ONE split mode: ADVICE r05.  A plain acquire / release -- a context manager object per call costs
+    # a microsecond on a launch path that is host-bound at batch 1)
+    if use_wino:
+        _lib.SPLIT_GUARD.acquire()
+    try:
+        wp, bias = packed_wino_weight(conv, bn) if use_wino else packed_weight(conv, bn)
+        slope = C.c_float(_act_code(leaky, act))
         with _lib.on_device(x.device):
-            rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb, rsp,
-                                        _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope, _lib.stream_ptr(x.device))
-        _lib.check(rc, "sr_conv2d_nhwc_fwd")
+            if prof is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            if padded:
+                rc = lib.sr_conv2d_padded_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
+                                                   rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, *pads, slope,
+                                                   _lib.stream_ptr(x.device))
+            elif use_wino:
+                nbytes = _shape_query(lib, "sr_wino_splitk_workspace_bytes", b, h, w, ci, co, dev=x.device.index)   # 0 unless the plan splits K
+                ws = _workspace(x.device, "wino_splitk", nbytes) if nbytes else None
+                rc = lib.sr_conv3x3_wino_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
+                                                         _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
+                                                         co, slope, _lib.ptr(ws), nbytes, _lib.stream_ptr(x.device))
+            elif replicate:
+                rc = lib.sr_conv2d_replicate_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias),
+                                                      _lib.ptr(residual), rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci,
+                                                      co, k, s, slope, _lib.stream_ptr(x.device))
+            else:
+                nbytes = _shape_query(lib, "sr_conv_splitk_workspace_bytes", b, h, w, ci, co, k, s, dev=x.device.index)   # 0 unless it may split K
+                ws = _workspace(x.device, "conv_splitk", nbytes) if nbytes else None
+                rc = lib.sr_conv2d_splitk_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual),
+                                                   rsb, rsp, _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope,
+                                                   _lib.ptr(ws), nbytes, _lib.stream_ptr(x.device))
+            if prof is not None:
+                ev1.record()
+                v4 = int(x.data_ptr() % 16 == 0 and isp % 4 == 0 and isb % 4 == 0)
+                if use_wino:
+                    vin = bool(v4 and ci % 4 == 0)
+                    al = lambda t, sb_, sp_: t is None or (t.data_ptr() % 16 == 0 and sp_ % 4 == 0 and sb_ % 4 == 0)
+                    vout = vin and co % 4 == 0 and al(out, osb, osp) and al(residual, rsb, rsp) and \
+                        (bias is None or bias.data_ptr() % 16 == 0)
+                    name = lib.sr_wino_kernel_name(b, h, w, ci, co, int(vin), int(vout)).decode()
+                    if wino_split_mode():   # (the fenced variant: sr_wino_split_kernel<NT, FMT>)
+                        name = name.replace("sr_wino_kernel<", "sr_wino_split_kernel<").replace(
+                            ", true, true>", f", {1 if wino_split_mode() == 'bf16' else 2}>")
+                else:
+                    name = lib.sr_conv_kernel_name(b, h, w, ci, co, k, s, v4).decode()
+                executed = None
+                if use_wino:  # multiplies actually issued: 16 per 2x2 tile and (ci, co) pair, on padded regions / channels
+                    regions = ((h + 7) // 8) * ((w + 15) // 16)
+                    executed = 2.0 * b * regions * 32 * 16 * ((ci + 15) // 16 * 16) * ((co + 31) // 32 * 32)
+                prof.append((name, 2.0 * b * ho * wo * co * ci * k * k, ev0, ev1,
+                             (b, ci, h, w, co, k, s, ho, wo, residual is not None), executed))
+        if use_wino and rc == 2 and not wino_split_mode():
+            # SR_ERR_UNSUPPORTED from the Winograd entry point (a per-image byte range past 2^31: its buffer descriptors carry 32-bit
+            # offsets): the implicit-GEMM kernel serves the shape with 64-bit addressing, as it did before r04
+            if prof is not None:
+                prof.pop()
+            wp, bias = packed_weight(conv, bn)
+            with _lib.on_device(x.device):
+                rc = lib.sr_conv2d_nhwc_fwd(_lib.ptr(x), isb, isp, _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(residual), rsb, rsp,
+                                            _lib.ptr(out), osb, osp, b, h, w, ci, co, k, s, slope, _lib.stream_ptr(x.device))
+            _lib.check(rc, "sr_conv2d_nhwc_fwd")
+            return out
+        _lib.check(rc, "sr_conv3x3_wino_nhwc_fwd" if use_wino else "sr_conv2d_nhwc_fwd")
         return out
-    _lib.check(rc, "sr_conv3x3_wino_nhwc_fwd" if use_wino else "sr_conv2d_nhwc_fwd")
-    return out
+    finally:
+        if use_wino:
+            _lib.SPLIT_GUARD.release()
 
 
 def basic_block(block, x, out=None):
