@@ -112,6 +112,31 @@ def test_wino4_numerics_on_offset_and_heavy_tailed_inputs(family, shape):
     assert e["w4"][1] < 40 * max(e["w2"][1], 1e-8), f"F(4x4) rms error {e['w4'][1]} vs F(2x2) {e['w2'][1]}"
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 48, 64, 64, True), (1, 24, 35, 53, 64, True), (1, 128, 24, 40, 128, False)], ids=str)
+def test_wino4_against_the_oracle_convolution(shape):
+    """The same layer through the CPU oracle (oracle/sr_oracle.c, the restatement pinned against the reference's modules in
+    tests/golden) rather than ATen: conv3x3 + bias + residual + LeakyReLU(0.2), fp64 accumulation, on post-ReLU inputs."""
+    import numpy as np
+    import wino_numerics as WN
+    import oracle as O
+    b, ci, h, w, co, with_res = shape
+    torch.manual_seed(ci * 7 + co)
+    conv = torch.nn.Conv2d(ci, co, 3, padding=1).to(DEV)
+    x = WN.make_input("relu", (b, ci, h, w), DEV).contiguous(memory_format=torch.channels_last)
+    res = WN.make_input("randn", (b, co, h, w), DEV, seed=3).contiguous(memory_format=torch.channels_last) if with_res else None
+    with torch.inference_mode():
+        y4 = _run("w4_ws", x, conv, res, 0.2)
+        ya = _ref64(x, conv, res, 0.2)
+    ref = O.conv2d(x.cpu().numpy(), conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(),
+                   residual=None if res is None else res.cpu().numpy(), leaky=0.2, precision="f64")
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(y4.cpu().double().numpy() - ref).max()) / scale
+    aten = float(np.abs(ya.cpu().numpy() - ref).max()) / scale
+    print(f"{shape}: F(4x4) vs oracle fp64 {err:.2e} of the range; ATen fp64 vs oracle fp64 {aten:.2e}")
+    assert aten < 1e-12, "the two fp64 references disagree"
+    assert err < 2e-5
+
+
 def test_wino4_writes_into_a_concat_slice_and_reads_from_one():
     torch.manual_seed(3)
     conv = torch.nn.Conv2d(32, 64, 3, padding=1).to(DEV)
