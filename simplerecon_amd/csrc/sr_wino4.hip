@@ -100,6 +100,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_rsrc(const void* base, int6
 __device__ __forceinline__ w4_f4 w4_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(w4_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
+// cache-policy probes for the wave-specialised kernel's streams (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1); product: 0
+#ifndef SR_W4WS_DEPHASE_UNIT
+#define SR_W4WS_DEPHASE_UNIT 1
+#endif
+#ifndef SR_W4WS_AUX_PATCH
+#define SR_W4WS_AUX_PATCH 0
+#endif
+#ifndef SR_W4WS_AUX_RES
+#define SR_W4WS_AUX_RES 0
+#endif
+#ifndef SR_W4WS_AUX_OUT
+#define SR_W4WS_AUX_OUT 0
+#endif
+template <int AUX>
+__device__ __forceinline__ w4_f4 w4_load_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(w4_f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void w4_store_aux(w4_f4 v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4_u4, v), r, (int)voff, 0, AUX);
+}
 // (the delta rides in the LANE offset: a 16-byte buffer store with an SGPR offset operand followed by a VALU write to its
 // data registers stores the new contents on gfx950 -- sr_wino.h, r04)
 __device__ __forceinline__ void w4_store(w4_f4 v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
@@ -740,10 +761,10 @@ __device__ __forceinline__ void w4ws_stage(const SrWino4Params& p, const W4Item&
     const unsigned base = (unsigned)(((it.oy0 - 1) * p.W + (it.ox0 - 1)) * p.in_sp + 16 * s) * 4u;   // scalar offset operand
     if (valid && 16 * s + 16 <= p.Cin) {   // (uniform) every channel quad of the slab exists
 #pragma unroll
-      for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load(rs_in, st_off[j], base);
+      for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load_aux<SR_W4WS_AUX_PATCH>(rs_in, st_off[j], base);
     } else {
 #pragma unroll
-      for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load(rs_in, chan_ok ? st_off[j] : W4_OOB, base);
+      for (int j = 0; j < W4_STAGE; ++j) st[j] = w4_load_aux<SR_W4WS_AUX_PATCH>(rs_in, chan_ok ? st_off[j] : W4_OOB, base);
     }
   } else {
     const unsigned q_off = (unsigned)(16 * s + 4 * st_q) * 4u;
@@ -784,6 +805,9 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
 #else
   const int n_items = ((int)p.total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int first = (int)blockIdx.x, item_stride = (int)gridDim.x;
+#endif
+#ifdef SR_W4WS_DEPHASE   // (probe builds: workgroups start a fraction of a tick apart -- profiles/r06_w4ws_trace.txt section 11)
+  for (int i = (((int)blockIdx.x >> 3) * SR_W4WS_DEPHASE) & 63; i > 0; --i) __builtin_amdgcn_s_sleep(SR_W4WS_DEPHASE_UNIT);
 #endif
   const int K = n_items * p.S;
   const bool one_slab = p.S == 1;   // an item closes on EVERY tick: half 1 of a tile is read in the tick that writes half 0 of the next
@@ -862,10 +886,10 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
         for (int i = 0; i < 8; ++i) {
           const unsigned d = (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.res_sp) * 4u;   // scalar
           if (full) {
-            rv[8 * h + i] = w4_load(rs_res, rl, rbase + d);
+            rv[8 * h + i] = w4_load_aux<SR_W4WS_AUX_RES>(rs_res, rl, rbase + d);
           } else {
             const bool ok = (eit.oy0 + 4 * (i >> 1) + 2 * h + o_kk < p.H) & (eit.ox0 + 4 * o_t0 + 8 * (i & 1) + o_l < p.W);
-            rv[8 * h + i] = w4_load(rs_res, ok ? rl : W4_OOB, rbase + d);
+            rv[8 * h + i] = w4_load_aux<SR_W4WS_AUX_RES>(rs_res, ok ? rl : W4_OOB, rbase + d);
           }
         }
     };
@@ -903,14 +927,14 @@ __global__ __launch_bounds__(512, 2) void sr_wino4ws_kernel(SrWino4Params p) {
       if (full) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          w4_store(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out,
-                   ol + obase + (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.out_sp) * 4u);
+          w4_store_aux<SR_W4WS_AUX_OUT>(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out,
+                                        ol + obase + (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.out_sp) * 4u);
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const bool ok = (eit.oy0 + 4 * (i >> 1) + 2 * h + o_kk < p.H) & (eit.ox0 + 4 * o_t0 + 8 * (i & 1) + o_l < p.W);
           const unsigned voff = ol + obase + (unsigned)(((4 * (i >> 1) + 2 * h) * p.W + 8 * (i & 1)) * p.out_sp) * 4u;
-          w4_store(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out, ok ? voff : W4_OOB);
+          w4_store_aux<SR_W4WS_AUX_OUT>(w4_f4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, rs_out, ok ? voff : W4_OOB);
         }
       }
     };
@@ -1188,6 +1212,11 @@ static void w4_trace_end(int blocks, hipStream_t stream) {
       }
       fprintf(stderr, "\n");
     }
+  {   // shader clock of workgroup 0 over its whole run: clock64 ticks per wall_clock64 tick (100 MHz)
+    const unsigned long long* t = host + (W4_TR_N - 4);
+    if (t[3] > t[1]) fprintf(stderr, "W4CLOCK %.3f GHz over %.1f us\n", 0.1 * (double)(t[2] - t[0]) / (double)(t[3] - t[1]),
+                             (double)(t[3] - t[1]) * 0.01);
+  }
   free(host);
 }
 #endif
@@ -1225,6 +1254,9 @@ static int w4_run(const float* in, int64_t in_batch_stride, int in_pix_stride, c
   p.slope = leaky_slope;
   if (variant == 3) {   // wave-specialised: 4 MFMA waves + 4 transform waves, one workgroup per CU
     int blocks = w4_num_cus();
+#ifdef SR_W4WS_MAXBLOCKS   // (probe builds: how much of an item's time is chip-wide contention -- profiles/r06_w4ws_trace.txt section 11)
+    if (blocks > SR_W4WS_MAXBLOCKS) blocks = SR_W4WS_MAXBLOCKS;
+#endif
     if (blocks > p.total) blocks = p.total;
     const bool generic_act = !((leaky_slope >= 0.0f && leaky_slope <= 1.0f) || (leaky_slope < 0.0f && leaky_slope > -1.5f));
     auto kernel = generic_act ? (residual ? sr_wino4ws_kernel<true, true> : sr_wino4ws_kernel<true, false>)
