@@ -546,6 +546,9 @@ static int sr_conv_launch(SrConvParams& p, int B, int nt, hipStream_t stream) {
   if (p.ksplit > 1) {   // split-K plan (1x1 / stride 1 only, see sr_conv2d_dispatch): fill the 2-per-CU slots once
     const int chunks = p.G / (G::CK / 8);
     int ks = (2 * sr_num_cus()) / p.total_tiles;
+    // 3x3 / stride 2: a work item is 9 taps deep and the finish is a second launch -- measured (scripts/conv_s2_sweep.py): 72 items x
+    // 16 slabs 56 -> 28 us split 8 ways, 150 items x 4 slabs 19 -> 28 us split in two, 144 items at batch 8 94 -> 102 us split in three
+    if (KS == 3 && 2 * p.total_tiles > sr_num_cus()) ks = 1;
     if (ks > chunks / 2) ks = chunks / 2;
     if (ks > p.ksplit) ks = p.ksplit;
     p.ksplit = ks < 2 ? 1 : ks;
@@ -608,14 +611,17 @@ static SrConvCfg sr_conv_cfg(const SrConvParams& p, int B, int stride, int ksize
   return cfg;
 }
 
-// Split-K is planned for 1x1 / stride-1 convolutions only (the deep projections of the image-prior encoder's MBConv
-// blocks: 1536 -> 256 channels on 15x20 maps is 24 slabs in a row on a few dozen workgroups); the finishing kernel
-// works on 16-byte channel quads.
+// Split-K is planned for 1x1 / stride-1 convolutions (the deep projections of the image-prior encoder's MBConv
+// blocks: 1536 -> 256 channels on 15x20 maps is 24 slabs in a row on a few dozen workgroups) and, since r06, for 3x3 /
+// stride-2 convolutions on small maps (256 -> 384 onto a 15x20 map at batch 1: 72 workgroups x 16 slabs in a row, 56 us);
+// the finishing kernel works on 16-byte channel quads.
 #define SR_CONV_KSPLIT_MAX 8
 static bool sr_conv_splitk_eligible(const float* out, int64_t out_sb, int out_sp, const float* bias, const float* res,
                                     int64_t res_sb, int res_sp, int Cin, int Cout, int ksize, int stride) {
   const int on = sr_opt(SR_OPT_CONV_KSPLIT);
-  if (!on || ksize != 1 || stride != 1 || Cout % 4 != 0 || Cin < 4 * SR_CK1) return false;
+  const bool pw = ksize == 1 && stride == 1 && Cin >= 4 * SR_CK1;
+  const bool s2 = ksize == 3 && stride == 2 && Cin >= 8 * sr_ck(3);   // r06: the deep down-convolutions of CVEncoder at batch 1
+  if (!on || !(pw || s2) || Cout % 4 != 0) return false;
   auto al = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   if (!al(out) || out_sp % 4 != 0 || out_sb % 4 != 0 || (bias && !al(bias))) return false;
   if (res && (!al(res) || res_sp % 4 != 0 || res_sb % 4 != 0)) return false;
@@ -724,11 +730,15 @@ extern "C" int sr_conv2d_padded_nhwc_fwd(const float* in, int64_t in_batch_strid
 }
 
 extern "C" size_t sr_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
-  if (B <= 0 || H <= 0 || W <= 0 || ksize != 1 || stride != 1 || Cout % 4 != 0 || Cin < 4 * SR_CK1) return 0;
-  // small pixel counts only: with >= 2 work items per CU already there is nothing to gain
-  const int64_t px = (int64_t)B * H * W;
+  if (B <= 0 || H <= 0 || W <= 0 || Cout % 4 != 0) return 0;
+  const bool pw = ksize == 1 && stride == 1 && Cin >= 4 * SR_CK1;
+  const bool s2 = ksize == 3 && stride == 2 && Cin >= 8 * sr_ck(3);
+  if (!pw && !s2) return 0;
+  // small pixel counts only: with >= 2 work items per CU already (1x1) / one per CU (3x3: a work item is 9x the MFMAs) there is
+  // nothing to gain
+  const int64_t px = s2 ? (int64_t)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) : (int64_t)B * H * W;
   const int64_t tiles = ((px + 127) / 128) * ((Cout + 31) / 32);
-  if (tiles >= 2 * sr_num_cus()) return 0;
+  if (s2 ? 2 * tiles > sr_num_cus() : tiles >= 2 * sr_num_cus()) return 0;
   return (size_t)SR_CONV_KSPLIT_MAX * px * Cout * sizeof(float);
 }
 

@@ -141,6 +141,35 @@ def test_winograd_split_k(shape):
     assert_close(y, ref, tol=1e-5, what=f"split-K Winograd conv {shape}")
 
 
+@pytest.mark.parametrize("shape", [(1, 256, 30, 40, 384, False), (1, 128, 60, 80, 256, False), (2, 192, 17, 23, 96, True),
+                                   (1, 144, 9, 7, 40, True)])
+def test_strided_conv_split_k(shape, sr_option):
+    """The 3x3 / stride-2 down-convolutions of CVEncoder (reference modules/networks.py:38-55) on small maps run split-K
+    since r06 (sr_conv2d_splitk_nhwc_fwd: partial outputs + the deterministic finish that applies bias / residual / LeakyReLU
+    once): the oracle's result, bit-reproducible, and -- where the plan really splits -- the low-order bits of a different
+    summation order than the unsplit launch."""
+    from simplerecon_amd import _lib
+    b, ci, h, w, co, with_res = shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    rng = np.random.default_rng(sum(shape[:5]))
+    x = rng.standard_normal((b, ci, h, w), dtype=np.float32)
+    res = rng.standard_normal((b, co, ho, wo), dtype=np.float32) if with_res else None
+    conv = synthetic.seeded_fill_(torch.nn.Conv2d(ci, co, 3, stride=2, padding=1), seed=11).to(DEV)
+    xt = torch.from_numpy(x).to(DEV)
+    rt = torch.from_numpy(res).to(DEV) if with_res else None
+    assert _lib.lib().sr_conv_splitk_workspace_bytes(b, h, w, ci, co, 3, 2) > 0, "this shape should be offered a split-K workspace"
+    with torch.inference_mode():
+        y = ops.conv2d(xt, conv, residual=rt, leaky=0.2)
+        y2 = ops.conv2d(xt, conv, residual=rt, leaky=0.2)
+        sr_option("SR_CONV_KSPLIT", 0)
+        y1 = ops.conv2d(xt, conv, residual=rt, leaky=0.2)
+    assert torch.equal(y, y2), "split-K finish must be deterministic"
+    ref = oracle.conv2d(x, conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy(), stride=2, residual=res, leaky=0.2)
+    assert_close(y, ref, tol=1e-5, what=f"split-K strided conv {shape}")
+    assert_close(y1, ref, tol=1e-5, what=f"unsplit strided conv {shape}")
+    assert_close(y, y1, tol=5e-6, what="split vs unsplit plan (summation order over K = 9 Cin only)")
+
+
 def test_conv_random_shapes_and_options():
     """Randomised sweep over the conv dispatcher (direct / Winograd / split-K, 32- or 64-channel blocks, vector or
     scalar epilogue): odd sizes, channel counts that are not multiples of 4 / 16 / 32, with and without bias,
