@@ -7,6 +7,9 @@ dev = "cuda:0"
 shapes = [(8, 1536, 15, 20, 256, True, True), (8, 960, 30, 40, 160, True, True), (8, 256, 15, 20, 1536, False, False),
           (8, 160, 30, 40, 960, False, False), (8, 192, 240, 320, 64, False, False), (8, 128, 60, 80, 64, False, False),
           (8, 512, 30, 40, 128, True, True), (8, 128, 30, 40, 512, False, False), (8, 192, 120, 160, 48, False, True)]
+if os.environ.get("SR_SWEEP_B1", "0") == "1":   # the same layers at batch 1 (the reference's published operating point)
+    shapes = [(1,) + s[1:] for s in shapes] + [(1, 256, 30, 40, 128, False, False), (1, 384, 15, 20, 256, False, False),
+                                               (1, 256, 60, 80, 64, False, True), (1, 768, 30, 40, 160, True, False)]
 TILED = os.environ.get("SR_SWEEP_TILED", "0") == "1"
 plans = [None, (1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (2, 4), (4, 1), (5, 1)]
 if TILED:
