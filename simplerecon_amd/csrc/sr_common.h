@@ -17,6 +17,9 @@
 // first access in the process (sr_options.hip)
 int sr_opt(int id);
 
+// CU count of the CURRENT device, cached per device index (sr_options.hip); 256 when the runtime cannot be asked
+int sr_device_cus();
+
 static inline int sr_hip_rc(hipError_t e) { return e == hipSuccess ? SR_OK : SR_ERR_HIP_BASE + (int)e; }
 
 static inline size_t sr_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -525,16 +525,7 @@ extern "C" int sr_conv_pack_weights(const float* weight, int Cout, int Cin, int 
   return sr_hip_rc(hipGetLastError());
 }
 
-static int sr_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    else cus = 256;
-  }
-  return cus;
-}
+static int sr_num_cus() { return sr_device_cus(); }
 
 template <int KS, int S, int MT, int CM>
 static int sr_conv_launch(SrConvParams& p, int B, int nt, hipStream_t stream) {

@@ -809,16 +809,7 @@ __global__ __launch_bounds__(256, 3) void sr_t16_kernel(SrT16Params p) {
 
 // ------------------------------------------------------------------ C ABI -------------
 
-static int sr_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    else cus = 256;
-  }
-  return cus;
-}
+static int sr_cus() { return sr_device_cus(); }
 
 extern "C" size_t sr_conv3x3_c16_packed_weight_floats(int Cout, int Cin) {
   if (Cout <= 0 || Cout > 16 || Cin <= 0 || (Cin % 32)) return 0;

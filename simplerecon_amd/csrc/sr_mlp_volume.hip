@@ -996,11 +996,7 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
   p.debug = 0;
 #endif
 
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = sr_device_cus();
   // planes per work unit: as many as possible (the hoisted invariant part is paid once per unit) while the
   // units still spread evenly over the 4*CUs persistent waves
   {

@@ -723,8 +723,7 @@ extern "C" int sr_mlp_volume_bwd(const float* grad_cv, int64_t g_sb, int64_t g_s
   p.inv_w = 1.0f / (float)w; p.inv_h = 1.0f / (float)h; p.slope = leaky_slope;
   const size_t lds = sr_mlp_bwd_lds_floats(K, C, Cin) * sizeof(float);
   if (lds > 160 * 1024) return SR_ERR_UNSUPPORTED;
-  int cus = 256;
-  { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
+  const int cus = sr_device_cus();
   const int blocks = p.total_items < cus ? p.total_items : cus;
 #define SR_BWD_LAUNCH(KERNEL)                                                                                          \
   {                                                                                                                    \

@@ -83,3 +83,18 @@ extern "C" int sr_option_default(int id, int* value) {
   *value = kDefs[id].dflt;
   return SR_OK;
 }
+
+// CU count of the current device, cached per device index (launch plans of every translation unit ask this; ADVICE r05: a
+// process-wide static answered with the first device's count for all of them)
+int sr_device_cus() {
+  constexpr int kMaxDevices = 64;
+  static std::atomic<int> cus[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}

@@ -219,16 +219,7 @@ __global__ __launch_bounds__(256, 2) void sr_pw_kernel(SrPwParams p) {
   }
 }
 
-int pw_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    else cus = 256;
-  }
-  return cus;
-}
+int pw_num_cus() { return sr_device_cus(); }
 
 struct PwPlan { int nt, ks; };
 

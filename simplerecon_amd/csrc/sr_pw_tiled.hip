@@ -168,16 +168,7 @@ __global__ __launch_bounds__(256, 2) void sr_pw_tiled_kernel(SrPtParams p) {
   }
 }
 
-int pt_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    else cus = 256;
-  }
-  return cus;
-}
+int pt_num_cus() { return sr_device_cus(); }
 
 struct PtPlan { int cfg, ks; };   // cfg: 0 = 64 x 128 (2x2 waves, 2 tiles each), 1 = 128 x 160 (4x1, 5), 2 = 128 x 64 (4x1, 2), 3 = 64 x 64 (2x2, 1)
 constexpr int PT_BM[4] = {64, 128, 128, 64}, PT_BN[4] = {128, 160, 64, 64};

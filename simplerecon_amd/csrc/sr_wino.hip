@@ -692,16 +692,7 @@ int sr_launch_splitk_reduce(const float* part, int ksplit, int64_t part_stride, 
 
 // ------------------------------------------------------------------ C ABI -------------
 
-static int sr_wino_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    else cus = 256;
-  }
-  return cus;
-}
+static int sr_wino_num_cus() { return sr_device_cus(); }
 
 extern "C" size_t sr_wino_packed_weight_floats(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0) return 0;

@@ -1107,16 +1107,7 @@ int w4_current_device() {
   int dev = 0;
   return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < W4_MAX_DEVICES ? dev : 0;
 }
-int w4_num_cus() {
-  static std::atomic<int> cus[W4_MAX_DEVICES];
-  const int dev = w4_current_device();
-  int v = cus[dev].load(std::memory_order_relaxed);
-  if (v == 0) {
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cus[dev].store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
+int w4_num_cus() { return sr_device_cus(); }
 // hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device) instead of once per launch; a device that refuses the
 // size answers SR_ERR_UNSUPPORTED (the caller falls back to the F(2x2) kernel) -- ADVICE r05.
 int w4_allow_lds(const void* kernel, int slot, int bytes) {
