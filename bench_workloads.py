@@ -854,6 +854,7 @@ WORKLOADS = {
     "hero_b1_graph_f16x3_convs": lambda dev, rank: HeroCfg3(dev, rank, B=1, graph=True, split="f16", split_convs=True,
                                                             name="hero_b1_graph_f16x3_convs"),
     "hero_b1_graph": lambda dev, rank: HeroCfg3(dev, rank, B=1, graph=True, name="hero_b1_graph"),
+    "hero_b1_noprior_graph": lambda dev, rank: HeroCfg3(dev, rank, B=1, prior=False, graph=True, name="hero_b1_noprior_graph"),
     "hero_b1_core_graph": lambda dev, rank: HeroCfg3(dev, rank, B=1, with_encoder=False, graph=True,
                                                      name="hero_b1_core_graph"),
     "hero_cfg3_s2": lambda dev, rank: HeroCfg3(dev, rank, streams=2),
