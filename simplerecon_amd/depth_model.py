@@ -59,12 +59,42 @@ class PendingPyramid:
     main stream.  (The side stream always forks from the main stream first -- `side.wait_stream(main)` -- which also
     orders the allocator's reuse of the pyramid buffers behind the previous frame's consumers.)"""
 
-    def __init__(self, stream, feats):
+    def __init__(self, stream, feats, events=None):
         self.stream, self.feats = stream, list(feats)
+        self.events = events   # one per pyramid level, recorded on `stream` right behind the launch that wrote the level
 
     def wait(self):
         torch.cuda.current_stream(self.feats[0].device).wait_stream(self.stream)
         return self.feats
+
+    def levels_from(self, first):
+        """Levels first.. as a sequence whose items join only as much of the encoder as produced them (r06): at batch 1
+        the encoder's ~200 small launches outlast matching encoder + sweep, and the first CVEncoder levels need only the
+        shallow pyramid levels -- they run while stages 5 / 6 of the encoder are still in flight."""
+        return _PendingLevels(self, first)
+
+
+class _PendingLevels:
+    def __init__(self, pending, first):
+        self.pending, self.first = pending, first
+
+    def __len__(self):
+        return len(self.pending.feats) - self.first
+
+    def peek(self):
+        """The tensors without any stream join (shapes / requires_grad checks only -- not for launching work on them)."""
+        return self.pending.feats[self.first:]
+
+    def __getitem__(self, i):
+        p = self.pending
+        if isinstance(i, slice) or i < 0:
+            raise TypeError("pending pyramid levels are taken one at a time, by non-negative index")
+        lvl = self.first + i
+        if p.events is None:
+            p.wait()
+        else:
+            torch.cuda.current_stream(p.feats[lvl].device).wait_event(p.events[lvl])
+        return p.feats[lvl]
 
 
 def tensor_B_to_bM(t, batch_size, num_views):
@@ -245,8 +275,12 @@ class DepthModel(nn.Module):
         if flip:
             cost_volume = torch.flip(cost_volume, (-1,))
         if isinstance(cur_feats, PendingPyramid):
+            # CVEncoder level i joins the encoder's side stream only as far as pyramid level matching_scale + i; the full join
+            # (which a HIP-graph capture and the allocator both need) follows, when the deepest level has been waited for anyway
+            cost_volume_features = self.cost_volume_net(cost_volume, cur_feats.levels_from(o.matching_scale))
             cur_feats = cur_feats.wait()
-        cost_volume_features = self.cost_volume_net(cost_volume, cur_feats[o.matching_scale:])
+        else:
+            cost_volume_features = self.cost_volume_net(cost_volume, cur_feats[o.matching_scale:])
         feats = list(cur_feats[:o.matching_scale]) + cost_volume_features
         depth_outputs = self.depth_decoder(feats)
         for k in list(depth_outputs.keys()):
@@ -289,9 +323,15 @@ class DepthModel(nn.Module):
         if side is None:
             side = self._prior_streams[dev] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        events = []
+
+        def on_level(_x):
+            ev = torch.cuda.Event()
+            ev.record(side)
+            events.append(ev)
         with torch.cuda.stream(side):
-            feats = self.encoder(cur_image)
-        return PendingPyramid(side, feats)
+            feats = self.encoder(cur_image, on_level=on_level)
+        return PendingPyramid(side, feats, events if len(events) == len(feats) else None)
 
     def forward_tensors(self, cur_image, src_image, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK,
                         unbatched_matching_encoder_forward=False, return_mask=False, flip=False):

@@ -174,7 +174,8 @@ class EfficientNetV2SFeatures(nn.Module):
         from . import autograd_ops
         return autograd_ops.grad_wanted([image], self) or autograd_ops.any_batchnorm_training(self)
 
-    def forward(self, image: torch.Tensor) -> List[torch.Tensor]:
+    def forward(self, image: torch.Tensor, on_level=None) -> List[torch.Tensor]:
+        """`on_level(x)`: called right behind the launch that produced a pyramid level (DepthModel records a HIP event there)."""
         if self._train_path(image):
             # training: the same graph on the differentiable operators of train_ops (conv -> BatchNorm per its own mode ->
             # SiLU unfused; drop-path rate 0 like timm's default for this model)
@@ -193,4 +194,6 @@ class EfficientNetV2SFeatures(nn.Module):
             x = stage(x)
             if i in FEATURE_STAGES:
                 feats.append(x)
+                if on_level is not None:
+                    on_level(x)
         return feats

@@ -81,17 +81,20 @@ class CVEncoder(nn.Module):
 
     def forward(self, x, img_feats):
         from . import autograd_ops, ops
-        if autograd_ops.grad_wanted(x, list(img_feats), self):
-            return self._forward_train(x, img_feats)
+        # `img_feats` may be DepthModel's pending pyramid (depth_model._PendingLevels): item i then joins the image-prior encoder's
+        # side stream just far enough for level i -- taken AFTER ds_conv_i has been launched, which does not need it
+        peek = img_feats.peek() if hasattr(img_feats, "peek") else list(img_feats)
+        if autograd_ops.grad_wanted(x, list(peek), self):
+            return self._forward_train(x, [img_feats[i] for i in range(len(peek))])
         outputs = []
         for i in range(self.num_blocks):
             ds = self.convs[f"ds_conv_{i}"]
             c_out = ds.conv2.out_channels
-            feat = img_feats[i]
             ho, wo = ops.conv_out_hw(x.shape[2], x.shape[3], ds.stride)
             # concat buffer [x | img_feats[i]] (reference networks.py:124): ds_conv writes its slice in place
-            buf = ops.empty_nhwc(x.shape[0], c_out + feat.shape[1], ho, wo, x.device)
+            buf = ops.empty_nhwc(x.shape[0], c_out + peek[i].shape[1], ho, wo, x.device)
             ds(x, out=buf[:, :c_out])
+            feat = img_feats[i]
             ops.copy_into(buf[:, c_out:], feat)
             x = self.convs[f"conv_{i}"][1](self.convs[f"conv_{i}"][0](buf))
             outputs.append(x)
