@@ -274,15 +274,25 @@ class DepthModel(nn.Module):
             max_depth=max_depth, return_mask=return_mask)
         if flip:
             cost_volume = torch.flip(cost_volume, (-1,))
-        if isinstance(cur_feats, PendingPyramid):
-            # CVEncoder level i joins the encoder's side stream only as far as pyramid level matching_scale + i; the full join
-            # (which a HIP-graph capture and the allocator both need) follows, when the deepest level has been waited for anyway
-            cost_volume_features = self.cost_volume_net(cost_volume, cur_feats.levels_from(o.matching_scale))
-            cur_feats = cur_feats.wait()
+        if isinstance(cur_feats, PendingPyramid) and isinstance(self.cost_volume_net, CVEncoder) \
+                and isinstance(self.depth_decoder, DepthDecoderPP):
+            # CVEncoder level i joins the encoder's side stream only as far as pyramid level matching_scale + i, and its LAST level
+            # is handed to the decoder as a closure: the decoder first launches the branches of its first column that do not read
+            # it (the full-resolution convolutions among them), then calls it.  The full join (which a HIP-graph capture and the
+            # allocator both need) comes last, when the deepest level has been waited for anyway.
+            pending = cur_feats
+            cost_volume_features, last_level = self.cost_volume_net(cost_volume, pending.levels_from(o.matching_scale),
+                                                                    defer_last=True)
+            shallow = pending.levels_from(0)
+            feats = [shallow[k] for k in range(o.matching_scale)] + cost_volume_features
+            depth_outputs = self.depth_decoder(feats, last_input=last_level)
+            pending.wait()
         else:
+            if isinstance(cur_feats, PendingPyramid):
+                cur_feats = cur_feats.wait()
             cost_volume_features = self.cost_volume_net(cost_volume, cur_feats[o.matching_scale:])
-        feats = list(cur_feats[:o.matching_scale]) + cost_volume_features
-        depth_outputs = self.depth_decoder(feats)
+            feats = list(cur_feats[:o.matching_scale]) + cost_volume_features
+            depth_outputs = self.depth_decoder(feats)
         for k in list(depth_outputs.keys()):
             log_depth = depth_outputs[k].float()
             if flip:

@@ -79,13 +79,18 @@ class CVEncoder(nn.Module):
             outputs.append(x)
         return outputs
 
-    def forward(self, x, img_feats):
+    def forward(self, x, img_feats, defer_last=False):
+        """defer_last=True (inference only): returns (outputs of levels 0 .. n-2, finish) where `finish()` -> the last level's
+        output.  ds_conv of the last level is already launched; `finish` takes the deepest image-prior level (a stream join when
+        the pyramid is still pending) and runs the two blocks that need it.  DepthModel hands `finish` to the decoder, which
+        first launches everything that does not depend on it."""
         from . import autograd_ops, ops
         # `img_feats` may be DepthModel's pending pyramid (depth_model._PendingLevels): item i then joins the image-prior encoder's
         # side stream just far enough for level i -- taken AFTER ds_conv_i has been launched, which does not need it
         peek = img_feats.peek() if hasattr(img_feats, "peek") else list(img_feats)
         if autograd_ops.grad_wanted(x, list(peek), self):
-            return self._forward_train(x, [img_feats[i] for i in range(len(peek))])
+            outs = self._forward_train(x, [img_feats[i] for i in range(len(peek))])
+            return (outs, None) if defer_last else outs
         outputs = []
         for i in range(self.num_blocks):
             ds = self.convs[f"ds_conv_{i}"]
@@ -94,11 +99,15 @@ class CVEncoder(nn.Module):
             # concat buffer [x | img_feats[i]] (reference networks.py:124): ds_conv writes its slice in place
             buf = ops.empty_nhwc(x.shape[0], c_out + peek[i].shape[1], ho, wo, x.device)
             ds(x, out=buf[:, :c_out])
-            feat = img_feats[i]
-            ops.copy_into(buf[:, c_out:], feat)
-            x = self.convs[f"conv_{i}"][1](self.convs[f"conv_{i}"][0](buf))
+
+            def finish(i=i, buf=buf, c_out=c_out):
+                ops.copy_into(buf[:, c_out:], img_feats[i])
+                return self.convs[f"conv_{i}"][1](self.convs[f"conv_{i}"][0](buf))
+            if defer_last and i == self.num_blocks - 1:
+                return outputs, finish
+            x = finish()
             outputs.append(x)
-        return outputs
+        return (outputs, None) if defer_last else outputs
 
 
 _SIDE_STREAMS = {}  # device -> (stream, stream) for DepthDecoderPP's branch parallelism
@@ -176,9 +185,15 @@ class DepthDecoderPP(nn.Module):
             prev_outputs = outputs[::-1]
         return {k: depth_outputs[k] for k in sorted(depth_outputs, reverse=True)}
 
-    def forward(self, input_features):
+    def forward(self, input_features, last_input=None):
+        """`last_input` (inference only): a callable returning the deepest input feature, when `input_features` holds all but that
+        one (CVEncoder.forward(defer_last=True)).  The first column then launches the right / diagonal branches of the nodes that do
+        not read it BEFORE calling it -- the call may join the image-prior encoder's stream, and those branches (the full-resolution
+        convolutions among them) run while the encoder finishes.  Same launches, same inputs: the result does not change."""
         from . import autograd_ops, ops
-        if autograd_ops.grad_wanted(list(input_features), self):
+        if last_input is not None and autograd_ops.grad_wanted(list(input_features), self):
+            input_features, last_input = list(input_features) + [last_input()], None
+        if last_input is None and autograd_ops.grad_wanted(list(input_features), self):
             return self._forward_train(input_features)
         prev_outputs = list(input_features)
         outputs = []
@@ -188,6 +203,26 @@ class DepthDecoderPP(nn.Module):
         if dev.type == "cuda":
             main = torch.cuda.current_stream(dev)
             s1, s2 = self._side_streams(dev)
+        early = {}   # node i of column 1 -> (buf, fork) whose right / diagonal branches are already launched
+        if last_input is not None:
+            for i in range(2, -1, -1):
+                right = self.convs[f"right_conv_{i}0"]
+                c = right.conv2.out_channels
+                x_i = prev_outputs[i]
+                buf = ops.empty_nhwc(x_i.shape[0], c * 3, x_i.shape[2], x_i.shape[3], x_i.device)
+                regions = x_i.shape[0] * ((x_i.shape[2] + 7) // 8) * ((x_i.shape[3] + 15) // 16)
+                fork = small_batch or (dev.type == "cuda" and regions <= self.branch_stream_max_regions)
+                diag = self.convs[f"diag_conv_{i + 1}0"]
+                if fork:
+                    s1.wait_stream(main)
+                    with torch.cuda.stream(s1):
+                        ops.upsample2x(diag(prev_outputs[i + 1]), out=buf[:, c:2 * c])
+                    right(x_i, out=buf[:, :c])
+                else:
+                    right(x_i, out=buf[:, :c])
+                    ops.upsample2x(diag(prev_outputs[i + 1]), out=buf[:, c:2 * c])
+                early[i] = (buf, fork)
+            prev_outputs.append(last_input())
         for j in range(1, 5):
             max_i = 4 - j
             for i in range(max_i, -1, -1):
@@ -196,6 +231,22 @@ class DepthDecoderPP(nn.Module):
                 c = right.conv2.out_channels
                 x_i = prev_outputs[i]
                 n_parts = 3 if i + j != 4 else 2
+                if j == 1 and i in early:
+                    # right / diagonal branches are in flight (or done): the up branch on its stream, then the joins
+                    buf, fork = early.pop(i)
+                    up = self.convs[f"up_conv_{i + 1}{j}"]
+                    if fork:
+                        s2.wait_stream(main)
+                        with torch.cuda.stream(s2):
+                            ops.upsample2x(up(outputs[-1]), out=buf[:, 2 * c:3 * c])
+                        main.wait_stream(s1)
+                        main.wait_stream(s2)
+                    else:
+                        ops.upsample2x(up(outputs[-1]), out=buf[:, 2 * c:3 * c])
+                    in_conv = self.convs[f"in_conv_{i}{j}"]
+                    output = in_conv[1](in_conv[0](buf))
+                    outputs.append(output)
+                    continue
                 buf = ops.empty_nhwc(x_i.shape[0], c * n_parts, x_i.shape[2], x_i.shape[3], x_i.device)
                 regions = x_i.shape[0] * ((x_i.shape[2] + 7) // 8) * ((x_i.shape[3] + 15) // 16)
                 fork = small_batch or (dev.type == "cuda" and regions <= self.branch_stream_max_regions)

@@ -74,3 +74,24 @@ def assert_lowest_cost(lowest, cost_volume, planes_bd, ref_lowest, what=""):
         gap = (srt[:, -1] - srt[:, -2]) / max(np.abs(cv).max(), 1e-30)
         assert (gap[bad] <= 2 * TOL).all(), f"{what}: argmax differs from reference beyond a tie ({bad.sum()} px)"
     return float(bad.mean())
+
+
+def capture_cv_encoder_levels(store, key="levels"):
+    """Forward hook for CVEncoder that leaves its outputs (all levels, in order) in store[key].  Since r06 DepthModel calls the
+    module with defer_last=True: the output is (levels 0 .. n-2, finish) and `finish` -- run later, inside the decoder -- yields
+    the deepest level; the hook wraps it so that its result is recorded too."""
+    def hook(_module, _args, out):
+        if isinstance(out, tuple) and len(out) == 2 and (out[1] is None or callable(out[1])):
+            levels, finish = out
+            store[key] = list(levels)
+            if finish is None:
+                return None
+
+            def recording_finish():
+                last = finish()
+                store[key].append(last)
+                return last
+            return (levels, recording_finish)
+        store[key] = list(out)
+        return None
+    return hook

@@ -19,7 +19,7 @@ import pytest
 import torch
 
 import oracle
-from parity import assert_close, assert_lowest_cost, elementwise_rel_percentiles, mismatch_fraction
+from parity import assert_close, assert_lowest_cost, elementwise_rel_percentiles, mismatch_fraction, capture_cv_encoder_levels
 from simplerecon_amd import depth_model as dm
 from simplerecon_amd import synthetic
 
@@ -67,7 +67,7 @@ class _Case:
         CVEncoder's outputs through forward hooks (the modules are called exactly as forward() calls them)."""
         got = {}
         hooks = [self.model.cost_volume.register_forward_hook(lambda m, a, o: got.__setitem__("cv", o)),
-                 self.model.cost_volume_net.register_forward_hook(lambda m, a, o: got.__setitem__("levels", o))]
+                 self.model.cost_volume_net.register_forward_hook(capture_cv_encoder_levels(got))]
         d = {k: v[frames].to(DEV) for k, v in self.inp.items() if k not in ("min_depth", "max_depth")}
         try:
             with torch.inference_mode():

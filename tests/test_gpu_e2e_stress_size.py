@@ -16,7 +16,7 @@ import pytest
 import torch
 
 import oracle
-from parity import assert_close, assert_lowest_cost, elementwise_rel_percentiles, mismatch_fraction
+from parity import assert_close, assert_lowest_cost, elementwise_rel_percentiles, mismatch_fraction, capture_cv_encoder_levels
 from simplerecon_amd import depth_model as dm
 from simplerecon_amd import synthetic
 
@@ -56,7 +56,7 @@ class _Case:
         got = {}
         m = self.model
         hooks = [m.cost_volume.register_forward_hook(lambda mod, a, o: got.__setitem__("cv", o)),
-                 m.cost_volume_net.register_forward_hook(lambda mod, a, o: got.__setitem__("levels", o))]
+                 m.cost_volume_net.register_forward_hook(capture_cv_encoder_levels(got))]
         d = {k: v[sl].to(DEV) for k, v in self.inp.items() if k not in ("min_depth", "max_depth")}
         with torch.inference_mode():
             out = m.forward_tensors(self.cur[sl].to(DEV), self.src[sl].to(DEV), d["src_extrinsics"], d["src_poses"], d["src_Ks"],
