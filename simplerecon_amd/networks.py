@@ -232,17 +232,13 @@ class DepthDecoderPP(nn.Module):
                 x_i = prev_outputs[i]
                 n_parts = 3 if i + j != 4 else 2
                 if j == 1 and i in early:
-                    # right / diagonal branches are in flight (or done): the up branch on its stream, then the joins
+                    # right / diagonal branches are in flight (or done): nothing is left for this stream to run beside the up
+                    # branch, so it runs here (no fork / join of a third stream), then the join of the diagonal branch
                     buf, fork = early.pop(i)
                     up = self.convs[f"up_conv_{i + 1}{j}"]
+                    ops.upsample2x(up(outputs[-1]), out=buf[:, 2 * c:3 * c])
                     if fork:
-                        s2.wait_stream(main)
-                        with torch.cuda.stream(s2):
-                            ops.upsample2x(up(outputs[-1]), out=buf[:, 2 * c:3 * c])
                         main.wait_stream(s1)
-                        main.wait_stream(s2)
-                    else:
-                        ops.upsample2x(up(outputs[-1]), out=buf[:, 2 * c:3 * c])
                     in_conv = self.convs[f"in_conv_{i}{j}"]
                     output = in_conv[1](in_conv[0](buf))
                     outputs.append(output)
