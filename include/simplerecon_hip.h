@@ -47,7 +47,7 @@ enum {
   SR_OPT_WINO_KSPLIT, SR_OPT_CONV_WINO, SR_OPT_CONV_TILE, SR_OPT_CONV_KSPLIT, SR_OPT_MLP_VEC_STORE, SR_OPT_MLP_XCD,
   SR_OPT_MLP_BWD_VALU, SR_OPT_T16_XCD, SR_OPT_POOL_BW, SR_OPT_POOL_XCD, SR_OPT_PW_NT, SR_OPT_PW_KS, SR_OPT_PT_CFG, SR_OPT_PT_KS,
   SR_OPT_DOT_LDS, SR_OPT_DOT_QUAD, SR_OPT_DOT_LDS_G, SR_OPT_DOT_LDS_CULL, SR_OPT_DOT_LDS_CAP, SR_OPT_GEMM_AUTOTUNE,
-  SR_OPT_UPSAMPLE_QUAD, SR_OPT_POOL_STREAM,
+  SR_OPT_UPSAMPLE_QUAD, SR_OPT_POOL_STREAM, SR_OPT_MLP_RESERVE_CUS,
   SR_OPT_COUNT
 };
 int sr_option_count(void);

@@ -359,6 +359,10 @@ class FeatureVolumeManager(CostVolumeManager):
     # grad mode with parameters that require grad builds an autograd graph; inference runs under no_grad /
     # inference_mode (reference test.py:210).
     differentiable = True
+    # CUs the NEXT sweep leaves to other streams (0: none).  Set and cleared by DepthModel around its own call, never persistent:
+    # a persistent workgroup of the sweep owns its CU, so work on other streams is parked for the whole sweep otherwise.
+    _reserve_cus = 0
+    _reserve_oid = None
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=(202, 128, 128, 1),
                  matching_dim_size=16, num_source_views=7):
@@ -422,7 +426,15 @@ class FeatureVolumeManager(CostVolumeManager):
         sb, sd, sp = self._volume_strides(vol)
         from . import ops   # (ops.PROFILE: bench.py's in-step kernel table)
         prof = ops.PROFILE
+        reserve = int(getattr(self, "_reserve_cus", 0))
         with _lib.SPLIT_GUARD, _lib.on_device(dev):   # (SR_MLP_SPLIT is read by the packing and by the sweep inside this one call)
+            if reserve > 0:
+                # this call only: the persistent grid leaves `reserve` CUs to other streams (DepthModel: the image-prior encoder on
+                # its side stream).  The option table is process-wide; every sweep launched through this module holds the guard.
+                if FeatureVolumeManager._reserve_oid is None:
+                    FeatureVolumeManager._reserve_oid = _lib._option_id("SR_MLP_RESERVE_CUS")
+                prev_reserve = C.c_int(0)
+                _lib.check(lib.sr_option_set(FeatureVolumeManager._reserve_oid, reserve, C.byref(prev_reserve)), "sr_option_set")
             if prof is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
@@ -432,6 +444,8 @@ class FeatureVolumeManager(CostVolumeManager):
                 C.c_float(0.01),  # nn.LeakyReLU default slope (reference networks.py:139)
                 b, k, c, h, w, self.num_depth_bins, _lib.ptr(vol), sb, sd, sp, _lib.ptr(lowest),
                 _lib.ptr(mask), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            if reserve > 0:
+                lib.sr_option_set(FeatureVolumeManager._reserve_oid, prev_reserve.value, C.byref(C.c_int(0)))
             if prof is not None:
                 ev1.record()
                 cin = c * (k + 1) + 10 * k + 4

@@ -996,22 +996,35 @@ extern "C" int sr_mlp_volume_sweep(const float* cur, const float* invK_cur, cons
   p.debug = 0;
 #endif
 
-  const int cus = sr_device_cus();
   // planes per work unit: as many as possible (the hoisted invariant part is paid once per unit) while the
   // units still spread evenly over the 4*CUs persistent waves
-  {
-    const long waves = 4L * cus;
-    int best = 1;
+  auto plan = [&](int ncu, int& chunk) {
+    const long waves = 4L * ncu;
     double best_cost = 1e30;
+    chunk = 1;
     for (int c = SR_PLANE_CHUNK; c >= 1; c >>= 1) {
       const long units = (long)B * p.tiles * ((D + c - 1) / c);
       const long rounds = (units + waves - 1) / waves;
       const double cost = (double)rounds * (c * 1192.0 + 168.0);  // MFMAs per unit: c planes + invariant part
-      if (cost < best_cost) { best_cost = cost; best = c; }
+      if (cost < best_cost) { best_cost = cost; chunk = c; }
     }
-    p.chunk = best;
-    p.chunks = (D + best - 1) / best;
+    return best_cost;
+  };
+  int cus = sr_device_cus(), best = 1;
+  const double full_cost = plan(cus, best);
+  // SR_MLP_RESERVE_CUS = n: the persistent grid leaves n CUs to other streams (one workgroup owns a CU's LDS and registers, so
+  // nothing else starts on a CU of the sweep); the plane chunk is planned for the CUs that remain.  DepthModel sets it around its
+  // own call at small batch, where the image-prior encoder's chain of small launches on the side stream is the critical path
+  // and would be parked for the whole sweep (batch 1, graph replay: 5.72 -> 5.48 ms per frame although the sweep itself takes
+  // 14 % longer).  At batch 8 it costs what it gains (25.4-25.6 vs 25.2-25.5 ms; 27.2 vs 26.5 on the keyframe stream), at
+  // 960x736 / 96 planes it loses 2.4 ms of 46: the caller's decision, by batch size.
+  {
+    const int r = sr_opt(SR_OPT_MLP_RESERVE_CUS);
+    if (r > 0 && cus - r >= 8) { cus -= r; (void)plan(cus, best); }
   }
+  (void)full_cost;
+  p.chunk = best;
+  p.chunks = (D + best - 1) / best;
   p.vec_store = (cv_sd == 1) && (p.chunk % 4 == 0) && (cv_sp % 4 == 0) && (cv_sb % 4 == 0) &&
                 (((uintptr_t)out_cv & 15) == 0);
   if (sr_opt(SR_OPT_MLP_VEC_STORE) == 0) p.vec_store = 0;   // ablation

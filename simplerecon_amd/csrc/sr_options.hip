@@ -25,6 +25,7 @@ const OptDef kDefs[SR_OPT_COUNT] = {
     {"SR_PW_NT", 0, 0},           {"SR_PW_KS", 0, 0},          {"SR_PT_CFG", -1, 0},         {"SR_PT_KS", 0, 0},
     {"SR_DOT_LDS", 1, 0},         {"SR_DOT_QUAD", 1, 0},       {"SR_DOT_LDS_G", 0, 0},       {"SR_DOT_LDS_CULL", 1, 0},
     {"SR_DOT_LDS_CAP", 634, 0},   {"SR_GEMM_AUTOTUNE", 1, 0},  {"SR_UPSAMPLE_QUAD", 1, 0},   {"SR_POOL_STREAM", 1, 0},
+    {"SR_MLP_RESERVE_CUS", 0, 0},
 };
 std::atomic<int> g_val[SR_OPT_COUNT];
 std::once_flag g_once;

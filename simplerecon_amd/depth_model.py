@@ -14,6 +14,7 @@ pluggable (`image_encoder=`, `matching_encoder=`); `timm_image_encoder()` builds
 constructor call when timm is importable.  `hot_path()` starts from the encoders' outputs.
 """
 import contextlib
+import os
 from dataclasses import dataclass
 
 import torch
@@ -174,6 +175,8 @@ class DepthModel(nn.Module):
         self._range_cache = {}
         # run the image-prior encoder on a side HIP stream, concurrently with matching encoder + plane sweep
         self.prior_on_side_stream = True
+        self.sweep_reserved_cus = int(os.environ.get("SR_SWEEP_RESERVED_CUS", "32"))   # see _hot_path_one
+        self.sweep_reserve_max_points = int(os.environ.get("SR_SWEEP_RESERVE_MAX_POINTS", "5000000"))   # batch 4 at 120x160x64
         self._prior_streams = {}
         # opt-in: run both encoders under no_grad when autograd is recording (frozen-encoder fine-tune)
         self.freeze_encoders = False
@@ -268,10 +271,25 @@ class DepthModel(nn.Module):
                       src_K, cur_invK, return_mask=False, flip=False):
         o = self.run_opts
         min_depth, max_depth = self._depth_range(src_K)
-        cost_volume, lowest_cost, _, overall_mask_bhw = self.cost_volume(
-            cur_feats=matching_cur_feats, src_feats=matching_src_feats, src_extrinsics=src_cam_T_cur_cam,
-            src_poses=cur_cam_T_src_cam, src_Ks=src_K, cur_invK=cur_invK, min_depth=min_depth,
-            max_depth=max_depth, return_mask=return_mask)
+        # While the image-prior encoder is still running on its side stream the sweep leaves it `sweep_reserved_cus` CUs: the
+        # sweep's persistent workgroups own their CUs, and the encoder's ~170 small launches would be parked for all of it
+        # -- for sweeps of up to `sweep_reserve_max_points` (pixel, plane) points, where 14 % more sweep time is less than what the
+        # encoder's progress is worth (measured, `profiles/r06_layer_tables.txt`, HIP-graph replays at 640x480 / 64 planes: batch 1
+        # 5.75 -> 5.44 ms, batch 2 8.75 -> 8.26, batch 4 14.21 -> 13.78; 32 of 256 CUs is the optimum, 16 / 24 lose; at batch 8 the
+        # longer sweep costs what the overlap gains, at 960x736 / 96 planes / batch 4 it loses 2.4 ms).
+        reserve = self.sweep_reserved_cus if isinstance(cur_feats, PendingPyramid) and hasattr(self.cost_volume, "_reserve_cus") \
+            and matching_cur_feats.shape[0] * matching_cur_feats.shape[2] * matching_cur_feats.shape[3] \
+            * getattr(self.cost_volume, "num_depth_bins", 1 << 30) <= self.sweep_reserve_max_points else 0
+        if reserve:
+            self.cost_volume._reserve_cus = reserve
+        try:
+            cost_volume, lowest_cost, _, overall_mask_bhw = self.cost_volume(
+                cur_feats=matching_cur_feats, src_feats=matching_src_feats, src_extrinsics=src_cam_T_cur_cam,
+                src_poses=cur_cam_T_src_cam, src_Ks=src_K, cur_invK=cur_invK, min_depth=min_depth,
+                max_depth=max_depth, return_mask=return_mask)
+        finally:
+            if reserve:
+                self.cost_volume._reserve_cus = 0
         if flip:
             cost_volume = torch.flip(cost_volume, (-1,))
         if isinstance(cur_feats, PendingPyramid) and isinstance(self.cost_volume_net, CVEncoder) \
